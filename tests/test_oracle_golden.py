@@ -1,0 +1,252 @@
+"""Pins the CPU oracle (oracle/seekr_oracle.py) to the reference.
+
+Sources of truth, all under tests/golden/ (see make_golden.py):
+  * reference_fixtures.npz  — data files the reference's own tests hold
+  * g1..g6 *.npz, meta.json — outputs of the reference run on seeded inputs
+  * literals re-typed from seekr/tests/test_kmer_counts.py / test_pearson.py
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import seekr_oracle as orc
+from inputs import EXAMPLE_FA, big_count_matrix, skewed_set, synth_2000, write_fasta
+
+
+def sha16(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    out = {name: np.load(os.path.join(golden_dir, name + ".npz")) for name in
+           ("reference_fixtures", "g1_example", "g3_skewed", "g4_synth2000", "g5_bigN", "g6_edges")}
+    with open(os.path.join(golden_dir, "meta.json")) as fh:
+        out["meta"] = json.load(fh)
+    return out
+
+
+@pytest.fixture(scope="module")
+def example_seqs(tmp_path_factory):
+    p = tmp_path_factory.mktemp("fa") / "example.fa"
+    p.write_text(EXAMPLE_FA)
+    headers, seqs = orc.read_fasta(str(p))
+    assert headers == [">SEQ1", ">SEQ2", ">SEQ3", ">SEQ4", ">SEQ5"]
+    return seqs
+
+
+# ------------------------- the reference's own known-answer tests ----------------------
+def test_reader_init(example_seqs):  # test_kmer_counts.py:13-16
+    assert len(example_seqs) == 5 and example_seqs[0] == "AAAAAA"
+
+
+def test_occurrences_literals(example_seqs, gold):  # test_kmer_counts.py:18-42
+    _, m1 = orc.kmer_vocabulary(1)
+    row = orc.occurrences_py(np.zeros(4), example_seqs[0], 1, m1)
+    assert np.allclose(row, [1000, 0, 0, 0])
+    row = orc.occurrences_py(np.zeros(4), example_seqs[1], 1, m1)
+    assert np.allclose(row, [0, 500, 500, 0])
+    _, m2 = orc.kmer_vocabulary(2)
+    row = orc.occurrences_py(np.zeros(16), example_seqs[1], 2, m2)
+    exp = np.zeros(16)
+    exp[5], exp[9], exp[10] = 454.545, 90.909, 454.545
+    assert np.allclose(row, exp)
+    g6 = gold["g6_edges"]
+    assert np.array_equal(row, g6["kat_occ_k2_seq1"])
+    assert np.array_equal(orc.occurrences_py(np.zeros(4), example_seqs[1], 1, m1), g6["kat_occ_k1_seq1"])
+
+
+def test_center_standardize_log2_literals():  # test_kmer_counts.py:44-90
+    x = np.array([[1, 2, 3, 4], [1, -2, 5, 10]], dtype=np.float32)
+    y, _ = orc.center(x)
+    assert np.allclose(y, [[0, 2, -1, -3], [0, -2, 1, 3]])
+    mean = np.ones(4)
+    mean[3] = -1
+    y, _ = orc.center(x, mean)
+    assert np.allclose(y, [[0, 1, 2, 5], [0, -3, 4, 11]])
+    x = np.array([[1, 2, 3, 4], [0, -2, 5, 10]], dtype=np.float32)
+    y, _ = orc.standardize(x)
+    assert np.allclose(y, [[2, 1, 3, 4 / 3], [0, -1, 5, 10 / 3]])
+    y, _ = orc.standardize(x, np.arange(1, 5))
+    assert np.allclose(y, [[1, 1, 1, 1], [0, -1, 5 / 3, 2.5]])
+    assert np.allclose(orc.log2_plus_one(x + 2), np.log2(x + 3))
+
+
+def test_get_counts_k1_literal(example_seqs):  # test_kmer_counts.py:92-106
+    expected = np.array([[2.1798673, 0.27807194, 0.0, 0.5133058],
+                         [0.6370419, 2.1100981, 2.048016, 0.5133058],
+                         [1.2010899, 1.4672222, 1.3604679, 1.8107259],
+                         [1.2073011, 1.3895708, 1.3721647, 1.8666755],
+                         [1.318994, 1.1856667, 1.5349197, 1.6688585]], dtype=np.float32)
+    got, _, _ = orc.get_counts(example_seqs, k=1)
+    assert np.allclose(got, expected, rtol=1e-4, atol=1e-5)
+
+
+def test_pearson_literals(gold):  # test_pearson.py:7-24
+    c1 = np.array([[8, 5, 6, 9, 2], [8, 3, 6, 6, 7], [7, 7, 3, 3, 7]])
+    c2 = np.array([[2, 8, -9, -1, -8], [-4, 1, 2, -1, 2], [5, -3, -7, 2, -9]])
+    exp = np.array([[0.3217847, -0.71611487, 0.85110363],
+                    [-0.52756992, -0.47172818, 0.22652512],
+                    [0.43762719, -0.17902872, 0.01547461]])
+    got = orc.pearson(c1, c2)
+    assert np.allclose(got, exp)
+    assert np.array_equal(got, gold["g6_edges"]["kat_pearson_int"])
+    one = np.array([[1, 2, 3, 4], [2, 4, 6, 8]])
+    assert np.allclose(orc.pearson(one, one), np.ones((2, 2)))
+
+
+def test_reference_data_fixtures(example_seqs, gold):  # test_console_scripts.py:34-124
+    fx = gold["reference_fixtures"]
+    full, _, _ = orc.get_counts(example_seqs, k=2)
+    assert np.allclose(full, fx["example_2mers_counts"])
+    raw3 = orc.raw_counts(example_seqs, 3)
+    assert np.allclose(raw3, fx["example_3mers_raw_csv"])
+    # %1.6f text round trip is how the reference's CSV test compares
+    txt = np.array([[float("%1.6f" % v) for v in r] for r in raw3])
+    assert np.array_equal(txt, fx["example_3mers_raw_csv"])
+    vec, _, _ = orc.get_counts(example_seqs, k=2, mean=fx["example_mean"], std=fx["example_std"])
+    assert np.allclose(vec, fx["example_2mers_count"])
+    _, mean, std = orc.get_counts(example_seqs, k=2, log2="Log2.none")
+    assert np.allclose(mean, fx["example_mean"]) and np.allclose(std, fx["example_std"])
+
+
+# ------------------------- vectors captured from the reference -------------------------
+def test_g1_example_bitexact(example_seqs, gold):
+    g1 = gold["g1_example"]
+    for k in (1, 2, 3):
+        raw = orc.raw_counts(example_seqs, k)
+        assert np.array_equal(bits(raw), bits(g1["raw_k%d" % k])), k
+        assert np.array_equal(bits(orc.raw_counts_py(example_seqs, k)), bits(raw))
+        assert sha16(raw) == gold["meta"]["example_raw_k%d_sha" % k]
+    assert orc.count_kmers_u32(example_seqs, 2).sum(axis=1).tolist() == [5, 11, 15, 74, 75]
+    for k in (1, 2):
+        for tag in ("post", "pre", "none"):
+            mode = "Log2." + tag
+            with np.errstate(all="ignore"):
+                x, mean, std = orc.get_counts(example_seqs, k=k, log2=mode)
+                assert np.array_equal(bits(mean), bits(g1["full_%s_k%d_mean" % (tag, k)]))
+                assert np.array_equal(bits(std), bits(g1["full_%s_k%d_std" % (tag, k)]))
+                assert np.array_equal(bits(x), bits(g1["full_%s_k%d" % (tag, k)])), (tag, k)
+                v, _, _ = orc.get_counts(example_seqs, k=k, log2=mode, mean=g1["mean_none_k%d" % k],
+                                         std=g1["std_none_k%d" % k])
+                assert np.array_equal(bits(v), bits(g1["vec_%s_k%d" % (tag, k)]))
+                mo, _, _ = orc.get_counts(example_seqs, k=k, log2=mode, mean=True, std=False)
+                assert np.array_equal(bits(mo), bits(g1["meanonly_%s_k%d" % (tag, k)]))
+
+
+def test_g3_skewed_sets(gold):
+    g3 = gold["g3_skewed"]
+    s1, s2 = skewed_set(101, 111), skewed_set(202, 151)
+    assert np.array_equal(bits(orc.raw_counts(s1, 4)), bits(g3["s1_raw_k4"]))
+    for k in (4, 5):
+        x, mean, std = orc.get_counts(s1, k=k)
+        assert np.array_equal(bits(mean), bits(g3["mean_k%d" % k]))
+        assert np.array_equal(bits(std), bits(g3["std_k%d" % k]))
+        c1, _, _ = orc.get_counts(s1, k=k, mean=mean, std=std)
+        c2, _, _ = orc.get_counts(s2, k=k, mean=mean, std=std)
+        if k == 4:
+            assert np.array_equal(bits(x), bits(g3["s1_self_default_k4"]))
+            assert np.array_equal(bits(c1), bits(g3["s1_counts_k4"]))
+        r = orc.pearson(c1, c2)
+        assert r.dtype == np.float32 and r.shape == (111, 151)
+        assert np.allclose(r, g3["pearson_k%d" % k], rtol=1e-5, atol=2e-6)
+    with np.errstate(all="ignore"):
+        x6, m6, s6 = orc.get_counts(s1, k=6)
+        c6, _, _ = orc.get_counts(s2, k=6, mean=m6, std=s6)
+        assert np.isnan(x6).all() and np.isnan(c6).all() and np.isnan(orc.pearson(x6, c6)).all()
+    a, b = g3["s1_counts_k4"][:7], g3["s1_counts_k4"][7:12]
+    assert np.allclose(orc.pearson(a, b, row_standardize=False), g3["pearson_nostd"], rtol=1e-5, atol=2e-6)
+    assert np.allclose(orc.pearson(a.astype(np.float64), b.astype(np.float64)), g3["pearson_f64"],
+                       rtol=1e-12, atol=1e-14)
+    assert orc.pearson(a, b.astype(np.float64)).dtype == np.float64
+
+
+def test_g4_synthetic_2000(gold):
+    g4, meta = gold["g4_synth2000"], gold["meta"]
+    seqs = synth_2000()
+    n = orc.count_kmers_u32(seqs, 6)
+    assert sha16(n) == meta["g4_u32_sha"] and int(n.sum()) == meta["g4_u32_sum"] == 2000 * 1995
+    raw = orc.per_kb_from_counts(n, [2000] * 2000, 6)
+    assert sha16(raw) == meta["g4_raw_sha"]
+    # structure-faithful python loop on a prefix (the slow path)
+    assert np.array_equal(bits(orc.raw_counts_py(seqs[:40], 6)), bits(raw[:40]))
+    for tag in ("post", "pre", "none"):
+        x, mean, std = orc.normalize(raw, log2="Log2." + tag)
+        assert np.array_equal(bits(mean), bits(g4["mean_" + tag])), tag
+        assert np.array_equal(bits(std), bits(g4["std_" + tag])), tag
+        assert np.array_equal(bits(x[:8]), bits(g4["counts_%s_head" % tag])), tag
+        assert sha16(x) == meta["g4_counts_%s_sha" % tag]
+        assert np.allclose(orc.pearson(x[:256], x[:256]), g4["pearson256_" + tag], rtol=1e-5, atol=2e-6)
+
+
+def test_g5_large_n_rowsequential_drift(gold):
+    """np.mean/np.std(axis=0) in the reference are strictly row-sequential float32 sums."""
+    g5 = gold["g5_bigN"]
+    big = big_count_matrix()
+    mean = orc.column_mean_f32(big)
+    assert np.array_equal(bits(mean), bits(g5["mean"]))
+    big -= mean
+    std = orc.column_std_f32(big)
+    assert np.array_equal(bits(std), bits(g5["std"]))
+    assert np.array_equal(bits(big[0] / std), bits(g5["z_row0"]))
+    assert np.array_equal(bits(big[-1] / std), bits(g5["z_rowlast"]))
+    # the same numpy build is on this box: the restatement must equal numpy's own reduce
+    assert np.array_equal(bits(np.std(big, axis=0)), bits(std))
+    # monotone-rounding shortcut used on the GPU: global min of z from per-column minima
+    with np.errstate(all="ignore"):
+        zmin = np.min((big.min(axis=0) / std).astype(np.float32))
+    assert np.float32(zmin) == g5["z_min"]
+
+
+def test_g6_edges(example_seqs, gold, tmp_path):
+    g6, edge = gold["g6_edges"], gold["meta"]["edge"]
+    raw = orc.raw_counts(edge["edge_seqs"], 3)
+    assert np.array_equal(bits(raw), bits(g6["edge_raw_k3"]))
+    assert np.array_equal(bits(orc.raw_counts_py(edge["edge_seqs"], 3)), bits(raw))
+    with pytest.raises(ZeroDivisionError):
+        orc.raw_counts(["ACGTAC", "AC"], 3)
+    with pytest.raises(ZeroDivisionError):
+        orc.raw_counts_py(["ACGTAC", "AC"], 3)
+    assert np.array_equal(bits(orc.raw_counts(example_seqs, 2, "ACGT")), bits(g6["raw_k2_ACGT"]))
+    # reader semantics
+    rs = skewed_set(303, 6, 50, 200)
+    p = str(tmp_path / "ml.fa")
+    write_fasta(p, rs, width=60, crlf=True, lower=True)
+    headers, seqs = orc.read_fasta(p)
+    assert seqs == rs and headers == edge["reader_headers"]
+    for name, text, exc in (("blank_line", ">a\nACGT\n\n>b\nACGT\n", IndexError),
+                            ("double_header", ">a\nACGT\n>b\n>c\nACGT\n", AssertionError)):
+        q = tmp_path / (name + ".fa")
+        q.write_text(text)
+        with pytest.raises(exc) as info:
+            orc.read_fasta(str(q))
+        assert edge["reader_" + name] == type(info.value).__name__ + ": " + str(info.value)
+    with np.errstate(all="ignore"):
+        x, _, _ = orc.get_counts(example_seqs, k=3, log2="Log2.none")
+        assert np.array_equal(bits(x), bits(g6["example_k3_none_with_nan"]))
+        x, _, _ = orc.get_counts(example_seqs, k=3, log2="Log2.post")
+        assert np.isnan(x).all() and np.isnan(g6["example_k3_post_with_nan"]).all()
+        x, _, _ = orc.get_counts(example_seqs, k=1, log2="Log2.none",
+                                 mean=np.array([100.0, 200.5, 300.25, 50.125]), std=np.array([3, 7, 11, 13]))
+        assert np.array_equal(bits(x), bits(g6["user_vec_f64_int_k1"]))
+        m = np.array([[1, 2, 3, 4], [5, 5, 5, 5], [4, 1, 3, 2]], dtype=np.float32)
+        r = orc.pearson(m, m)
+        assert np.array_equal(np.isnan(r), np.isnan(g6["pearson_const_row"]))
+        assert np.allclose(r, g6["pearson_const_row"], equal_nan=True)
+    with pytest.raises(ValueError):
+        orc.pearson(np.zeros((2, 4), np.float32), np.zeros((2, 5), np.float32), row_standardize=False)
+    with pytest.raises(ValueError):
+        orc.normalize(np.zeros((2, 4), np.float32), log2="log2")
+
+
+def test_synthetic_prefix_property():
+    a = orc.synthetic_codes(2, 25, 100, start=9_990)
+    b = orc.synthetic_codes(2, 10_015, 100)
+    assert np.array_equal(a, b[9_990:])
