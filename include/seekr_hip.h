@@ -1,0 +1,184 @@
+/* seekr_hip.h — C-ABI of libseekr_hip.so, the MI355X (gfx950) implementation of SEEKR's
+ * k-mer counting + column normalisation + all-pairs Pearson hot path.
+ *
+ * The reference (CalabreseLab/seekr v2.0.2) is pure Python and has no FFI of its own
+ * (SURVEY.md §8b); the boundary it exposes for this path is its Python API.  Every entry
+ * point below therefore cites the reference *Python* lines whose result it must reproduce;
+ * `seekr_amd/` is the ctypes host that re-creates the reference classes on top of these
+ * symbols, and INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; no exceptions, no callbacks, no torch types
+ *   - every function returns an int status (SKR_OK == 0, negative == error) and leaves a
+ *     human-readable message retrievable with skr_last_error() (thread-local)
+ *   - the caller owns every host buffer; the library owns device memory behind the opaque
+ *     handles (skr_ctx / skr_seqs / skr_mat) until the matching *_free / *_destroy
+ *   - one skr_ctx == one GPU + one HIP stream; work submitted through a ctx is ordered on
+ *     that stream; functions that fill host memory synchronise before returning
+ *   - matrices are dense row-major (C order), float32 unless stated otherwise
+ */
+#ifndef SEEKR_HIP_H
+#define SEEKR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SKR_ABI_VERSION 1
+
+/* status codes */
+enum {
+    SKR_OK = 0,
+    SKR_ERR_INVALID = -1,     /* bad argument (NULL, shape/dtype mismatch, k out of range …)      */
+    SKR_ERR_HIP = -2,         /* a HIP runtime call failed (message carries hipGetErrorString)    */
+    SKR_ERR_NOMEM = -3,       /* host or device allocation failed                                 */
+    SKR_ERR_UNSUPPORTED = -4, /* valid request the device path does not implement                 */
+    SKR_ERR_ZERODIV = -5,     /* a sequence has len == k-1 (kmer_counts.py:144 ZeroDivisionError) */
+    SKR_ERR_COMM = -6,        /* RCCL failure / communicator not initialised                      */
+    SKR_ERR_IO = -7,          /* file could not be read                                           */
+    SKR_ERR_FASTA_BLANK = -8, /* blank line in FASTA (fasta_reader.py:53 IndexError)              */
+    SKR_ERR_FASTA_HEADER = -9 /* header without sequence (fasta_reader.py:58 AssertionError)      */
+};
+
+/* element types of a skr_mat */
+enum { SKR_F32 = 0, SKR_F64 = 1, SKR_U32 = 2 };
+
+/* log2 handling of BasicCounter (kmer_counts.py:201-209) */
+enum { SKR_LOG2_NONE = 0, SKR_LOG2_PRE = 1, SKR_LOG2_POST = 2 };
+
+/* arithmetic of the Pearson contraction (pearson.py:41) */
+enum {
+    SKR_PREC_FP32 = 0,   /* v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulate           */
+    SKR_PREC_BF16X3 = 1, /* split-bf16: hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16       */
+    SKR_PREC_F64 = 2     /* v_mfma_f64_16x16x4_f64 (float64 inputs: CSV / integer count files)   */
+};
+
+typedef struct skr_ctx skr_ctx;   /* one GPU + one stream + scratch + optional RCCL communicator */
+typedef struct skr_seqs skr_seqs; /* a set of sequences packed 2 bits/base, resident in HBM      */
+typedef struct skr_mat skr_mat;   /* a row-major device matrix                                   */
+
+/* ---------------------------------------------------------------- library / context ---- */
+const char* skr_last_error(void);
+int skr_abi_version(void);
+int skr_device_count(int* count);
+int skr_ctx_create(int device, skr_ctx** out);
+int skr_ctx_destroy(skr_ctx* ctx);
+int skr_ctx_sync(skr_ctx* ctx);
+int skr_ctx_device(const skr_ctx* ctx, int* device);
+/* device-side timing of every kernel launched through the ctx (HIP events on the ctx stream) */
+int skr_prof_enable(skr_ctx* ctx, int on);
+int skr_prof_reset(skr_ctx* ctx);
+/* total milliseconds and launch count recorded for kernels whose name starts with `prefix` */
+int skr_prof_query(skr_ctx* ctx, const char* prefix, double* total_ms, int64_t* launches);
+/* names of all recorded kernels, '\n'-separated, into buf (truncated to cap-1 chars) */
+int skr_prof_names(skr_ctx* ctx, char* buf, int64_t cap);
+
+/* ---------------------------------------------------------------- device matrices ------ */
+int skr_mat_create(skr_ctx* ctx, int64_t rows, int64_t cols, int dtype, skr_mat** out);
+int skr_mat_free(skr_mat* m);
+int skr_mat_shape(const skr_mat* m, int64_t* rows, int64_t* cols, int* dtype);
+/* copy `nrows` rows starting at `row0` between a dense host buffer and the matrix */
+int skr_mat_upload(skr_mat* m, const void* host, int64_t row0, int64_t nrows);
+int skr_mat_download(const skr_mat* m, void* host, int64_t row0, int64_t nrows);
+int skr_mat_fill_zero(skr_mat* m);
+/* raw device pointer (for RCCL / interop); valid until skr_mat_free */
+int skr_mat_device_ptr(const skr_mat* m, void** ptr);
+
+/* ---------------------------------------------------------------- sequences (K1) -------- */
+/* Pack `n` sequences given as one concatenated ASCII buffer + n+1 byte offsets.
+ * alphabet[c] is the character whose code is c (kmer_counts.py:121-122: code = position in
+ * `alphabet`, default "AGTC"); any other byte marks every window that covers it as skipped
+ * (kmer_counts.py:149).  No case folding is applied here (the reader upper-cases,
+ * fasta_reader.py:55,62; a caller assigning `seqs` directly gets lower case skipped).      */
+int skr_seqs_pack(skr_ctx* ctx, const char* bases, const int64_t* offsets, int64_t n,
+                  const char alphabet[4], skr_seqs** out);
+/* Read + pack a FASTA file with the reference reader's semantics (fasta_reader.py:41-63):
+ * lines stripped, '>' first char == header, other lines concatenated and upper-cased.
+ * Headers are returned through skr_seqs_headers.                                            */
+int skr_seqs_from_fasta(skr_ctx* ctx, const char* path, const char alphabet[4], skr_seqs** out);
+int skr_seqs_free(skr_seqs* s);
+int skr_seqs_info(const skr_seqs* s, int64_t* n, int64_t* total_bases, int64_t* max_len);
+/* lengths[n] (int64) of the packed sequences */
+int skr_seqs_lengths(const skr_seqs* s, int64_t* lengths);
+/* FASTA headers ('\n'-joined, including the leading '>'); *needed receives the byte count   */
+int skr_seqs_headers(const skr_seqs* s, char* buf, int64_t cap, int64_t* needed);
+
+/* ---------------------------------------------------------------- counting (K2+K3) ------ */
+/* Integer surface: out[i, j] = number of windows of sequence i equal to k-mer j
+ * (kmer_counts.py:142-150 before scaling).  `out` is a SKR_U32 matrix [n, 4^k].            */
+int skr_count_u32(skr_ctx* ctx, const skr_seqs* s, int k, skr_mat* out);
+/* Per-kb matrix exactly as BasicCounter.get_counts fills it (kmer_counts.py:194-200):
+ * out[i, j] = float32(sum of n[i,j] float64 additions of 1000/(L_i-k+1)).  `out` is
+ * SKR_F32 or SKR_F64 [n, 4^k].  log2_pre != 0 additionally applies log2(x + 1)
+ * (kmer_counts.py:201-202, 189-192) in the same pass (SKR_F32 only).
+ * Returns SKR_ERR_ZERODIV if any sequence has length k-1.                                   */
+int skr_count_per_kb(skr_ctx* ctx, const skr_seqs* s, int k, int log2_pre, skr_mat* out);
+
+/* ---------------------------------------------------------------- normalisation (K4+K5) - */
+/* Sequential float32 column sums in row order, continuing from `acc` (1 x cols, SKR_F32):
+ *     acc[j] = fl32(acc[j] + t(x[i, j]))   for i = 0 .. rows-1
+ * t(x) = x                                   (center == NULL, square == 0)
+ * t(x) = fl32(x - center[j])                 (center given; f64 center: round once from f64)
+ * t(x) = fl32(d*d), d = fl32(t_prev(x) - center2[j])   (square != 0; center2 may be NULL)
+ * This is the order numpy's axis-0 reduce uses in the reference (kmer_counts.py:168,174;
+ * SURVEY Appendix A.4) and is what makes mean/std bit-identical.  A multi-GPU run passes
+ * `acc` from rank to rank.                                                                   */
+int skr_colsum_seq(skr_ctx* ctx, const skr_mat* x, const skr_mat* center, const skr_mat* center2,
+                   int square, skr_mat* acc);
+/* v[j] = fl32(v[j] / fl32(n));  if take_sqrt: v[j] = sqrt_rn(that)  (np.mean / np.std tail) */
+int skr_vec_finish(skr_ctx* ctx, skr_mat* v, int64_t n, int take_sqrt);
+/* NaN-propagating minimum (np.min, kmer_counts.py:208) of z = (x - center) / scale over the
+ * whole matrix, plus whether any z is NaN (kmer_counts.py:176).  center/scale may be NULL.  */
+int skr_min_nan(skr_ctx* ctx, const skr_mat* x, const skr_mat* center, const skr_mat* scale,
+                float* min_out, int* has_nan);
+/* y = post(scale(center(pre(x)))) elementwise, y may alias x:
+ *   pre    : log2(x + 1)                                  (kmer_counts.py:189-192)
+ *   center : x - center[j]                                (:169)
+ *   scale  : x / scale[j]   (IEEE division)               (:175)
+ *   post   : log2(fl32(fl32(x + shift) + 1))              (:208-209, shift = |min|)
+ * has_nan (optional) reports NaN after the scale step (the warning condition, :176).        */
+int skr_apply(skr_ctx* ctx, const skr_mat* x, int pre, const skr_mat* center, const skr_mat* scale,
+              int post, float shift, skr_mat* y, int* has_nan);
+/* Whole single-GPU pipeline of get_counts after counting (kmer_counts.py:201-209), in place.
+ * mean_mode / std_mode: 0 = skip, 1 = compute (written to mean_out / std_out, 1 x cols F32),
+ * 2 = use the supplied vector (mean_vec / std_vec, 1 x cols, F32 or F64).                   */
+int skr_normalize(skr_ctx* ctx, skr_mat* x, int log2_mode, int mean_mode, const skr_mat* mean_vec,
+                  int std_mode, const skr_mat* std_vec, skr_mat* mean_out, skr_mat* std_out,
+                  int* has_nan);
+
+/* ---------------------------------------------------------------- Pearson (K6+K7) ------- */
+/* z = row-standardised x (pearson.py:35-38): per row, subtract the mean, divide by the
+ * population std of the centred row.  F32 -> F32 or F64 -> F64, same shape.                 */
+int skr_row_standardize(skr_ctx* ctx, const skr_mat* x, skr_mat* z);
+/* r[row0 + i, col0 + j] = <a_i, b_j> / K   (pearson.py:41) for all rows of a and b.
+ * a: [M, K], b: [N, K], r: at least [row0+M, col0+N]; dtype F32 (precision FP32 or BF16X3)
+ * or F64 (precision F64).  symmetric != 0 promises a and b hold the same rows and
+ * row0 == col0, letting the kernel compute one triangle and mirror it.                      */
+int skr_pearson_gemm(skr_ctx* ctx, const skr_mat* a, const skr_mat* b, int precision, int symmetric,
+                     skr_mat* r, int64_t row0, int64_t col0);
+/* pearson(counts1, counts2, row_standardize) end to end on device matrices                 */
+int skr_pearson(skr_ctx* ctx, const skr_mat* counts1, const skr_mat* counts2, int row_standardize,
+                int precision, skr_mat* r);
+
+/* ---------------------------------------------------------------- multi-GPU (C1, C2) ---- */
+/* One process per GPU.  Rank 0 creates an id and distributes the 128 bytes out of band.    */
+int skr_comm_unique_id(char id[128]);
+int skr_comm_init(skr_ctx* ctx, int nranks, int rank, const char id[128]);
+int skr_comm_destroy(skr_ctx* ctx);
+int skr_comm_barrier(skr_ctx* ctx);
+/* send rows [srow0, srow0+snrows) of `src` to `dst_rank` and receive rows into `dst` from
+ * `src_rank` as one grouped RCCL operation on the ctx's communication stream; either side
+ * may be skipped with rank < 0.  Completion is tracked per call: the returned ticket can be
+ * waited on by the compute stream with skr_comm_wait.                                       */
+int skr_comm_sendrecv(skr_ctx* ctx, const skr_mat* src, int64_t srow0, int64_t snrows, int dst_rank,
+                      skr_mat* dst, int64_t drow0, int64_t dnrows, int src_rank, int64_t* ticket);
+int skr_comm_wait(skr_ctx* ctx, int64_t ticket);
+/* all-reduce of a few host doubles (op: 0 = sum, 1 = max, 2 = min)                          */
+int skr_comm_allreduce_f64(skr_ctx* ctx, double* values, int n, int op);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEEKR_HIP_H */

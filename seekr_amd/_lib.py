@@ -1,0 +1,429 @@
+"""ctypes binding of libseekr_hip.so (see include/seekr_hip.h) plus thin RAII wrappers.
+
+There is deliberately NO fallback: if the HIP library is missing or no MI355X is visible
+every compute entry point raises.  `import seekr_amd` itself stays importable on a CPU-only
+box so that the build step and the host-logic tests can run there.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libseekr_hip.so")
+
+SKR_OK = 0
+F32, F64, U32 = 0, 1, 2
+LOG2_NONE, LOG2_PRE, LOG2_POST = 0, 1, 2
+PREC_FP32, PREC_BF16X3, PREC_F64 = 0, 1, 2
+LOG2_CODES = {"Log2.none": LOG2_NONE, "Log2.pre": LOG2_PRE, "Log2.post": LOG2_POST}
+PRECISIONS = {"fp32": PREC_FP32, "bf16x3": PREC_BF16X3, "f64": PREC_F64}
+_NP_OF = {F32: np.float32, F64: np.float64, U32: np.uint32}
+_CODE_OF = {np.dtype(np.float32): F32, np.dtype(np.float64): F64, np.dtype(np.uint32): U32}
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_int = C.c_int
+
+# name -> (restype, argtypes); every symbol include/seekr_hip.h declares
+SIGNATURES = {
+    "skr_last_error": (C.c_char_p, []),
+    "skr_abi_version": (_int, []),
+    "skr_device_count": (_int, [C.POINTER(_int)]),
+    "skr_ctx_create": (_int, [_int, C.POINTER(_p)]),
+    "skr_ctx_destroy": (_int, [_p]),
+    "skr_ctx_sync": (_int, [_p]),
+    "skr_ctx_device": (_int, [_p, C.POINTER(_int)]),
+    "skr_prof_enable": (_int, [_p, _int]),
+    "skr_prof_reset": (_int, [_p]),
+    "skr_prof_query": (_int, [_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "skr_prof_names": (_int, [_p, C.c_char_p, _i64]),
+    "skr_mat_create": (_int, [_p, _i64, _i64, _int, C.POINTER(_p)]),
+    "skr_mat_free": (_int, [_p]),
+    "skr_mat_shape": (_int, [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_int)]),
+    "skr_mat_upload": (_int, [_p, _p, _i64, _i64]),
+    "skr_mat_download": (_int, [_p, _p, _i64, _i64]),
+    "skr_mat_fill_zero": (_int, [_p]),
+    "skr_mat_device_ptr": (_int, [_p, C.POINTER(_p)]),
+    "skr_seqs_pack": (_int, [_p, _p, _p, _i64, C.c_char_p, C.POINTER(_p)]),
+    "skr_seqs_from_fasta": (_int, [_p, C.c_char_p, C.c_char_p, C.POINTER(_p)]),
+    "skr_seqs_free": (_int, [_p]),
+    "skr_seqs_info": (_int, [_p, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "skr_seqs_lengths": (_int, [_p, _p]),
+    "skr_seqs_headers": (_int, [_p, C.c_char_p, _i64, C.POINTER(_i64)]),
+    "skr_count_u32": (_int, [_p, _p, _int, _p]),
+    "skr_count_per_kb": (_int, [_p, _p, _int, _int, _p]),
+    "skr_colsum_seq": (_int, [_p, _p, _p, _p, _int, _p]),
+    "skr_vec_finish": (_int, [_p, _p, _i64, _int]),
+    "skr_min_nan": (_int, [_p, _p, _p, _p, C.POINTER(C.c_float), C.POINTER(_int)]),
+    "skr_apply": (_int, [_p, _p, _int, _p, _p, _int, C.c_float, _p, C.POINTER(_int)]),
+    "skr_normalize": (_int, [_p, _p, _int, _int, _p, _int, _p, _p, _p, C.POINTER(_int)]),
+    "skr_row_standardize": (_int, [_p, _p, _p]),
+    "skr_pearson_gemm": (_int, [_p, _p, _p, _int, _int, _p, _i64, _i64]),
+    "skr_pearson": (_int, [_p, _p, _p, _int, _int, _p]),
+    "skr_comm_unique_id": (_int, [C.c_char_p]),
+    "skr_comm_init": (_int, [_p, _int, _int, C.c_char_p]),
+    "skr_comm_destroy": (_int, [_p]),
+    "skr_comm_barrier": (_int, [_p]),
+    "skr_comm_sendrecv": (_int, [_p, _p, _i64, _i64, _int, _p, _i64, _i64, _int, C.POINTER(_i64)]),
+    "skr_comm_wait": (_int, [_p, _i64]),
+    "skr_comm_allreduce_f64": (_int, [_p, C.POINTER(C.c_double), _int, _int]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class SeekrHipError(RuntimeError):
+    """A HIP / RCCL runtime failure inside libseekr_hip."""
+
+
+def lib():
+    """Load libseekr_hip.so once; raise ImportError (never fall back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "seekr_amd: {} is missing — build it with `python -m seekr_amd.build` "
+                "(hipcc, gfx950). There is no CPU fallback.".format(LIB_PATH))
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the .so is stale
+            fn.restype = res
+            fn.argtypes = args
+        if handle.skr_abi_version() != 1:
+            raise ImportError("seekr_amd: libseekr_hip.so has ABI {}, expected 1".format(handle.skr_abi_version()))
+        _lib = handle
+    return _lib
+
+
+_EXC = {
+    -1: ValueError,
+    -2: SeekrHipError,
+    -3: MemoryError,
+    -4: NotImplementedError,
+    -5: ZeroDivisionError,
+    -6: SeekrHipError,
+    -7: OSError,
+    -8: IndexError,
+    -9: AssertionError,
+}
+
+
+def check(rc):
+    if rc == SKR_OK:
+        return
+    msg = lib().skr_last_error().decode("utf-8", "replace")
+    raise _EXC.get(rc, SeekrHipError)(msg)
+
+
+def device_count():
+    n = _int(0)
+    rc = lib().skr_device_count(C.byref(n))
+    return n.value if rc == SKR_OK else 0
+
+
+class Context:
+    """One GPU + one stream (skr_ctx)."""
+
+    def __init__(self, device=0):
+        self._h = _p()
+        self.device = device
+        check(lib().skr_ctx_create(int(device), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().skr_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    def sync(self):
+        check(lib().skr_ctx_sync(self._h))
+
+    # ---- profiling -----------------------------------------------------------------
+    def prof_enable(self, on=True):
+        check(lib().skr_prof_enable(self._h, 1 if on else 0))
+
+    def prof_reset(self):
+        check(lib().skr_prof_reset(self._h))
+
+    def prof_query(self, prefix):
+        ms, cnt = C.c_double(0), _i64(0)
+        check(lib().skr_prof_query(self._h, prefix.encode(), C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+    def prof_names(self):
+        buf = C.create_string_buffer(4096)
+        check(lib().skr_prof_names(self._h, buf, 4096))
+        return [s for s in buf.value.decode().split("\n") if s]
+
+    # ---- factories ------------------------------------------------------------------
+    def empty(self, rows, cols, dtype=np.float32):
+        return Matrix(self, rows, cols, dtype)
+
+    def zeros(self, rows, cols, dtype=np.float32):
+        m = Matrix(self, rows, cols, dtype)
+        check(lib().skr_mat_fill_zero(m._h))
+        return m
+
+    def from_numpy(self, a):
+        a = np.ascontiguousarray(a)
+        if a.ndim == 1:
+            a = a.reshape(1, -1)
+        if a.ndim != 2:
+            raise ValueError("expected a 1-D or 2-D array")
+        m = Matrix(self, a.shape[0], a.shape[1], a.dtype)
+        m.upload(a)
+        return m
+
+    def pack(self, seqs, alphabet="AGTC"):
+        return PackedSeqs.from_strings(self, seqs, alphabet)
+
+    def pack_fasta(self, path, alphabet="AGTC"):
+        return PackedSeqs.from_fasta(self, path, alphabet)
+
+
+_default_ctx = {}
+
+
+def default_context():
+    """Process-wide context on device $SEEKR_DEVICE (default 0)."""
+    dev = int(os.environ.get("SEEKR_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    ctx = _default_ctx.get(dev)
+    if ctx is None:
+        ctx = _default_ctx[dev] = Context(dev)
+    return ctx
+
+
+class Matrix:
+    """Row-major device matrix (skr_mat)."""
+
+    def __init__(self, ctx, rows, cols, dtype=np.float32):
+        code = _CODE_OF.get(np.dtype(dtype))
+        if code is None:
+            raise TypeError("device matrices are float32, float64 or uint32 (got {})".format(dtype))
+        self.ctx = ctx
+        self.rows, self.cols, self.dtype = int(rows), int(cols), np.dtype(dtype)
+        self._h = _p()
+        check(lib().skr_mat_create(ctx._h, self.rows, self.cols, code, C.byref(self._h)))
+
+    @property
+    def shape(self):
+        return (self.rows, self.cols)
+
+    def free(self):
+        if getattr(self, "_h", None):
+            lib().skr_mat_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def upload(self, a, row0=0):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        if a.ndim == 1:
+            a = a.reshape(1, -1)
+        if a.shape[1] != self.cols:
+            raise ValueError("column count mismatch")
+        check(lib().skr_mat_upload(self._h, a.ctypes.data_as(_p), int(row0), a.shape[0]))
+
+    def to_numpy(self, row0=0, nrows=None, out=None):
+        nrows = self.rows - row0 if nrows is None else nrows
+        if out is None:
+            out = np.empty((nrows, self.cols), dtype=self.dtype)
+        assert out.flags.c_contiguous and out.dtype == self.dtype and out.shape == (nrows, self.cols)
+        check(lib().skr_mat_download(self._h, out.ctypes.data_as(_p), int(row0), int(nrows)))
+        return out
+
+    def vector(self):
+        return self.to_numpy().reshape(-1)
+
+    def device_ptr(self):
+        ptr = _p()
+        check(lib().skr_mat_device_ptr(self._h, C.byref(ptr)))
+        return ptr.value
+
+
+def _h(m):
+    return m._h if m is not None else None
+
+
+class PackedSeqs:
+    """Sequences packed 2 bits/base in HBM (skr_seqs)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self._h = handle
+        n, tot, mx = _i64(0), _i64(0), _i64(0)
+        check(lib().skr_seqs_info(handle, C.byref(n), C.byref(tot), C.byref(mx)))
+        self.n, self.total_bases, self.max_len = n.value, tot.value, mx.value
+
+    @staticmethod
+    def _alpha(alphabet):
+        if len(alphabet) != 4:
+            raise NotImplementedError(
+                "the MI355X counting path packs 2 bits per base and needs a 4-letter alphabet (got {!r})".format(alphabet))
+        return alphabet.encode("latin-1")
+
+    @classmethod
+    def from_strings(cls, ctx, seqs, alphabet="AGTC"):
+        seqs = list(seqs)
+        lengths = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
+        offsets = np.zeros(len(seqs) + 1, dtype=np.int64)
+        np.cumsum(lengths, out=offsets[1:])
+        blob = "".join(seqs).encode("latin-1", "replace")  # 1 char -> 1 byte; non-latin-1 -> '?'
+        return cls.from_buffer(ctx, blob, offsets, alphabet)
+
+    @classmethod
+    def from_buffer(cls, ctx, blob, offsets, alphabet="AGTC"):
+        """`blob`: bytes / uint8 array of concatenated ASCII bases; `offsets`: int64 [n+1]."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        if isinstance(blob, np.ndarray):
+            blob = np.ascontiguousarray(blob, dtype=np.uint8)
+            ptr = blob.ctypes.data_as(_p)
+        else:
+            ptr = C.cast(C.c_char_p(blob), _p)
+        h = _p()
+        check(lib().skr_seqs_pack(ctx._h, ptr, offsets.ctypes.data_as(_p), len(offsets) - 1, cls._alpha(alphabet),
+                                  C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_fasta(cls, ctx, path, alphabet="AGTC"):
+        h = _p()
+        check(lib().skr_seqs_from_fasta(ctx._h, os.fsencode(path), cls._alpha(alphabet), C.byref(h)))
+        return cls(ctx, h)
+
+    def lengths(self):
+        out = np.empty(self.n, dtype=np.int64)
+        check(lib().skr_seqs_lengths(self._h, out.ctypes.data_as(_p)))
+        return out
+
+    def headers(self):
+        need = _i64(0)
+        check(lib().skr_seqs_headers(self._h, None, 0, C.byref(need)))
+        buf = C.create_string_buffer(max(need.value, 1))
+        check(lib().skr_seqs_headers(self._h, buf, need.value, None))
+        text = buf.value.decode("utf-8", "replace")
+        return text.split("\n") if text else []
+
+    def free(self):
+        if getattr(self, "_h", None):
+            lib().skr_seqs_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+# ----------------------------------------------------------------------------- operations --
+def count_u32(ctx, seqs, k):
+    out = ctx.empty(seqs.n, 4 ** k, np.uint32)
+    check(lib().skr_count_u32(ctx._h, seqs._h, int(k), out._h))
+    return out
+
+
+def count_per_kb(ctx, seqs, k, log2_pre=False, dtype=np.float32, out=None):
+    if out is None:
+        out = ctx.empty(seqs.n, 4 ** k, dtype)
+    check(lib().skr_count_per_kb(ctx._h, seqs._h, int(k), 1 if log2_pre else 0, out._h))
+    return out
+
+
+def colsum_seq(ctx, x, acc, center=None, center2=None, square=False):
+    check(lib().skr_colsum_seq(ctx._h, x._h, _h(center), _h(center2), 1 if square else 0, acc._h))
+    return acc
+
+
+def vec_finish(ctx, v, n, take_sqrt=False):
+    check(lib().skr_vec_finish(ctx._h, v._h, int(n), 1 if take_sqrt else 0))
+    return v
+
+
+def min_nan(ctx, x, center=None, scale=None):
+    mn, nan = C.c_float(0), _int(0)
+    check(lib().skr_min_nan(ctx._h, x._h, _h(center), _h(scale), C.byref(mn), C.byref(nan)))
+    return np.float32(mn.value), bool(nan.value)
+
+
+def apply(ctx, x, y=None, pre=False, center=None, scale=None, post=False, shift=0.0, want_nan=False):
+    y = x if y is None else y
+    nan = _int(0)
+    check(lib().skr_apply(ctx._h, x._h, 1 if pre else 0, _h(center), _h(scale), 1 if post else 0,
+                          C.c_float(shift), y._h, C.byref(nan) if want_nan else None))
+    return y, bool(nan.value)
+
+
+def normalize(ctx, x, log2, mean_mode, mean_vec, std_mode, std_vec):
+    """In-place kmer_counts.py:201-209 on one GPU; returns (mean_out, std_out, has_nan)."""
+    mean_out = ctx.empty(1, x.cols) if mean_mode == 1 else None
+    std_out = ctx.empty(1, x.cols) if std_mode == 1 else None
+    nan = _int(0)
+    check(lib().skr_normalize(ctx._h, x._h, LOG2_CODES[log2], mean_mode, _h(mean_vec), std_mode, _h(std_vec),
+                              _h(mean_out), _h(std_out), C.byref(nan)))
+    return mean_out, std_out, bool(nan.value)
+
+
+def row_standardize(ctx, x, z=None):
+    z = ctx.empty(x.rows, x.cols, x.dtype) if z is None else z
+    check(lib().skr_row_standardize(ctx._h, x._h, z._h))
+    return z
+
+
+def pearson_gemm(ctx, a, b, r, precision=PREC_FP32, symmetric=False, row0=0, col0=0):
+    check(lib().skr_pearson_gemm(ctx._h, a._h, b._h, int(precision), 1 if symmetric else 0, r._h, int(row0), int(col0)))
+    return r
+
+
+def pearson(ctx, c1, c2, row_standardize=True, precision=PREC_FP32, r=None):
+    r = ctx.empty(c1.rows, c2.rows, c1.dtype) if r is None else r
+    check(lib().skr_pearson(ctx._h, c1._h, c2._h, 1 if row_standardize else 0, int(precision), r._h))
+    return r
+
+
+# ----------------------------------------------------------------------------- RCCL --------
+def comm_unique_id():
+    buf = C.create_string_buffer(128)
+    check(lib().skr_comm_unique_id(buf))
+    return buf.raw
+
+
+def comm_init(ctx, nranks, rank, uid):
+    check(lib().skr_comm_init(ctx._h, int(nranks), int(rank), uid))
+
+
+def comm_sendrecv(ctx, src, srow0, snrows, dst_rank, dst, drow0, dnrows, src_rank):
+    ticket = _i64(-1)
+    check(lib().skr_comm_sendrecv(ctx._h, _h(src), int(srow0), int(snrows), int(dst_rank), _h(dst), int(drow0),
+                                  int(dnrows), int(src_rank), C.byref(ticket)))
+    return ticket.value
+
+
+def comm_wait(ctx, ticket):
+    check(lib().skr_comm_wait(ctx._h, int(ticket)))
+
+
+def comm_allreduce(ctx, values, op="sum"):
+    arr = (C.c_double * len(values))(*values)
+    check(lib().skr_comm_allreduce_f64(ctx._h, arr, len(values), {"sum": 0, "max": 1, "min": 2}[op]))
+    return list(arr)
+
+
+def comm_barrier(ctx):
+    check(lib().skr_comm_barrier(ctx._h))

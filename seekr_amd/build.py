@@ -1,0 +1,60 @@
+"""Build libseekr_hip.so (hipcc, gfx950 only) in-tree.  `python -m seekr_amd.build [--force]`."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJDIR = os.path.join(CSRC, "build")
+LIB = os.path.join(HERE, "libseekr_hip.so")
+SOURCES = ["ctx.hip", "pack.hip", "count.hip", "normalize.hip", "pearson.hip", "comm.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+          "-I" + os.path.join(HERE, "..", "include")]
+PER_FILE = {
+    # numpy-order parity: no FMA contraction anywhere in the normalisation / scaling arithmetic
+    "normalize.hip": ["-ffp-contract=off"],
+    "count.hip": ["-ffp-contract=off"],
+}
+
+
+def _newer(src, dst, extra=()):
+    if not os.path.exists(dst):
+        return True
+    t = os.path.getmtime(dst)
+    return any(os.path.getmtime(p) > t for p in (src, *extra))
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJDIR, exist_ok=True)
+    headers = [os.path.join(CSRC, "common.hpp"), os.path.join(HERE, "..", "include", "seekr_hip.h"),
+               os.path.abspath(__file__)]
+    headers += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    jobs = []
+    objs = []
+    for name in SOURCES:
+        src = os.path.join(CSRC, name)
+        obj = os.path.join(OBJDIR, name.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _newer(src, obj, headers):
+            jobs.append([HIPCC, *COMMON, *PER_FILE.get(name, []), "-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        proc = subprocess.run(cmd, capture_output=True, text=True)
+        if proc.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + proc.stdout + proc.stderr)
+        if verbose and proc.stderr.strip():
+            print(proc.stderr, file=sys.stderr)
+
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        list(pool.map(run, jobs))
+    if jobs or force or not os.path.exists(LIB):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl", "-lpthread"])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

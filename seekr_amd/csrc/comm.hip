@@ -1,0 +1,176 @@
+// C1 + C2 — RCCL over xGMI, one process per GPU.  librccl is loaded lazily with dlopen so that
+// single-GPU users never pay for it.  All traffic runs on the ctx's communication stream;
+// a "ticket" (HIP event) lets the compute stream wait for one specific exchange, which is how
+// the Pearson row-block schedule overlaps the arrival of shard s+1 with the GEMM on shard s.
+#include <dlfcn.h>
+#include <cstring>
+#include <rccl/rccl.h>
+
+#include "common.hpp"
+
+namespace {
+
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi g_api;
+
+int load_rccl() {
+    if (g_api.handle) return SKR_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return skr_set_error(SKR_ERR_COMM, "cannot load librccl: %s", dlerror());
+#define SYM(field, name)                                                          \
+    do {                                                                          \
+        *(void**)(&g_api.field) = dlsym(h, name);                                 \
+        if (!g_api.field) return skr_set_error(SKR_ERR_COMM, "librccl lacks %s", name); \
+    } while (0)
+    SYM(GetUniqueId, "ncclGetUniqueId");
+    SYM(CommInitRank, "ncclCommInitRank");
+    SYM(CommDestroy, "ncclCommDestroy");
+    SYM(Send, "ncclSend");
+    SYM(Recv, "ncclRecv");
+    SYM(GroupStart, "ncclGroupStart");
+    SYM(GroupEnd, "ncclGroupEnd");
+    SYM(AllReduce, "ncclAllReduce");
+    SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    g_api.handle = h;
+    return SKR_OK;
+}
+
+#define SKR_NCCL(call)                                                                          \
+    do {                                                                                        \
+        ncclResult_t r_ = (call);                                                               \
+        if (r_ != ncclSuccess)                                                                  \
+            return skr_set_error(SKR_ERR_COMM, "%s failed: %s", #call, g_api.GetErrorString(r_)); \
+    } while (0)
+
+int need_comm(skr_ctx* ctx) {
+    SKR_REQUIRE(ctx, "ctx is NULL");
+    if (!ctx->comm) return skr_set_error(SKR_ERR_COMM, "communicator not initialised (call skr_comm_init)");
+    return skr_activate(ctx);
+}
+
+}  // namespace
+
+extern "C" int skr_comm_unique_id(char id[128]) {
+    SKR_REQUIRE(id, "id is NULL");
+    SKR_TRY(load_rccl());
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+    ncclUniqueId uid;
+    SKR_NCCL(g_api.GetUniqueId(&uid));
+    memcpy(id, &uid, 128);
+    return SKR_OK;
+}
+
+extern "C" int skr_comm_init(skr_ctx* ctx, int nranks, int rank, const char id[128]) {
+    SKR_REQUIRE(ctx && id, "NULL argument");
+    SKR_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "bad rank %d of %d", rank, nranks);
+    SKR_REQUIRE(!ctx->comm, "communicator already initialised");
+    SKR_TRY(load_rccl());
+    SKR_TRY(skr_activate(ctx));
+    ncclUniqueId uid;
+    memcpy(&uid, id, 128);
+    ncclComm_t comm = nullptr;
+    SKR_NCCL(g_api.CommInitRank(&comm, nranks, uid, rank));
+    ctx->comm = comm;
+    ctx->nranks = nranks;
+    ctx->rank = rank;
+    return SKR_OK;
+}
+
+extern "C" int skr_comm_destroy(skr_ctx* ctx) {
+    if (!ctx || !ctx->comm) return SKR_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->comm_stream);
+    g_api.CommDestroy((ncclComm_t)ctx->comm);
+    ctx->comm = nullptr;
+    ctx->nranks = 1;
+    ctx->rank = 0;
+    return SKR_OK;
+}
+
+extern "C" int skr_comm_sendrecv(skr_ctx* ctx, const skr_mat* src, int64_t srow0, int64_t snrows, int dst_rank,
+                                 skr_mat* dst, int64_t drow0, int64_t dnrows, int src_rank, int64_t* ticket) {
+    SKR_TRY(need_comm(ctx));
+    const bool do_send = dst_rank >= 0 && snrows > 0, do_recv = src_rank >= 0 && dnrows > 0;
+    if (do_send) {
+        SKR_REQUIRE(src && src->ctx == ctx, "src missing");
+        SKR_REQUIRE(srow0 >= 0 && srow0 + snrows <= src->rows, "send rows out of range");
+        SKR_REQUIRE(dst_rank < ctx->nranks, "dst_rank out of range");
+    }
+    if (do_recv) {
+        SKR_REQUIRE(dst && dst->ctx == ctx, "dst missing");
+        SKR_REQUIRE(drow0 >= 0 && drow0 + dnrows <= dst->rows, "recv rows out of range");
+        SKR_REQUIRE(src_rank < ctx->nranks, "src_rank out of range");
+    }
+    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    // the data being sent was produced on the compute stream
+    hipEvent_t ready;
+    SKR_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    SKR_HIP(hipEventRecord(ready, ctx->stream));
+    SKR_HIP(hipStreamWaitEvent(ctx->comm_stream, ready, 0));
+    SKR_HIP(hipEventDestroy(ready));
+    SKR_NCCL(g_api.GroupStart());
+    if (do_send) {
+        const size_t rb = (size_t)src->cols * src->elem();
+        SKR_NCCL(g_api.Send((const char*)src->data + (size_t)srow0 * rb, (size_t)snrows * rb, ncclUint8, dst_rank, comm,
+                            ctx->comm_stream));
+    }
+    if (do_recv) {
+        const size_t rb = (size_t)dst->cols * dst->elem();
+        SKR_NCCL(g_api.Recv((char*)dst->data + (size_t)drow0 * rb, (size_t)dnrows * rb, ncclUint8, src_rank, comm,
+                            ctx->comm_stream));
+    }
+    SKR_NCCL(g_api.GroupEnd());
+    hipEvent_t done;
+    SKR_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    SKR_HIP(hipEventRecord(done, ctx->comm_stream));
+    ctx->tickets.push_back(done);
+    if (ticket) *ticket = (int64_t)ctx->tickets.size() - 1;
+    return SKR_OK;
+}
+
+extern "C" int skr_comm_wait(skr_ctx* ctx, int64_t ticket) {
+    SKR_TRY(need_comm(ctx));
+    SKR_REQUIRE(ticket >= 0 && ticket < (int64_t)ctx->tickets.size() && ctx->tickets[ticket], "unknown ticket");
+    SKR_HIP(hipStreamWaitEvent(ctx->stream, ctx->tickets[ticket], 0));
+    return SKR_OK;
+}
+
+extern "C" int skr_comm_allreduce_f64(skr_ctx* ctx, double* values, int n, int op) {
+    SKR_TRY(need_comm(ctx));
+    SKR_REQUIRE(values && n > 0 && n <= 32, "need 1..32 values");
+    SKR_REQUIRE(op >= 0 && op <= 2, "op must be 0 (sum), 1 (max) or 2 (min)");
+    double* dbuf = reinterpret_cast<double*>(ctx->d_flags + 32);  // 128 bytes of the flag block
+    static_assert(sizeof(double) * 16 <= 32 * sizeof(uint32_t), "flag block too small");
+    SKR_REQUIRE(n <= 16, "need 1..16 values");
+    SKR_HIP(hipStreamSynchronize(ctx->stream));
+    SKR_HIP(hipMemcpyAsync(dbuf, values, n * sizeof(double), hipMemcpyHostToDevice, ctx->comm_stream));
+    const ncclRedOp_t rop = op == 0 ? ncclSum : (op == 1 ? ncclMax : ncclMin);
+    SKR_NCCL(g_api.AllReduce(dbuf, dbuf, (size_t)n, ncclFloat64, rop, (ncclComm_t)ctx->comm, ctx->comm_stream));
+    SKR_HIP(hipMemcpyAsync(values, dbuf, n * sizeof(double), hipMemcpyDeviceToHost, ctx->comm_stream));
+    SKR_HIP(hipStreamSynchronize(ctx->comm_stream));
+    return SKR_OK;
+}
+
+extern "C" int skr_comm_barrier(skr_ctx* ctx) {
+    double v = 0.0;
+    SKR_TRY(skr_ctx_sync(ctx));
+    return skr_comm_allreduce_f64(ctx, &v, 1, 0);
+}

@@ -1,0 +1,94 @@
+// Internal declarations shared by the translation units of libseekr_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/seekr_hip.h"
+
+struct skr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;       // compute stream
+    hipStream_t comm_stream = nullptr;  // RCCL traffic, overlapped with compute
+    int num_cu = 256;
+    // small device scratch: [0] encoded min, [1] nan flag, [2] error flag, ...
+    uint32_t* d_flags = nullptr;
+    uint32_t* h_flags = nullptr;  // pinned mirror
+    // workspaces owned by the ctx and grown on demand
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    // profiling
+    bool prof = false;
+    struct ProfRec {
+        std::string name;
+        hipEvent_t start, stop;
+    };
+    std::vector<ProfRec> prof_recs;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
+    // RCCL (loaded lazily with dlopen; see comm.cpp)
+    void* comm = nullptr;
+    int nranks = 1, rank = 0;
+    std::vector<hipEvent_t> tickets;
+};
+
+struct skr_mat {
+    skr_ctx* ctx = nullptr;
+    int64_t rows = 0, cols = 0;
+    int dtype = SKR_F32;
+    void* data = nullptr;
+    size_t bytes() const { return (size_t)rows * (size_t)cols * elem(); }
+    size_t elem() const { return dtype == SKR_F64 ? 8 : 4; }
+};
+
+struct skr_seqs {
+    skr_ctx* ctx = nullptr;
+    int64_t n = 0;
+    int64_t total_bases = 0;
+    int64_t max_len = 0;
+    int64_t n_words = 0;       // packed 2-bit words (16 bases each), per-sequence word aligned
+    int64_t n_mask_words = 0;  // validity bit words (32 bases each), only for sequences with invalid bases
+    uint32_t* d_packed = nullptr;
+    int64_t* d_word_off = nullptr;  // [n+1]
+    int64_t* d_len = nullptr;       // [n]
+    uint32_t* d_mask = nullptr;
+    int64_t* d_mask_off = nullptr;  // [n], -1 when the sequence is all-alphabet
+    std::vector<int64_t> h_len;
+    std::string headers;  // '\n' joined (FASTA input only)
+};
+
+int skr_set_error(int code, const char* fmt, ...);
+
+#define SKR_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return skr_set_error(e_ == hipErrorOutOfMemory ? SKR_ERR_NOMEM : SKR_ERR_HIP,      \
+                                 "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                                 __LINE__);                                                    \
+    } while (0)
+
+#define SKR_REQUIRE(cond, ...)                                  \
+    do {                                                        \
+        if (!(cond)) return skr_set_error(SKR_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+#define SKR_TRY(call)             \
+    do {                          \
+        int rc_ = (call);         \
+        if (rc_ != SKR_OK) return rc_; \
+    } while (0)
+
+// Scoped kernel timer: records a start/stop event pair on the ctx stream when profiling is on.
+struct SkrProfScope {
+    skr_ctx* ctx;
+    int idx = -1;
+    SkrProfScope(skr_ctx* c, const char* name);
+    ~SkrProfScope();
+};
+
+int skr_ctx_workspace(skr_ctx* ctx, size_t bytes, void** out);
+int skr_activate(const skr_ctx* ctx);

@@ -1,0 +1,190 @@
+// K2 + K3 — k-mer counting: sliding-window 4^k indexer, per-sequence LDS histogram, and the
+// per-kb scaling fused into the histogram flush (kmer_counts.py:140-151, 194-202).
+//
+// One 256-thread workgroup owns one sequence at a time (persistent grid-stride loop over the
+// sequences).  Thread t of a sweep takes the 16 windows that start inside packed word
+// w = sweep*256 + t: it loads words w and w+1 (consecutive lanes -> consecutive words, fully
+// coalesced), and every window's column index is a bit-field of that 64-bit pair because the
+// packer stores the first base in the top bits.  Counts go to a 4^k-bin uint32 histogram in
+// LDS (16 KiB at k=6, 64 KiB at k=7) with ds_add_u32; runs of equal indices inside a thread
+// (homopolymers) are merged before the atomic.  The flush converts bins to the reference's
+// float32 per-kb values and streams the dense row to HBM as 16-byte stores — the row write
+// (4*4^k bytes per sequence) is the algorithmic traffic that bounds this kernel.
+#include "common.hpp"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// float32( n sequential float64 additions of `inc` ) — what kmer_counts.py:144-150 stores.
+// n*inc (one rounding) equals the sequential sum unless the product sits within the
+// accumulated rounding slack of a float32 rounding boundary; only then replay the additions.
+__device__ __forceinline__ float per_kb_value(uint32_t n, double inc) {
+    if (n == 0) return 0.0f;
+    const double p = (double)n * inc;
+    const float f = (float)p;
+    if (n <= 3) return f;  // 1*inc, inc+inc and fl(2inc+inc) are single roundings of n*inc
+    const double slack = p * ((double)(n + 4) * 0x1.0p-53);
+    if ((float)(p - slack) == f && (float)(p + slack) == f) return f;
+    double s = 0.0;
+    for (uint32_t i = 0; i < n; i++) s += inc;
+    return (float)s;
+}
+
+__device__ __forceinline__ double per_kb_value_f64(uint32_t n, double inc) {
+    double s = 0.0;
+    for (uint32_t i = 0; i < n; i++) s += inc;  // exact replay; f64 output is a small-input path
+    return s;
+}
+
+enum OutKind { OUT_F32 = 0, OUT_F32_LOG2 = 1, OUT_U32 = 2, OUT_F64 = 3 };
+
+template <int OUT>
+__global__ __launch_bounds__(kThreads) void count_kmers_kernel(
+    const uint32_t* __restrict__ packed, const int64_t* __restrict__ word_off, const int64_t* __restrict__ len,
+    const uint32_t* __restrict__ mask, const int64_t* __restrict__ mask_off, int64_t n_seqs, int k, void* __restrict__ out,
+    uint32_t* __restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    const int tid = threadIdx.x;
+    const uint32_t nbins = 1u << (2 * k);
+    const uint32_t idx_mask = nbins - 1u;
+    const uint32_t win_mask = (1u << k) - 1u;  // k consecutive validity bits
+
+    for (int64_t seq = blockIdx.x; seq < n_seqs; seq += gridDim.x) {
+        // ---- zero the histogram (16 B per lane per step)
+        for (uint32_t b = tid * 4; b < nbins; b += kThreads * 4) {
+            if (nbins >= 4) {
+                *reinterpret_cast<uint4*>(&hist[b]) = make_uint4(0, 0, 0, 0);
+            } else {
+                hist[b] = 0;  // k == 0 is rejected on the host; nbins >= 4 always
+            }
+        }
+        __syncthreads();
+
+        const int64_t L = len[seq];
+        const int64_t W = L - k + 1;  // windows, counting every character (kmer_counts.py:143-144)
+        if (W == 0 && tid == 0) atomicOr(&flags[2], 1u);  // ZeroDivisionError in the reference
+        if (W > 0) {
+            const uint32_t* words = packed + word_off[seq];
+            const int64_t moff = mask_off[seq];
+            const uint32_t* mwords = moff >= 0 ? mask + moff : nullptr;
+            const int64_t n_win_words = (W + 15) >> 4;
+            for (int64_t w = tid; w < n_win_words; w += kThreads) {
+                const uint32_t hi = words[w];
+                const uint32_t lo = words[w + 1];  // pad word keeps this in bounds
+                const unsigned long long pair = ((unsigned long long)hi << 32) | lo;
+                uint32_t invalid = 0;  // bit j: base 16w+j is not in the alphabet
+                if (mwords) {
+                    const int64_t mw = w >> 1;
+                    const unsigned long long mpair =
+                        (unsigned long long)mwords[mw] | ((unsigned long long)mwords[mw + 1] << 32);
+                    invalid = (uint32_t)(mpair >> ((w & 1) * 16));
+                }
+                const int64_t first = w << 4;
+                const int lim = (int)((W - first) < 16 ? (W - first) : 16);
+                uint32_t run_idx = 0xFFFFFFFFu, run_len = 0;
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    if (j < lim) {
+                        const bool ok = ((invalid >> j) & win_mask) == 0;
+                        if (ok) {
+                            const uint32_t idx = (uint32_t)(pair >> (64 - 2 * j - 2 * k)) & idx_mask;
+                            if (idx == run_idx) {
+                                run_len++;
+                            } else {
+                                if (run_len) atomicAdd(&hist[run_idx], run_len);
+                                run_idx = idx;
+                                run_len = 1;
+                            }
+                        }
+                    }
+                }
+                if (run_len) atomicAdd(&hist[run_idx], run_len);
+            }
+        }
+        __syncthreads();
+
+        // ---- flush: bins -> per-kb values, dense row to HBM
+        const double inc = W > 0 ? 1000.0 / (double)W : 0.0;
+        if (OUT == OUT_U32) {
+            uint32_t* row = reinterpret_cast<uint32_t*>(out) + (size_t)seq * nbins;
+            for (uint32_t b = tid * 4; b < nbins; b += kThreads * 4)
+                *reinterpret_cast<uint4*>(&row[b]) = *reinterpret_cast<const uint4*>(&hist[b]);
+        } else if (OUT == OUT_F64) {
+            double* row = reinterpret_cast<double*>(out) + (size_t)seq * nbins;
+            for (uint32_t b = tid; b < nbins; b += kThreads) row[b] = per_kb_value_f64(hist[b], inc);
+        } else {
+            float* row = reinterpret_cast<float*>(out) + (size_t)seq * nbins;
+            for (uint32_t b = tid * 4; b < nbins; b += kThreads * 4) {
+                const uint4 c = *reinterpret_cast<const uint4*>(&hist[b]);
+                float4 v;
+                v.x = per_kb_value(c.x, inc);
+                v.y = per_kb_value(c.y, inc);
+                v.z = per_kb_value(c.z, inc);
+                v.w = per_kb_value(c.w, inc);
+                if (OUT == OUT_F32_LOG2) {  // kmer_counts.py:189-192: counts += 1; log2
+                    v.x = log2f(v.x + 1.0f);
+                    v.y = log2f(v.y + 1.0f);
+                    v.z = log2f(v.z + 1.0f);
+                    v.w = log2f(v.w + 1.0f);
+                }
+                *reinterpret_cast<float4*>(&row[b]) = v;
+            }
+        }
+        __syncthreads();  // the histogram is reused by the next sequence
+    }
+}
+
+template <int OUT>
+int launch_count(skr_ctx* ctx, const skr_seqs* s, int k, void* out, const char* name) {
+    const size_t lds = (size_t)4 << (2 * k);
+    SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(count_kmers_kernel<OUT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // as many resident workgroups as LDS allows, capped by the wave limit (8 x 256 threads / CU)
+    int per_cu = (int)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1));
+    if (per_cu < 1) per_cu = 1;
+    int64_t grid = std::min<int64_t>(s->n, (int64_t)ctx->num_cu * per_cu);
+    if (grid < 1) return SKR_OK;
+    SkrProfScope prof(ctx, name);
+    hipLaunchKernelGGL(count_kmers_kernel<OUT>, dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream, s->d_packed,
+                       s->d_word_off, s->d_len, s->d_mask, s->d_mask_off, s->n, k, out, ctx->d_flags);
+    SKR_HIP(hipGetLastError());
+    return SKR_OK;
+}
+
+int check_count_args(skr_ctx* ctx, const skr_seqs* s, int k, const skr_mat* out) {
+    SKR_REQUIRE(ctx && s && out, "NULL argument");
+    SKR_REQUIRE(s->ctx == ctx && out->ctx == ctx, "handles belong to a different ctx");
+    SKR_REQUIRE(k >= 1, "k must be >= 1 (got %d)", k);
+    if (k > 7)
+        return skr_set_error(SKR_ERR_UNSUPPORTED,
+                             "k=%d needs a %d KiB histogram per sequence; the LDS path covers k <= 7", k,
+                             4 << (2 * k - 10));
+    SKR_REQUIRE(out->rows == s->n && out->cols == ((int64_t)1 << (2 * k)),
+                "output must be [%lld, %lld], got [%lld, %lld]", (long long)s->n, (long long)1 << (2 * k),
+                (long long)out->rows, (long long)out->cols);
+    return SKR_OK;
+}
+
+}  // namespace
+
+extern "C" int skr_count_u32(skr_ctx* ctx, const skr_seqs* s, int k, skr_mat* out) {
+    SKR_TRY(check_count_args(ctx, s, k, out));
+    SKR_REQUIRE(out->dtype == SKR_U32, "skr_count_u32 needs a SKR_U32 matrix");
+    SKR_TRY(skr_activate(ctx));
+    return launch_count<OUT_U32>(ctx, s, k, out->data, "count_kmers_u32");
+}
+
+extern "C" int skr_count_per_kb(skr_ctx* ctx, const skr_seqs* s, int k, int log2_pre, skr_mat* out) {
+    SKR_TRY(check_count_args(ctx, s, k, out));
+    SKR_REQUIRE(out->dtype == SKR_F32 || out->dtype == SKR_F64, "skr_count_per_kb needs a float matrix");
+    SKR_REQUIRE(!(log2_pre && out->dtype == SKR_F64), "log2_pre is implemented for SKR_F32 output only");
+    SKR_TRY(skr_activate(ctx));
+    // len == k-1 is an error in the reference (ZeroDivisionError, kmer_counts.py:144): detect on the host
+    for (int64_t L : s->h_len)
+        if (L == k - 1)
+            return skr_set_error(SKR_ERR_ZERODIV, "division by zero (a sequence has length k-1 = %d)", k - 1);
+    if (out->dtype == SKR_F64) return launch_count<OUT_F64>(ctx, s, k, out->data, "count_kmers_f64");
+    if (log2_pre) return launch_count<OUT_F32_LOG2>(ctx, s, k, out->data, "count_kmers_f32_log2");
+    return launch_count<OUT_F32>(ctx, s, k, out->data, "count_kmers_f32");
+}

@@ -1,0 +1,269 @@
+// Context, device matrices, error plumbing and per-kernel HIP-event profiling.
+#include <cstring>
+
+#include "common.hpp"
+
+static thread_local char g_err[1024] = "";
+
+int skr_set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char* skr_last_error(void) { return g_err; }
+extern "C" int skr_abi_version(void) { return SKR_ABI_VERSION; }
+
+extern "C" int skr_device_count(int* count) {
+    SKR_REQUIRE(count, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return skr_set_error(SKR_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return SKR_OK;
+}
+
+int skr_activate(const skr_ctx* ctx) {
+    SKR_REQUIRE(ctx, "ctx is NULL");
+    SKR_HIP(hipSetDevice(ctx->device));
+    return SKR_OK;
+}
+
+extern "C" int skr_ctx_create(int device, skr_ctx** out) {
+    SKR_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    SKR_TRY(skr_device_count(&n));
+    if (n <= 0) return skr_set_error(SKR_ERR_HIP, "no HIP device visible");
+    SKR_REQUIRE(device >= 0 && device < n, "device %d out of range (0..%d)", device, n - 1);
+    SKR_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SKR_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return skr_set_error(SKR_ERR_UNSUPPORTED, "device %d is %s; libseekr_hip is built for gfx950 only",
+                             device, prop.gcnArchName);
+    skr_ctx* c = new skr_ctx();
+    c->device = device;
+    c->num_cu = prop.multiProcessorCount;
+    SKR_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    SKR_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    SKR_HIP(hipMalloc((void**)&c->d_flags, 64 * sizeof(uint32_t)));
+    SKR_HIP(hipHostMalloc((void**)&c->h_flags, 64 * sizeof(uint32_t), hipHostMallocDefault));
+    SKR_HIP(hipMemsetAsync(c->d_flags, 0, 64 * sizeof(uint32_t), c->stream));
+    *out = c;
+    return SKR_OK;
+}
+
+extern "C" int skr_comm_destroy(skr_ctx* ctx);
+
+extern "C" int skr_ctx_destroy(skr_ctx* ctx) {
+    if (!ctx) return SKR_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    skr_comm_destroy(ctx);
+    for (auto& r : ctx->prof_recs) {
+        (void)hipEventDestroy(r.start);
+        (void)hipEventDestroy(r.stop);
+    }
+    for (auto& p : ctx->event_pool) {
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    for (auto& t : ctx->tickets)
+        if (t) (void)hipEventDestroy(t);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->d_flags) (void)hipFree(ctx->d_flags);
+    if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
+    delete ctx;
+    return SKR_OK;
+}
+
+extern "C" int skr_ctx_sync(skr_ctx* ctx) {
+    SKR_TRY(skr_activate(ctx));
+    SKR_HIP(hipStreamSynchronize(ctx->stream));
+    SKR_HIP(hipStreamSynchronize(ctx->comm_stream));
+    return SKR_OK;
+}
+
+extern "C" int skr_ctx_device(const skr_ctx* ctx, int* device) {
+    SKR_REQUIRE(ctx && device, "NULL argument");
+    *device = ctx->device;
+    return SKR_OK;
+}
+
+int skr_ctx_workspace(skr_ctx* ctx, size_t bytes, void** out) {
+    if (bytes > ctx->ws_bytes) {
+        SKR_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->ws) SKR_HIP(hipFree(ctx->ws));
+        ctx->ws = nullptr;
+        ctx->ws_bytes = 0;
+        size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+        SKR_HIP(hipMalloc(&ctx->ws, want));
+        ctx->ws_bytes = want;
+    }
+    *out = ctx->ws;
+    return SKR_OK;
+}
+
+// ---------------------------------------------------------------- profiling -------------
+SkrProfScope::SkrProfScope(skr_ctx* c, const char* name) : ctx(c) {
+    if (!c->prof) return;
+    skr_ctx::ProfRec rec;
+    rec.name = name;
+    if (!c->event_pool.empty()) {
+        rec.start = c->event_pool.back().first;
+        rec.stop = c->event_pool.back().second;
+        c->event_pool.pop_back();
+    } else {
+        if (hipEventCreate(&rec.start) != hipSuccess) return;
+        if (hipEventCreate(&rec.stop) != hipSuccess) return;
+    }
+    (void)hipEventRecord(rec.start, c->stream);
+    c->prof_recs.push_back(rec);
+    idx = (int)c->prof_recs.size() - 1;
+}
+
+SkrProfScope::~SkrProfScope() {
+    if (idx >= 0) (void)hipEventRecord(ctx->prof_recs[idx].stop, ctx->stream);
+}
+
+extern "C" int skr_prof_enable(skr_ctx* ctx, int on) {
+    SKR_REQUIRE(ctx, "ctx is NULL");
+    ctx->prof = on != 0;
+    return SKR_OK;
+}
+
+extern "C" int skr_prof_reset(skr_ctx* ctx) {
+    SKR_TRY(skr_activate(ctx));
+    SKR_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto& r : ctx->prof_recs) ctx->event_pool.emplace_back(r.start, r.stop);
+    ctx->prof_recs.clear();
+    return SKR_OK;
+}
+
+extern "C" int skr_prof_query(skr_ctx* ctx, const char* prefix, double* total_ms, int64_t* launches) {
+    SKR_REQUIRE(ctx && prefix && total_ms && launches, "NULL argument");
+    SKR_TRY(skr_activate(ctx));
+    SKR_HIP(hipStreamSynchronize(ctx->stream));
+    double tot = 0;
+    int64_t cnt = 0;
+    size_t plen = strlen(prefix);
+    for (auto& r : ctx->prof_recs) {
+        if (r.name.compare(0, plen, prefix) != 0) continue;
+        float ms = 0;
+        SKR_HIP(hipEventElapsedTime(&ms, r.start, r.stop));
+        tot += ms;
+        cnt++;
+    }
+    *total_ms = tot;
+    *launches = cnt;
+    return SKR_OK;
+}
+
+extern "C" int skr_prof_names(skr_ctx* ctx, char* buf, int64_t cap) {
+    SKR_REQUIRE(ctx && buf && cap > 0, "bad argument");
+    std::string all;
+    std::vector<std::string> seen;
+    for (auto& r : ctx->prof_recs) {
+        bool dup = false;
+        for (auto& s : seen) dup |= (s == r.name);
+        if (dup) continue;
+        seen.push_back(r.name);
+        if (!all.empty()) all += "\n";
+        all += r.name;
+    }
+    snprintf(buf, (size_t)cap, "%s", all.c_str());
+    return SKR_OK;
+}
+
+// ---------------------------------------------------------------- matrices --------------
+extern "C" int skr_mat_create(skr_ctx* ctx, int64_t rows, int64_t cols, int dtype, skr_mat** out) {
+    SKR_REQUIRE(ctx && out, "NULL argument");
+    *out = nullptr;
+    SKR_REQUIRE(rows >= 0 && cols >= 0, "negative shape");
+    SKR_REQUIRE(dtype == SKR_F32 || dtype == SKR_F64 || dtype == SKR_U32, "unknown dtype %d", dtype);
+    SKR_TRY(skr_activate(ctx));
+    skr_mat* m = new skr_mat();
+    m->ctx = ctx;
+    m->rows = rows;
+    m->cols = cols;
+    m->dtype = dtype;
+    size_t bytes = m->bytes();
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(&m->data, bytes);
+    if (e != hipSuccess) {
+        delete m;
+        return skr_set_error(SKR_ERR_NOMEM, "hipMalloc(%zu bytes) for a %lld x %lld matrix failed: %s", bytes,
+                             (long long)rows, (long long)cols, hipGetErrorString(e));
+    }
+    *out = m;
+    return SKR_OK;
+}
+
+extern "C" int skr_mat_free(skr_mat* m) {
+    if (!m) return SKR_OK;
+    (void)hipSetDevice(m->ctx->device);
+    (void)hipStreamSynchronize(m->ctx->stream);
+    (void)hipStreamSynchronize(m->ctx->comm_stream);
+    if (m->data) (void)hipFree(m->data);
+    delete m;
+    return SKR_OK;
+}
+
+extern "C" int skr_mat_shape(const skr_mat* m, int64_t* rows, int64_t* cols, int* dtype) {
+    SKR_REQUIRE(m, "matrix is NULL");
+    if (rows) *rows = m->rows;
+    if (cols) *cols = m->cols;
+    if (dtype) *dtype = m->dtype;
+    return SKR_OK;
+}
+
+extern "C" int skr_mat_device_ptr(const skr_mat* m, void** ptr) {
+    SKR_REQUIRE(m && ptr, "NULL argument");
+    *ptr = m->data;
+    return SKR_OK;
+}
+
+static int check_rows(const skr_mat* m, const void* host, int64_t row0, int64_t nrows) {
+    SKR_REQUIRE(m, "matrix is NULL");
+    SKR_REQUIRE(row0 >= 0 && nrows >= 0 && row0 + nrows <= m->rows, "row range [%lld, %lld) outside 0..%lld",
+                (long long)row0, (long long)(row0 + nrows), (long long)m->rows);
+    SKR_REQUIRE(host || nrows * m->cols == 0, "host buffer is NULL");
+    return SKR_OK;
+}
+
+extern "C" int skr_mat_upload(skr_mat* m, const void* host, int64_t row0, int64_t nrows) {
+    SKR_TRY(check_rows(m, host, row0, nrows));
+    SKR_TRY(skr_activate(m->ctx));
+    size_t rb = (size_t)m->cols * m->elem();
+    if (nrows * rb == 0) return SKR_OK;
+    SKR_HIP(hipMemcpyAsync((char*)m->data + (size_t)row0 * rb, host, (size_t)nrows * rb, hipMemcpyHostToDevice,
+                           m->ctx->stream));
+    SKR_HIP(hipStreamSynchronize(m->ctx->stream));
+    return SKR_OK;
+}
+
+extern "C" int skr_mat_download(const skr_mat* m, void* host, int64_t row0, int64_t nrows) {
+    SKR_TRY(check_rows(m, host, row0, nrows));
+    SKR_TRY(skr_activate(m->ctx));
+    size_t rb = (size_t)m->cols * m->elem();
+    if (nrows * rb == 0) return SKR_OK;
+    SKR_HIP(hipMemcpyAsync(host, (const char*)m->data + (size_t)row0 * rb, (size_t)nrows * rb,
+                           hipMemcpyDeviceToHost, m->ctx->stream));
+    SKR_HIP(hipStreamSynchronize(m->ctx->stream));
+    return SKR_OK;
+}
+
+extern "C" int skr_mat_fill_zero(skr_mat* m) {
+    SKR_REQUIRE(m, "matrix is NULL");
+    SKR_TRY(skr_activate(m->ctx));
+    if (m->bytes()) SKR_HIP(hipMemsetAsync(m->data, 0, m->bytes(), m->ctx->stream));
+    return SKR_OK;
+}

@@ -1,0 +1,445 @@
+// K4 + K5 — column statistics in numpy's reduction order and the elementwise transforms of
+// BasicCounter (kmer_counts.py:165-209).
+//
+// Parity here is defined by rounding, not mathematics:
+//   * np.mean/np.std(axis=0) on the C-contiguous float32 matrix add the rows one after the
+//     other into one float32 accumulator per column.  colsum_seq_kernel reproduces exactly
+//     that chain; a tree reduction would be *more* accurate and fail parity at N >= 50k.
+//   * every elementwise step is a separately rounded float32 operation (no FMA contraction).
+#include <algorithm>
+#include <cmath>
+
+#include "common.hpp"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int kColsPerWG = 32;    // 128-byte column strip per workgroup
+constexpr int kTileRows = 256;    // rows staged in LDS per step
+constexpr int kThreads = 256;
+
+enum CenterKind { C_NONE = 0, C_F32 = 1, C_F64 = 2 };
+
+template <int KIND>
+__device__ __forceinline__ float sub_center(float x, const void* vec, int64_t col) {
+    if (KIND == C_F32) return __fsub_rn(x, reinterpret_cast<const float*>(vec)[col]);
+    if (KIND == C_F64) return (float)((double)x - reinterpret_cast<const double*>(vec)[col]);
+    return x;
+}
+
+template <int KIND>
+__device__ __forceinline__ float div_scale(float x, const void* vec, int64_t col) {
+    if (KIND == C_F32) return __fdiv_rn(x, reinterpret_cast<const float*>(vec)[col]);
+    if (KIND == C_F64) return (float)((double)x / reinterpret_cast<const double*>(vec)[col]);
+    return x;
+}
+
+// ---------------------------------------------------------------------------------------
+// Sequential column sums.  A workgroup owns a strip of 32 columns.  All 256 threads stream
+// tiles of 256 rows x 32 columns into LDS (8 lanes x 16 B per row: full 128-B lines, the
+// t() transform applied on the way), double-buffered through registers so the next tile's
+// HBM loads are in flight while lanes 0..31 of wave 0 walk the current tile row by row, each
+// extending one column's float32 chain.
+// ---------------------------------------------------------------------------------------
+template <int CK, bool SQUARE>
+__global__ __launch_bounds__(kThreads) void colsum_seq_kernel(const float* __restrict__ x, int64_t rows,
+                                                              int64_t cols, const void* __restrict__ center,
+                                                              const float* __restrict__ center2,
+                                                              float* __restrict__ acc) {
+    __shared__ __attribute__((aligned(16))) float tile[2][kTileRows][kColsPerWG];
+    const int tid = threadIdx.x;
+    const int64_t col0 = (int64_t)blockIdx.x * kColsPerWG;
+    const int lane_c4 = (tid & 7) * 4;  // 4 consecutive columns handled by this thread
+    const int lane_r = tid >> 3;        // 0..31: row inside a 32-row slab
+    const bool vec_ok = (cols % 4 == 0) && (col0 + kColsPerWG <= cols);
+
+    float c1[4] = {0, 0, 0, 0}, c2[4] = {0, 0, 0, 0};
+    (void)c1;
+    if (SQUARE && center2) {
+        for (int j = 0; j < 4; j++)
+            if (col0 + lane_c4 + j < cols) c2[j] = center2[col0 + lane_c4 + j];
+    }
+
+    auto load_tile = [&](int64_t row_base, float4 (&regs)[kTileRows / 32]) {
+#pragma unroll
+        for (int s = 0; s < kTileRows / 32; s++) {
+            const int64_t r = row_base + s * 32 + lane_r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < rows) {
+                const float* p = x + (size_t)r * cols + col0 + lane_c4;
+                if (vec_ok) {
+                    v = *reinterpret_cast<const float4*>(p);
+                } else {
+                    if (col0 + lane_c4 + 0 < cols) v.x = p[0];
+                    if (col0 + lane_c4 + 1 < cols) v.y = p[1];
+                    if (col0 + lane_c4 + 2 < cols) v.z = p[2];
+                    if (col0 + lane_c4 + 3 < cols) v.w = p[3];
+                }
+            }
+            regs[s] = v;
+        }
+    };
+    auto transform = [&](float v, int j) -> float {
+        const int64_t c = col0 + lane_c4 + j;
+        if (c >= cols) return 0.f;
+        float t = sub_center<CK>(v, center, c);
+        if (SQUARE) {
+            const float d = center2 ? __fsub_rn(t, c2[j]) : t;
+            t = __fmul_rn(d, d);
+        }
+        return t;
+    };
+    auto store_tile = [&](int buf, int64_t row_base, const float4 (&regs)[kTileRows / 32]) {
+#pragma unroll
+        for (int s = 0; s < kTileRows / 32; s++) {
+            float4 v = regs[s];
+            if (CK != C_NONE || SQUARE) {
+                v.x = transform(v.x, 0);
+                v.y = transform(v.y, 1);
+                v.z = transform(v.z, 2);
+                v.w = transform(v.w, 3);
+            }
+            *reinterpret_cast<float4*>(&tile[buf][s * 32 + lane_r][lane_c4]) = v;
+        }
+        (void)row_base;
+    };
+
+    float running = 0.f;
+    if (tid < kColsPerWG && col0 + tid < cols) running = acc[col0 + tid];
+
+    float4 regs[kTileRows / 32];
+    const int64_t n_tiles = (rows + kTileRows - 1) / kTileRows;
+    if (n_tiles > 0) load_tile(0, regs);
+    for (int64_t t = 0; t < n_tiles; t++) {
+        const int buf = (int)(t & 1);
+        store_tile(buf, t * kTileRows, regs);
+        __syncthreads();
+        if (t + 1 < n_tiles) load_tile((t + 1) * kTileRows, regs);  // in flight during the walk
+        if (tid < kColsPerWG) {
+            const int64_t left = rows - t * kTileRows;
+            const int nr = (int)(left < kTileRows ? left : kTileRows);
+            if (nr == kTileRows) {
+#pragma unroll 32
+                for (int r = 0; r < kTileRows; r++) running = __fadd_rn(running, tile[buf][r][tid]);
+            } else {
+                for (int r = 0; r < nr; r++) running = __fadd_rn(running, tile[buf][r][tid]);
+            }
+        }
+        // the other buffer is rewritten next iteration; this one the iteration after: one barrier per tile
+    }
+    if (tid < kColsPerWG && col0 + tid < cols) acc[col0 + tid] = running;
+}
+
+__global__ void vec_finish_kernel(float* v, int64_t cols, float n, int take_sqrt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cols) return;
+    float q = __fdiv_rn(v[i], n);
+    if (take_sqrt) q = __fsqrt_rn(q);
+    v[i] = q;
+}
+
+// ---------------------------------------------------------------------------------------
+// Elementwise: y = post(scale(center(pre(x)))) and the NaN-propagating global minimum of z.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t order_bits(float f) {  // monotone float -> uint map
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+inline float unorder_bits(uint32_t u) {  // host side inverse
+    const uint32_t b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+    union {
+        uint32_t u32;
+        float f32;
+    } cv;
+    cv.u32 = b;
+    return cv.f32;
+}
+
+template <int CK, int SK, bool PRE, bool POST, bool WRITE, bool MIN>
+__global__ __launch_bounds__(256) void elementwise_kernel(const float* __restrict__ x, int64_t rows, int64_t cols,
+                                                          const void* __restrict__ center,
+                                                          const void* __restrict__ scale, float shift,
+                                                          float* __restrict__ y, uint32_t* __restrict__ flags) {
+    const int64_t total = rows * cols;
+    const bool vec_ok = (cols % 4) == 0;
+    float vmin = INFINITY;
+    bool any_nan = false;
+    auto one = [&](float v, int64_t c) -> float {
+        if (PRE) v = log2f(__fadd_rn(v, 1.0f));
+        v = sub_center<CK>(v, center, c);
+        v = div_scale<SK>(v, scale, c);
+        if (v != v) any_nan = true;
+        if (MIN) vmin = fminf(vmin, v);
+        if (POST) {
+            v = __fadd_rn(v, shift);
+            v = __fadd_rn(v, 1.0f);
+            v = log2f(v);
+        }
+        return v;
+    };
+    if (vec_ok) {
+        const int64_t n4 = total / 4;
+        const int64_t c4 = cols / 4;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t c = (i % c4) * 4;
+            float4 v = reinterpret_cast<const float4*>(x)[i];
+            v.x = one(v.x, c);
+            v.y = one(v.y, c + 1);
+            v.z = one(v.z, c + 2);
+            v.w = one(v.w, c + 3);
+            if (WRITE) reinterpret_cast<float4*>(y)[i] = v;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+            const float v = one(x[i], i % cols);
+            if (WRITE) y[i] = v;
+        }
+    }
+    // block reduction of (min, nan)
+    uint32_t enc = order_bits(vmin);
+    uint32_t nanf = any_nan ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = __shfl_down(enc, off, 64);
+        enc = o < enc ? o : enc;
+        nanf |= __shfl_down(nanf, off, 64);
+    }
+    __shared__ uint32_t s_enc[4], s_nan[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        s_enc[wave] = enc;
+        s_nan[wave] = nanf;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t e = s_enc[0], f = s_nan[0];
+        for (int w = 1; w < 4; w++) {
+            e = s_enc[w] < e ? s_enc[w] : e;
+            f |= s_nan[w];
+        }
+        if (MIN) atomicMin(&flags[0], e);
+        if (f) atomicOr(&flags[1], 1u);
+    }
+}
+
+int vec_kind(const skr_mat* v, int64_t cols, const char* what, int* kind) {
+    if (!v) {
+        *kind = C_NONE;
+        return SKR_OK;
+    }
+    SKR_REQUIRE(v->rows * v->cols == cols, "%s vector has %lld entries, matrix has %lld columns", what,
+                (long long)(v->rows * v->cols), (long long)cols);
+    SKR_REQUIRE(v->dtype == SKR_F32 || v->dtype == SKR_F64, "%s vector must be float32 or float64", what);
+    *kind = v->dtype == SKR_F32 ? C_F32 : C_F64;
+    return SKR_OK;
+}
+
+template <int CK, int SK, bool PRE, bool POST, bool WRITE, bool MIN>
+void launch_elem(skr_ctx* ctx, const skr_mat* x, const skr_mat* center, const skr_mat* scale, float shift, float* y) {
+    const int64_t total = x->rows * x->cols;
+    int64_t blocks = (total / 4 + 255) / 256;
+    blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, (int64_t)ctx->num_cu * 8));
+    hipLaunchKernelGGL((elementwise_kernel<CK, SK, PRE, POST, WRITE, MIN>), dim3((unsigned)blocks), dim3(256), 0,
+                       ctx->stream, (const float*)x->data, x->rows, x->cols, center ? center->data : nullptr,
+                       scale ? scale->data : nullptr, shift, y, ctx->d_flags);
+}
+
+template <int CK, int SK>
+void dispatch_elem(skr_ctx* ctx, const skr_mat* x, const skr_mat* c, const skr_mat* s, bool pre, bool post, bool write,
+                   bool mn, float shift, float* y) {
+    if (!write) {  // min / nan scan only
+        launch_elem<CK, SK, false, false, false, true>(ctx, x, c, s, shift, y);
+        return;
+    }
+    if (pre && post) launch_elem<CK, SK, true, true, true, false>(ctx, x, c, s, shift, y);
+    else if (pre) launch_elem<CK, SK, true, false, true, false>(ctx, x, c, s, shift, y);
+    else if (post) launch_elem<CK, SK, false, true, true, false>(ctx, x, c, s, shift, y);
+    else launch_elem<CK, SK, false, false, true, false>(ctx, x, c, s, shift, y);
+    (void)mn;
+}
+
+int run_elem(skr_ctx* ctx, const skr_mat* x, const skr_mat* c, const skr_mat* s, bool pre, bool post, bool write,
+             float shift, float* y) {
+    int ck, sk;
+    SKR_TRY(vec_kind(c, x->cols, "center", &ck));
+    SKR_TRY(vec_kind(s, x->cols, "scale", &sk));
+#define CASE(CK_, SK_) \
+    if (ck == CK_ && sk == SK_) dispatch_elem<CK_, SK_>(ctx, x, c, s, pre, post, write, !write, shift, y)
+    CASE(C_NONE, C_NONE);
+    CASE(C_NONE, C_F32);
+    CASE(C_NONE, C_F64);
+    CASE(C_F32, C_NONE);
+    CASE(C_F32, C_F32);
+    CASE(C_F32, C_F64);
+    CASE(C_F64, C_NONE);
+    CASE(C_F64, C_F32);
+    CASE(C_F64, C_F64);
+#undef CASE
+    SKR_HIP(hipGetLastError());
+    return SKR_OK;
+}
+
+int reset_flags(skr_ctx* ctx) {
+    // flags[0] = +inf in ordered encoding is 0xFF800000 -> use all ones (above every float), flags[1] = 0
+    SKR_HIP(hipMemsetAsync(ctx->d_flags, 0xFF, 4, ctx->stream));
+    SKR_HIP(hipMemsetAsync(ctx->d_flags + 1, 0, 4, ctx->stream));
+    return SKR_OK;
+}
+
+int read_flags(skr_ctx* ctx) {
+    SKR_HIP(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SKR_HIP(hipStreamSynchronize(ctx->stream));
+    return SKR_OK;
+}
+
+int check_f32(const skr_ctx* ctx, const skr_mat* m, const char* what) {
+    SKR_REQUIRE(m, "%s is NULL", what);
+    SKR_REQUIRE(m->ctx == ctx, "%s belongs to a different ctx", what);
+    SKR_REQUIRE(m->dtype == SKR_F32, "%s must be float32", what);
+    return SKR_OK;
+}
+
+}  // namespace
+
+extern "C" int skr_colsum_seq(skr_ctx* ctx, const skr_mat* x, const skr_mat* center, const skr_mat* center2,
+                              int square, skr_mat* acc) {
+    SKR_REQUIRE(ctx, "ctx is NULL");
+    SKR_TRY(check_f32(ctx, x, "x"));
+    SKR_TRY(check_f32(ctx, acc, "acc"));
+    SKR_REQUIRE(acc->rows * acc->cols == x->cols, "acc must hold one float per column");
+    int ck;
+    SKR_TRY(vec_kind(center, x->cols, "center", &ck));
+    if (center2) {
+        SKR_REQUIRE(square, "center2 is only used with square != 0");
+        SKR_TRY(check_f32(ctx, center2, "center2"));
+        SKR_REQUIRE(center2->rows * center2->cols == x->cols, "center2 must hold one float per column");
+    }
+    SKR_TRY(skr_activate(ctx));
+    if (x->cols == 0) return SKR_OK;
+    const unsigned grid = (unsigned)((x->cols + kColsPerWG - 1) / kColsPerWG);
+    const float* c2 = center2 ? (const float*)center2->data : nullptr;
+    const void* c1 = center ? center->data : nullptr;
+    SkrProfScope prof(ctx, square ? "colsum_seq_sq" : "colsum_seq");
+#define LAUNCH(CK_, SQ_)                                                                                         \
+    hipLaunchKernelGGL((colsum_seq_kernel<CK_, SQ_>), dim3(grid), dim3(kThreads), 0, ctx->stream,                \
+                       (const float*)x->data, x->rows, x->cols, c1, c2, (float*)acc->data)
+    if (square) {
+        if (ck == C_NONE) LAUNCH(C_NONE, true);
+        else if (ck == C_F32) LAUNCH(C_F32, true);
+        else LAUNCH(C_F64, true);
+    } else {
+        if (ck == C_NONE) LAUNCH(C_NONE, false);
+        else if (ck == C_F32) LAUNCH(C_F32, false);
+        else LAUNCH(C_F64, false);
+    }
+#undef LAUNCH
+    SKR_HIP(hipGetLastError());
+    return SKR_OK;
+}
+
+extern "C" int skr_vec_finish(skr_ctx* ctx, skr_mat* v, int64_t n, int take_sqrt) {
+    SKR_REQUIRE(ctx, "ctx is NULL");
+    SKR_TRY(check_f32(ctx, v, "v"));
+    SKR_TRY(skr_activate(ctx));
+    const int64_t cols = v->rows * v->cols;
+    if (cols == 0) return SKR_OK;
+    hipLaunchKernelGGL(vec_finish_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (float*)v->data, cols, (float)n, take_sqrt);
+    SKR_HIP(hipGetLastError());
+    return SKR_OK;
+}
+
+extern "C" int skr_min_nan(skr_ctx* ctx, const skr_mat* x, const skr_mat* center, const skr_mat* scale,
+                           float* min_out, int* has_nan) {
+    SKR_REQUIRE(ctx, "ctx is NULL");
+    SKR_TRY(check_f32(ctx, x, "x"));
+    SKR_TRY(skr_activate(ctx));
+    SKR_TRY(reset_flags(ctx));
+    if (x->rows * x->cols > 0) {
+        SkrProfScope prof(ctx, "elementwise_min");
+        SKR_TRY(run_elem(ctx, x, center, scale, false, false, /*write=*/false, 0.f, nullptr));
+    }
+    SKR_TRY(read_flags(ctx));
+    const bool nan = ctx->h_flags[1] != 0;
+    if (has_nan) *has_nan = nan ? 1 : 0;
+    if (min_out) *min_out = nan ? NAN : unorder_bits(ctx->h_flags[0]);
+    return SKR_OK;
+}
+
+extern "C" int skr_apply(skr_ctx* ctx, const skr_mat* x, int pre, const skr_mat* center, const skr_mat* scale,
+                         int post, float shift, skr_mat* y, int* has_nan) {
+    SKR_REQUIRE(ctx, "ctx is NULL");
+    SKR_TRY(check_f32(ctx, x, "x"));
+    SKR_TRY(check_f32(ctx, y, "y"));
+    SKR_REQUIRE(x->rows == y->rows && x->cols == y->cols, "x and y shapes differ");
+    SKR_TRY(skr_activate(ctx));
+    SKR_TRY(reset_flags(ctx));
+    if (x->rows * x->cols > 0) {
+        SkrProfScope prof(ctx, "elementwise_apply");
+        SKR_TRY(run_elem(ctx, x, center, scale, pre != 0, post != 0, /*write=*/true, shift, (float*)y->data));
+    }
+    if (has_nan) {
+        SKR_TRY(read_flags(ctx));
+        *has_nan = ctx->h_flags[1] != 0;
+    }
+    return SKR_OK;
+}
+
+extern "C" int skr_normalize(skr_ctx* ctx, skr_mat* x, int log2_mode, int mean_mode, const skr_mat* mean_vec,
+                             int std_mode, const skr_mat* std_vec, skr_mat* mean_out, skr_mat* std_out,
+                             int* has_nan) {
+    SKR_REQUIRE(ctx, "ctx is NULL");
+    SKR_TRY(check_f32(ctx, x, "x"));
+    SKR_REQUIRE(log2_mode >= SKR_LOG2_NONE && log2_mode <= SKR_LOG2_POST, "bad log2 mode %d", log2_mode);
+    SKR_REQUIRE(mean_mode >= 0 && mean_mode <= 2 && std_mode >= 0 && std_mode <= 2, "bad mean/std mode");
+    SKR_REQUIRE(mean_mode != 2 || mean_vec, "mean_mode 2 needs mean_vec");
+    SKR_REQUIRE(std_mode != 2 || std_vec, "std_mode 2 needs std_vec");
+    SKR_REQUIRE(mean_mode != 1 || mean_out, "mean_mode 1 needs mean_out");
+    SKR_REQUIRE(std_mode != 1 || std_out, "std_mode 1 needs std_out");
+    SKR_TRY(skr_activate(ctx));
+    if (has_nan) *has_nan = 0;
+    const int64_t n = x->rows;
+    // Log2.pre is applied eagerly (the statistics are statistics of log2(count + 1), :201-202)
+    if (log2_mode == SKR_LOG2_PRE) SKR_TRY(skr_apply(ctx, x, 1, nullptr, nullptr, 0, 0.f, x, nullptr));
+    // centre (:165-169): the matrix itself stays raw; the transform is replayed by later passes
+    const skr_mat* center = nullptr;
+    if (mean_mode == 1) {
+        SKR_TRY(check_f32(ctx, mean_out, "mean_out"));
+        SKR_TRY(skr_mat_fill_zero(mean_out));
+        SKR_TRY(skr_colsum_seq(ctx, x, nullptr, nullptr, 0, mean_out));
+        SKR_TRY(skr_vec_finish(ctx, mean_out, n, 0));
+        center = mean_out;
+    } else if (mean_mode == 2) {
+        center = mean_vec;
+    }
+    // standardise (:171-175): np.std of the centred matrix = its own mean m', then squares
+    const skr_mat* scale = nullptr;
+    if (std_mode == 1) {
+        SKR_TRY(check_f32(ctx, std_out, "std_out"));
+        skr_mat* mprime = nullptr;
+        SKR_TRY(skr_mat_create(ctx, 1, x->cols, SKR_F32, &mprime));
+        int rc = skr_mat_fill_zero(mprime);
+        if (rc == SKR_OK) rc = skr_colsum_seq(ctx, x, center, nullptr, 0, mprime);
+        if (rc == SKR_OK) rc = skr_vec_finish(ctx, mprime, n, 0);
+        if (rc == SKR_OK) rc = skr_mat_fill_zero(std_out);
+        if (rc == SKR_OK) rc = skr_colsum_seq(ctx, x, center, mprime, 1, std_out);
+        if (rc == SKR_OK) rc = skr_vec_finish(ctx, std_out, n, 1);
+        skr_mat_free(mprime);
+        SKR_TRY(rc);
+        scale = std_out;
+    } else if (std_mode == 2) {
+        scale = std_vec;
+    }
+    float shift = 0.f;
+    if (log2_mode == SKR_LOG2_POST) {
+        float mn = 0.f;
+        SKR_TRY(skr_min_nan(ctx, x, center, scale, &mn, nullptr));
+        shift = fabsf(mn);  // NaN stays NaN (np.abs(np.min(...)), :208)
+    }
+    int nan_after_scale = 0;
+    if (center || scale || log2_mode == SKR_LOG2_POST)
+        SKR_TRY(skr_apply(ctx, x, 0, center, scale, log2_mode == SKR_LOG2_POST, shift, x,
+                          (scale && has_nan) ? &nan_after_scale : nullptr));
+    if (has_nan) *has_nan = nan_after_scale;
+    return SKR_OK;
+}

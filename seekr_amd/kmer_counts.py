@@ -1,0 +1,266 @@
+"""k-mer count matrices on MI355X — drop-in for `seekr.kmer_counts` (kmer_counts.py:48-262).
+
+`BasicCounter` keeps the reference's constructor, public attributes and methods; the work is
+done by hand-written HIP kernels behind `libseekr_hip.so`:
+
+    sequences --pack 2 bit/base--> HBM --count_kmers (LDS histogram + per-kb scale)-->
+    float32 [N, 4^k] in HBM --colsum_seq / elementwise (numpy-order normalisation)--> host
+
+There is no CPU fallback: without the library or without a gfx950 device every method that
+computes raises.
+"""
+from itertools import product
+
+import numpy as np
+
+from seekr_amd import _lib
+from seekr_amd.fasta_reader import Reader
+from seekr_amd.my_tqdm import my_tqdm
+
+_LOG2_CHOICES = ["Log2.pre", "Log2.post", "Log2.none"]
+
+NAN_WARNING = (
+    "\nWARNING: You have `np.nan` values in your counts "
+    "after standardization. This is likely due to "
+    "a kmer not appearing in any of your sequences. "
+    "Try: \n1) using a smaller kmer size, \n2) beginning "
+    "with a larger set of sequences, \n3) passing "
+    "precomputed normalization vectors from a larger "
+    "data set (e.g. GENCODE)."
+)
+
+
+def _as_device_vector(ctx, vec, n_cols):
+    """User mean/std vector -> 1 x K device vector; float32 stays float32, everything else is
+    evaluated in float64 and rounded once, like numpy's in-place `counts -= vec`."""
+    arr = np.asarray(vec)
+    if arr.dtype == np.float32 or arr.dtype == np.float16:
+        arr = arr.astype(np.float32, copy=False)
+    else:
+        arr = arr.astype(np.float64)
+    arr = np.ascontiguousarray(np.broadcast_to(arr, (n_cols,)))
+    return ctx.from_numpy(arr)
+
+
+class BasicCounter:
+    """Generates overlapping k-mer counts for a fasta file (reference: kmer_counts.py:48-135).
+
+    Parameters
+    ----------
+    infasta : str, optional        path of the FASTA file to count
+    outfile : str, optional        where `save` writes
+    k : int                        k-mer length (1..7 on the LDS-histogram path)
+    binary : bool                  save as .npy if True, else csv
+    mean, std : bool | ndarray | str
+        True = compute from the data, False = skip, str = np.load(path), array = use as given
+    log2 : 'Log2.post' | 'Log2.pre' | 'Log2.none'
+    leave, silent : progress-bar options (cosmetic; counting is one kernel launch)
+    label : bool                   label rows/columns of a csv
+    alphabet : str                 4 letters; column order follows `itertools.product`
+    """
+
+    def __init__(self, infasta=None, outfile=None, k=6, binary=True, mean=True, std=True, log2="Log2.post",
+                 leave=True, silent=False, label=False, alphabet="AGTC"):
+        self.infasta = infasta
+        self._seqs = None
+        self._packed = None  # PackedSeqs resident in HBM (native FASTA path)
+        self.alphabet = alphabet
+        if infasta is not None:
+            # kmer_counts.py:103-105 reads the file here; errors of the reader surface here too
+            self._packed = _lib.default_context().pack_fasta(infasta, alphabet) if len(alphabet) == 4 else None
+            if self._packed is None:
+                self._seqs = Reader(infasta).get_seqs()
+        self.outfile = outfile
+        self.k = k
+        self.binary = binary
+        self.mean = np.load(mean) if isinstance(mean, str) else mean
+        self.std = np.load(std) if isinstance(std, str) else std
+        self.log2 = log2
+        self.leave = leave
+        self.silent = silent
+        self.label = label
+        self.counts = None
+        self.alpha_len = len(alphabet)
+        self.kmers = ["".join(t) for t in product(alphabet, repeat=k)]
+        self.map = {kmer: col for col, kmer in enumerate(self.kmers)}
+
+        n_seqs = self._packed.n if self._packed is not None else (len(self._seqs) if self._seqs is not None else None)
+        if n_seqs == 1 and self.std is True:
+            raise ValueError(
+                "You cannot standardize a single sequence. "
+                "Please pass the path to an std. dev. array, "
+                "or use raw counts by setting std=False."
+            )
+        if self.log2 not in _LOG2_CHOICES:
+            raise ValueError("log2 must be one of ['Log2.pre', 'Log2.post', 'Log2.none']")
+
+    # ---- `seqs` keeps the reference's public attribute (list of str), materialised lazily ----
+    @property
+    def seqs(self):
+        if self._seqs is None and self.infasta is not None:
+            self._seqs = Reader(self.infasta).get_seqs()
+        return self._seqs
+
+    @seqs.setter
+    def seqs(self, value):
+        self._seqs = value
+        self._packed = None  # caller-assigned sequences win over the packed file
+
+    def _ctx(self):
+        return _lib.default_context()
+
+    def _packed_seqs(self):
+        if self._packed is not None:
+            return self._packed
+        if self._seqs is None:
+            raise TypeError("BasicCounter has no sequences: pass infasta or assign `seqs`")
+        return self._ctx().pack(self._seqs, self.alphabet)
+
+    def _check_k(self):
+        if not isinstance(self.k, (int, np.integer)) or self.k < 1:
+            raise ValueError("k must be a positive integer")
+
+    # ---- kmer_counts.py:140-151 -----------------------------------------------------------
+    def occurrences(self, row, seq):
+        """Counts k-mers of one sequence on a per-kilobase scale into `row` (any float dtype).
+
+        Bins of k-mers that do not occur keep their previous content, exactly like the
+        reference's dict-driven assignment."""
+        self._check_k()
+        ctx = self._ctx()
+        packed = ctx.pack([seq], self.alphabet)
+        n = _lib.count_u32(ctx, packed, self.k).to_numpy()[0]
+        vals = _lib.count_per_kb(ctx, packed, self.k, dtype=np.float64).to_numpy()[0]
+        present = n > 0
+        row[present] = vals[present]
+        return row
+
+    def _progress(self):
+        """The reference iterates sequences under a tqdm bar (:153-163); counting here is one
+        launch, so the bar is advanced once by the number of sequences."""
+        if self.silent:
+            return None
+        total = self._packed.n if self._packed is not None else len(self._seqs)
+        if not self.leave:
+            return my_tqdm()(total=total, desc="Kmers", leave=False)
+        return my_tqdm()(total=total)
+
+    # ---- host-array versions of the normalisation steps (kmer_counts.py:165-192) -----------
+    def _device_counts(self):
+        counts = np.asarray(self.counts)
+        if counts.ndim != 2:
+            raise ValueError("counts must be a 2-D matrix")
+        if counts.dtype != np.float32:
+            raise TypeError("the MI355X normalisation kernels work on float32 count matrices "
+                            "(got {}); get_counts() always produces float32".format(counts.dtype))
+        return self._ctx().from_numpy(counts)
+
+    def _store(self, dev):
+        if isinstance(self.counts, np.ndarray) and self.counts.flags.c_contiguous and self.counts.flags.writeable:
+            dev.to_numpy(out=self.counts)  # in place, like `self.counts -= ...`
+        else:
+            self.counts = dev.to_numpy()
+
+    def center(self):
+        """Mean center counts by column (:165-169)."""
+        ctx = self._ctx()
+        dev = self._device_counts()
+        if self.mean is True:
+            acc = ctx.zeros(1, dev.cols)
+            _lib.colsum_seq(ctx, dev, acc)
+            _lib.vec_finish(ctx, acc, dev.rows)
+            self.mean = acc.vector()
+            mean_dev = acc
+        else:
+            mean_dev = _as_device_vector(ctx, self.mean, dev.cols)
+        _lib.apply(ctx, dev, center=mean_dev)
+        self._store(dev)
+
+    def standardize(self):
+        """Divide out the standard deviations from columns of the count matrix (:171-187)."""
+        ctx = self._ctx()
+        dev = self._device_counts()
+        if self.std is True:
+            mprime = ctx.zeros(1, dev.cols)
+            _lib.colsum_seq(ctx, dev, mprime)
+            _lib.vec_finish(ctx, mprime, dev.rows)
+            var = ctx.zeros(1, dev.cols)
+            _lib.colsum_seq(ctx, dev, var, center2=mprime, square=True)
+            _lib.vec_finish(ctx, var, dev.rows, take_sqrt=True)
+            self.std = var.vector()
+            std_dev = var
+        else:
+            std_dev = _as_device_vector(ctx, self.std, dev.cols)
+        _, has_nan = _lib.apply(ctx, dev, scale=std_dev, want_nan=True)
+        self._store(dev)
+        if has_nan:
+            print(NAN_WARNING)
+
+    def log2_norm(self):
+        """Apply a log2 transform to the count matrix (:189-192): counts += 1; log2."""
+        ctx = self._ctx()
+        dev = self._device_counts()
+        _lib.apply(ctx, dev, pre=True)
+        self.counts = dev.to_numpy()
+
+    # ---- kmer_counts.py:194-209 -------------------------------------------------------------
+    def get_counts(self):
+        """Generates k-mer counts for the sequences: count -> Log2.pre -> centre ->
+        standardise -> Log2.post, all on the GPU; `self.counts` receives the float32 result."""
+        self._check_k()
+        ctx = self._ctx()
+        bar = self._progress()
+        packed = self._packed_seqs()
+        dev = _lib.count_per_kb(ctx, packed, self.k, log2_pre=(self.log2 == "Log2.pre"))
+        if bar is not None:
+            bar.update(packed.n)
+            bar.close()
+        mean_mode, mean_vec = 0, None
+        if self.mean is True:
+            mean_mode = 1
+        elif self.mean is not False:
+            mean_mode, mean_vec = 2, _as_device_vector(ctx, self.mean, dev.cols)
+        std_mode, std_vec = 0, None
+        if self.std is True:
+            std_mode = 1
+        elif self.std is not False:
+            std_mode, std_vec = 2, _as_device_vector(ctx, self.std, dev.cols)
+        # Log2.pre was fused into the counting flush, so the normaliser sees 'none' for it
+        log2 = "Log2.post" if self.log2 == "Log2.post" else "Log2.none"
+        mean_out, std_out, has_nan = _lib.normalize(ctx, dev, log2, mean_mode, mean_vec, std_mode, std_vec)
+        if mean_out is not None:
+            self.mean = mean_out.vector()
+        if std_out is not None:
+            self.std = std_out.vector()
+        self.counts = dev.to_numpy()
+        if has_nan:
+            print(NAN_WARNING)
+
+    # ---- kmer_counts.py:211-241 -------------------------------------------------------------
+    def save(self, names=None):
+        """Saves the counts: .npy (binary), labelled csv (label) or plain csv (%1.6f)."""
+        err_msg = (
+            "You cannot label a binary file. "
+            'Set only one of "binary" or "label" as True. '
+            "If you used `-b` from the command line, "
+            "try also using `-rl`."
+        )
+        assert not (self.binary and self.label), err_msg
+        assert self.outfile is not None, "Please provide an outfile location."
+        if self.binary:
+            np.save(self.outfile, self.counts)
+        elif self.label:
+            from pandas import DataFrame
+            if names is None:
+                names = self._packed.headers() if self._packed is not None else Reader(self.infasta).get_headers()
+            DataFrame(data=self.counts, index=names, columns=self.kmers).to_csv(self.outfile)
+        else:
+            np.savetxt(self.outfile, self.counts, delimiter=",", fmt="%1.6f")
+
+    # ---- kmer_counts.py:243-262 -------------------------------------------------------------
+    def make_count_file(self, names=None):
+        """get_counts() then save() when an outfile was given; returns the count matrix."""
+        self.get_counts()
+        if self.outfile is not None:
+            self.save(names)
+        return self.counts

@@ -1,0 +1,53 @@
+"""All-pairs Pearson correlation of k-mer profiles on MI355X — drop-in for `seekr.pearson`
+(pearson.py:32-44): same signature, same dtype promotion, same NaN behaviour.
+
+float32 inputs run on the f32-input MFMA (`SEEKR_PRECISION=fp32`, default) or the split-bf16
+MFMA path (`SEEKR_PRECISION=bf16x3`); anything else (float64, integers, DataFrames read from
+CSV) is promoted to float64 like numpy does and runs on the f64 MFMA.
+"""
+import os
+
+import numpy as np
+
+from seekr_amd import _lib
+
+
+def _as_matrix(counts):
+    arr = counts.values if hasattr(counts, "values") and not isinstance(counts, np.ndarray) else counts
+    arr = np.asarray(arr)
+    if arr.ndim != 2:
+        raise ValueError("pearson expects 2-D count matrices, got shape {}".format(arr.shape))
+    return arr
+
+
+def _precision_for(dtype):
+    if dtype == np.float64:
+        return _lib.PREC_F64
+    name = os.environ.get("SEEKR_PRECISION", "fp32").lower()
+    if name not in ("fp32", "bf16x3"):
+        raise ValueError("SEEKR_PRECISION must be 'fp32' or 'bf16x3', got {!r}".format(name))
+    return _lib.PRECISIONS[name]
+
+
+def pearson(counts1, counts2, row_standardize=True, outfile=None):
+    """Calculates a column standardized Pearson correlation matrix (pearson.py:32-44).
+
+    r[i, j] = <z1_i, z2_j> / K with z the row-standardised counts (population std, computed
+    on the centred row) when `row_standardize`, else the raw inner product / K.
+    """
+    c1, c2 = _as_matrix(counts1), _as_matrix(counts2)
+    if c1.shape[1] != c2.shape[1]:
+        raise ValueError("shapes {} and {} not aligned: {} (dim 1) != {} (dim 1)".format(
+            c1.shape, c2.shape, c1.shape[1], c2.shape[1]))
+    # numpy promotion of the reference: f32 with f32 stays f32, everything else becomes f64
+    # (np.mean of an integer matrix is float64)
+    work = np.float32 if (c1.dtype == np.float32 and c2.dtype == np.float32) else np.float64
+    ctx = _lib.default_context()
+    same = c1 is c2 or (c1.shape == c2.shape and c1.ctypes.data == c2.ctypes.data and c1.strides == c2.strides)
+    d1 = ctx.from_numpy(c1.astype(work, copy=False))
+    d2 = d1 if same else ctx.from_numpy(c2.astype(work, copy=False))
+    r = _lib.pearson(ctx, d1, d2, row_standardize=row_standardize, precision=_precision_for(np.dtype(work)))
+    dist = r.to_numpy()
+    if outfile:
+        np.save(outfile, dist)
+    return dist

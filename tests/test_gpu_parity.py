@@ -1,0 +1,476 @@
+"""Parity of the HIP path (through the C-ABI / the seekr_amd API) with the oracle and with the
+golden vectors captured from the reference.  Needs a real MI355X: run with `-m gpu`.
+
+Bars (BASELINE.json north_star): integer counts and everything that is pure IEEE arithmetic
+(per-kb float32 counts, column mean/std, centred / standardised values) BIT-EXACT;
+log2 outputs and Pearson r within |a-b| <= atol + 1e-5 |b| with atol stated per test.
+"""
+import hashlib
+import io
+import json
+import os
+import contextlib
+
+import numpy as np
+import pytest
+
+from oracle import seekr_oracle as orc
+from inputs import EXAMPLE_FA, big_count_matrix, skewed_set, synth_2000, write_fasta
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+ATOL_R = 2e-6      # Pearson r (the reference's own error vs fp64 is 4.8e-7)
+ATOL_LOG = 1e-6    # log2 outputs (values in [0, ~5]; device log2f vs numpy log2: <= 1 ulp)
+
+
+def sha16(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_bits(a, b, what=""):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    bad = bits(a) != bits(b)
+    both_nan = np.isnan(a) & np.isnan(b)
+    bad &= ~both_nan
+    assert not bad.any(), "{}: {} of {} cells differ, first at {}: {} vs {}".format(
+        what, int(bad.sum()), bad.size, np.argwhere(bad)[0], a[bad][0], b[bad][0])
+
+
+@pytest.fixture(scope="module")
+def L():
+    from seekr_amd import _lib
+    return _lib
+
+
+@pytest.fixture(scope="module")
+def ctx(L):
+    return L.default_context()
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    out = {name: np.load(os.path.join(golden_dir, name + ".npz")) for name in
+           ("reference_fixtures", "g1_example", "g3_skewed", "g4_synth2000", "g5_bigN", "g6_edges")}
+    with open(os.path.join(golden_dir, "meta.json")) as fh:
+        out["meta"] = json.load(fh)
+    return out
+
+
+@pytest.fixture(scope="module")
+def example_fa(tmp_path_factory):
+    p = tmp_path_factory.mktemp("fa") / "example.fa"
+    p.write_text(EXAMPLE_FA)
+    return str(p)
+
+
+def counter(seqs=None, **kw):
+    from seekr_amd.kmer_counts import BasicCounter
+    c = BasicCounter(silent=True, **kw)
+    if seqs is not None:
+        c.seqs = list(seqs)
+    return c
+
+
+def run(seqs, **kw):
+    c = counter(seqs, **kw)
+    with contextlib.redirect_stdout(io.StringIO()):
+        c.get_counts()
+    return c
+
+
+# ------------------------------------------------------------------ config 1 + reference KATs
+def test_cfg1_example_raw_counts_bitexact(example_fa, gold, L, ctx):
+    from seekr_amd.kmer_counts import BasicCounter
+    g1 = gold["g1_example"]
+    for k in (1, 2, 3):
+        c = BasicCounter(example_fa, k=k, mean=False, std=False, log2="Log2.none", silent=True)
+        c.get_counts()
+        assert c.counts.dtype == np.float32
+        assert_bits(c.counts, g1["raw_k%d" % k], "example raw k=%d" % k)
+        assert sha16(c.counts) == gold["meta"]["example_raw_k%d_sha" % k]
+    n = L.count_u32(ctx, ctx.pack_fasta(example_fa), 2).to_numpy()
+    assert n.dtype == np.uint32 and n.sum(axis=1).tolist() == [5, 11, 15, 74, 75]
+    assert np.array_equal(n, orc.count_kmers_u32(orc.read_fasta(example_fa)[1], 2))
+
+
+def test_reference_known_answers_through_api(example_fa, gold):
+    """seekr/tests/test_kmer_counts.py:13-117 and test_pearson.py:7-24 replayed on the HIP path."""
+    from seekr_amd.kmer_counts import BasicCounter
+    from seekr_amd.pearson import pearson
+    c = BasicCounter(example_fa, k=1, silent=True)
+    assert len(c.seqs) == 5 and c.seqs[0] == "AAAAAA"
+    assert np.allclose(c.occurrences(np.zeros(4), c.seqs[0]), [1000, 0, 0, 0])
+    assert np.allclose(c.occurrences(np.zeros(4), c.seqs[1]), [0, 500, 500, 0])
+    c2 = BasicCounter(example_fa, k=2, silent=True)
+    exp = np.zeros(16)
+    exp[5], exp[9], exp[10] = 454.545, 90.909, 454.545
+    row = c2.occurrences(np.zeros(16), c2.seqs[1])
+    assert np.allclose(row, exp)
+    assert np.array_equal(row, gold["g6_edges"]["kat_occ_k2_seq1"])  # float64 row: exact replay
+    # center / standardize / log2_norm on hand-assigned matrices
+    c.counts = np.array([[1, 2, 3, 4], [1, -2, 5, 10]], dtype=np.float32)
+    c.center()
+    assert np.allclose(c.counts, [[0, 2, -1, -3], [0, -2, 1, 3]])
+    c = BasicCounter(example_fa, k=1, silent=True)
+    c.counts = np.array([[1, 2, 3, 4], [1, -2, 5, 10]], dtype=np.float32)
+    c.mean = np.array([1, 1, 1, -1.0])
+    c.center()
+    assert np.allclose(c.counts, [[0, 1, 2, 5], [0, -3, 4, 11]])
+    c = BasicCounter(example_fa, k=1, silent=True)
+    c.counts = np.array([[1, 2, 3, 4], [0, -2, 5, 10]], dtype=np.float32)
+    c.standardize()
+    assert np.allclose(c.counts, [[2, 1, 3, 4 / 3], [0, -1, 5, 10 / 3]])
+    c = BasicCounter(example_fa, k=1, silent=True)
+    c.counts = np.array([[1, 2, 3, 4], [0, -2, 5, 10]], dtype=np.float32)
+    c.std = np.arange(1, 5)
+    c.standardize()
+    assert np.allclose(c.counts, [[1, 1, 1, 1], [0, -1, 5 / 3, 2.5]])
+    c.counts = np.array([[3, 4, 5, 6], [2, 0, 7, 12]], dtype=np.float32)
+    c.log2_norm()
+    assert np.allclose(c.counts, np.log2(np.array([[4, 5, 6, 7], [3, 1, 8, 13]], dtype=np.float32)))
+    c = BasicCounter(example_fa, k=1, silent=True)
+    c.get_counts()
+    expected = np.array([[2.1798673, 0.27807194, 0.0, 0.5133058],
+                         [0.6370419, 2.1100981, 2.048016, 0.5133058],
+                         [1.2010899, 1.4672222, 1.3604679, 1.8107259],
+                         [1.2073011, 1.3895708, 1.3721647, 1.8666755],
+                         [1.318994, 1.1856667, 1.5349197, 1.6688585]], dtype=np.float32)
+    assert np.allclose(c.counts, expected, rtol=1e-4, atol=1e-5)
+    # pearson literals (integer inputs -> float64 path)
+    c1 = np.array([[8, 5, 6, 9, 2], [8, 3, 6, 6, 7], [7, 7, 3, 3, 7]])
+    c2_ = np.array([[2, 8, -9, -1, -8], [-4, 1, 2, -1, 2], [5, -3, -7, 2, -9]])
+    r = pearson(c1, c2_)
+    assert r.dtype == np.float64
+    assert np.allclose(r, [[0.3217847, -0.71611487, 0.85110363], [-0.52756992, -0.47172818, 0.22652512],
+                           [0.43762719, -0.17902872, 0.01547461]])
+    assert np.allclose(r, gold["g6_edges"]["kat_pearson_int"], rtol=1e-12, atol=1e-14)
+    one = np.array([[1, 2, 3, 4], [2, 4, 6, 8]])
+    assert np.allclose(pearson(one, one), np.ones((2, 2)))
+
+
+def test_reference_data_fixtures_through_cli(example_fa, gold, tmp_path):
+    """seekr/tests/test_console_scripts.py:34-124 against the reference's own data files."""
+    from seekr_amd import console_scripts as cs
+    fx = gold["reference_fixtures"]
+    out = str(tmp_path / "2mers.npy")
+    cs._run_kmer_counts(example_fa, out, 2, True, True, True, "Log2.post", True, None, None, "AGTC")
+    assert np.allclose(np.load(out), fx["example_2mers_counts"])
+    out = str(tmp_path / "3mers.csv")
+    cs._run_kmer_counts(example_fa, out, 3, False, False, False, "Log2.none", True, None, None, "AGTC")
+    assert np.array_equal(np.loadtxt(out, delimiter=","), fx["example_3mers_raw_csv"])
+    mv, sv = str(tmp_path / "mean.npy"), str(tmp_path / "std.npy")
+    cs._run_norm_vectors(example_fa, mv, sv, "Log2.none", 2)
+    assert_bits(np.load(mv), fx["example_mean"], "norm vector mean")
+    assert_bits(np.load(sv), fx["example_std"], "norm vector std")
+    out = str(tmp_path / "2mers_vectors.npy")
+    cs._run_kmer_counts(example_fa, out, 2, True, False, False, "Log2.post", True, mv, sv, "AGTC")
+    assert np.allclose(np.load(out), fx["example_2mers_count"])
+    # seekr_pearson: .npy in/out and labelled csv in/out
+    cs._run_kmer_counts(example_fa, str(tmp_path / "lab.csv"), 2, False, True, True, "Log2.post", False, None, None,
+                        "AGTC")
+    cs._run_pearson(str(tmp_path / "lab.csv"), str(tmp_path / "lab.csv"), str(tmp_path / "r.csv"), False, False)
+    import pandas as pd
+    rdf = pd.read_csv(str(tmp_path / "r.csv"), index_col=0)
+    assert list(rdf.index) == [">SEQ1", ">SEQ2", ">SEQ3", ">SEQ4", ">SEQ5"] == list(rdf.columns)
+    cs._run_pearson(str(tmp_path / "2mers.npy"), str(tmp_path / "2mers.npy"), str(tmp_path / "r.npy"), True, True)
+    rb = np.load(str(tmp_path / "r.npy"))
+    assert rb.dtype == np.float32
+    assert np.allclose(rb, orc.pearson(fx["example_2mers_counts"], fx["example_2mers_counts"]), rtol=RTOL, atol=ATOL_R)
+    assert np.allclose(rdf.values, rb, rtol=1e-5, atol=1e-5)  # csv text round trip of the counts
+
+
+# ------------------------------------------------------------------ golden vectors
+def test_g1_example_pipelines(example_fa, gold):
+    g1 = gold["g1_example"]
+    seqs = orc.read_fasta(example_fa)[1]
+    for k in (1, 2):
+        for tag in ("post", "pre", "none"):
+            mode = "Log2." + tag
+            with np.errstate(all="ignore"):
+                c = run(seqs, k=k, log2=mode)
+                if tag == "pre":  # statistics of log2 values: device log2f may differ in the last ulp
+                    assert np.allclose(c.mean, g1["full_pre_k%d_mean" % k], rtol=RTOL, atol=ATOL_LOG)
+                    assert np.allclose(c.std, g1["full_pre_k%d_std" % k], rtol=RTOL, atol=ATOL_LOG)
+                else:
+                    assert_bits(c.mean, g1["full_%s_k%d_mean" % (tag, k)], "mean %s k%d" % (tag, k))
+                    assert_bits(c.std, g1["full_%s_k%d_std" % (tag, k)], "std %s k%d" % (tag, k))
+                if tag == "none":
+                    assert_bits(c.counts, g1["full_none_k%d" % k], "z k%d" % k)
+                else:
+                    assert np.allclose(c.counts, g1["full_%s_k%d" % (tag, k)], rtol=RTOL, atol=2e-6, equal_nan=True)
+                v = run(seqs, k=k, log2=mode, mean=g1["mean_none_k%d" % k], std=g1["std_none_k%d" % k])
+                assert np.allclose(v.counts, g1["vec_%s_k%d" % (tag, k)], rtol=RTOL, atol=2e-6, equal_nan=True)
+                mo = run(seqs, k=k, log2=mode, mean=True, std=False)
+                assert np.allclose(mo.counts, g1["meanonly_%s_k%d" % (tag, k)], rtol=RTOL, atol=2e-6, equal_nan=True)
+
+
+def test_g3_skewed_sets_counts_and_pearson(gold):
+    from seekr_amd.pearson import pearson
+    g3 = gold["g3_skewed"]
+    s1, s2 = skewed_set(101, 111), skewed_set(202, 151)
+    assert_bits(run(s1, k=4, mean=False, std=False, log2="Log2.none").counts, g3["s1_raw_k4"], "raw k4")
+    for k in (4, 5):
+        nv = run(s1, k=k)
+        assert_bits(nv.mean, g3["mean_k%d" % k], "mean k%d" % k)
+        assert_bits(nv.std, g3["std_k%d" % k], "std k%d" % k)
+        c1 = run(s1, k=k, mean=nv.mean, std=nv.std)
+        c2 = run(s2, k=k, mean=nv.mean, std=nv.std)
+        if k == 4:
+            assert np.allclose(c1.counts, g3["s1_counts_k4"], rtol=RTOL, atol=ATOL_LOG)
+            assert np.allclose(nv.counts, g3["s1_self_default_k4"], rtol=RTOL, atol=ATOL_LOG)
+        r = pearson(c1.counts, c2.counts)
+        assert r.dtype == np.float32 and r.shape == (111, 151)
+        assert np.allclose(r, g3["pearson_k%d" % k], rtol=RTOL, atol=ATOL_R)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        x6 = counter(s1, k=6)
+        x6.get_counts()
+    assert "WARNING: You have `np.nan` values" in buf.getvalue()
+    assert np.isnan(x6.counts).all()  # NaN propagates through np.min (kmer_counts.py:208)
+    assert np.isnan(pearson(x6.counts, x6.counts)).all()
+    a, b = g3["s1_counts_k4"][:7], g3["s1_counts_k4"][7:12]
+    assert np.allclose(pearson(a, b, row_standardize=False), g3["pearson_nostd"], rtol=RTOL, atol=ATOL_R)
+    r64 = pearson(a.astype(np.float64), b.astype(np.float64))
+    assert r64.dtype == np.float64 and np.allclose(r64, g3["pearson_f64"], rtol=1e-12, atol=1e-14)
+    rm = pearson(a, b.astype(np.float64))
+    assert rm.dtype == np.float64 and np.allclose(rm, g3["pearson_mixed"], rtol=1e-12, atol=1e-14)
+
+
+def test_g4_synthetic_2000x2kb(gold, L, ctx):
+    from seekr_amd.pearson import pearson
+    g4, meta = gold["g4_synth2000"], gold["meta"]
+    seqs = synth_2000()
+    packed = ctx.pack(seqs, "AGTC")
+    n = L.count_u32(ctx, packed, 6).to_numpy()
+    assert sha16(n) == meta["g4_u32_sha"] and int(n.sum()) == 2000 * 1995
+    raw = L.count_per_kb(ctx, packed, 6).to_numpy()
+    assert sha16(raw) == meta["g4_raw_sha"]
+    for tag in ("post", "none", "pre"):
+        c = run(seqs, k=6, log2="Log2." + tag)
+        if tag == "pre":
+            assert np.allclose(c.mean, g4["mean_pre"], rtol=RTOL, atol=ATOL_LOG)
+            assert np.allclose(c.std, g4["std_pre"], rtol=RTOL, atol=ATOL_LOG)
+        else:
+            assert_bits(c.mean, g4["mean_" + tag], "mean " + tag)
+            assert_bits(c.std, g4["std_" + tag], "std " + tag)
+        if tag == "none":
+            assert sha16(c.counts) == meta["g4_counts_none_sha"]
+        assert np.allclose(c.counts[:8], g4["counts_%s_head" % tag], rtol=RTOL, atol=2e-6)
+        r = pearson(c.counts[:256], c.counts[:256])
+        assert np.allclose(r, g4["pearson256_" + tag], rtol=RTOL, atol=ATOL_R)
+
+
+def test_g5_large_n_column_stats_bitexact(gold, L, ctx):
+    """50 000 rows: float32 row-sequential drift must be reproduced, not improved upon."""
+    g5 = gold["g5_bigN"]
+    big = big_count_matrix()
+    c = counter(["ACGT"] * 2, k=6)
+    c.counts = big
+    c.center()
+    assert_bits(c.mean, g5["mean"], "mean 50k")
+    c.standardize()
+    assert_bits(c.std, g5["std"], "std 50k")
+    assert_bits(c.counts[0], g5["z_row0"], "z row 0")
+    assert_bits(c.counts[-1], g5["z_rowlast"], "z last row")
+    dev = ctx.from_numpy(c.counts)
+    mn, has_nan = L.min_nan(ctx, dev)
+    assert not has_nan and np.float32(mn) == g5["z_min"]
+
+
+def test_g6_edges(example_fa, gold, tmp_path):
+    from seekr_amd.kmer_counts import BasicCounter
+    from seekr_amd.fasta_reader import Reader
+    from seekr_amd.pearson import pearson
+    g6, edge = gold["g6_edges"], gold["meta"]["edge"]
+    assert_bits(run(edge["edge_seqs"], k=3, mean=False, std=False, log2="Log2.none").counts, g6["edge_raw_k3"], "edges")
+    with pytest.raises(ZeroDivisionError):
+        run(["ACGTAC", "AC"], k=3, mean=False, std=False, log2="Log2.none")
+    seqs = orc.read_fasta(example_fa)[1]
+    assert_bits(run(seqs, k=2, mean=False, std=False, log2="Log2.none", alphabet="ACGT").counts, g6["raw_k2_ACGT"], "ACGT")
+    # reader: python mirror and native packer agree with the reference on a CRLF / multi-line / lower-case file
+    rs = skewed_set(303, 6, 50, 200)
+    p = str(tmp_path / "ml.fa")
+    write_fasta(p, rs, width=60, crlf=True, lower=True)
+    assert Reader(p).get_seqs() == rs and Reader(p).get_headers() == edge["reader_headers"]
+    native = BasicCounter(p, k=3, mean=False, std=False, log2="Log2.none", silent=True)
+    native.get_counts()
+    assert_bits(native.counts, orc.raw_counts(rs, 3), "native fasta")
+    assert native._packed.headers() == edge["reader_headers"]
+    for name, text, exc in (("blank_line", ">a\nACGT\n\n>b\nACGT\n", IndexError),
+                            ("double_header", ">a\nACGT\n>b\n>c\nACGT\n", AssertionError)):
+        q = tmp_path / (name + ".fa")
+        q.write_text(text)
+        for make in (lambda: Reader(str(q)).get_seqs(), lambda: BasicCounter(str(q), k=2)):
+            with pytest.raises(exc) as info:
+                make()
+            assert edge["reader_" + name] == type(info.value).__name__ + ": " + str(info.value)
+    one = tmp_path / "one.fa"
+    one.write_text(">a\nACGTACGT\n")
+    with pytest.raises(ValueError) as info:
+        BasicCounter(str(one), k=2)
+    assert edge["single_seq_infasta"] == "ValueError: " + str(info.value)
+    with pytest.raises(ValueError) as info:
+        BasicCounter(example_fa, k=2, log2="log2")
+    assert edge["bad_log2"] == "ValueError: " + str(info.value)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf), np.errstate(all="ignore"):
+        c = counter(seqs, k=3, log2="Log2.none")
+        c.get_counts()
+    assert buf.getvalue() == edge["nan_warning_text"]
+    assert_bits(c.counts, g6["example_k3_none_with_nan"], "k3 none NaN pattern")
+    with contextlib.redirect_stdout(io.StringIO()):
+        c = counter(seqs, k=3, log2="Log2.post")
+        c.get_counts()
+    assert np.isnan(c.counts).all()
+    c = run(seqs, k=1, log2="Log2.none", mean=np.array([100.0, 200.5, 300.25, 50.125]), std=np.array([3, 7, 11, 13]))
+    assert_bits(c.counts, g6["user_vec_f64_int_k1"], "f64/int user vectors")
+    m = np.array([[1, 2, 3, 4], [5, 5, 5, 5], [4, 1, 3, 2]], dtype=np.float32)
+    r = pearson(m, m)
+    assert np.array_equal(np.isnan(r), np.isnan(g6["pearson_const_row"]))
+    assert np.allclose(r, g6["pearson_const_row"], equal_nan=True, rtol=RTOL, atol=ATOL_R)
+    with pytest.raises(ValueError):
+        pearson(np.zeros((2, 4), np.float32), np.zeros((2, 5), np.float32), row_standardize=False)
+    # save modes
+    out = str(tmp_path / "counts.seekr")
+    c = BasicCounter(example_fa, outfile=out, k=2, binary=True, label=False, silent=True)
+    c.make_count_file()
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("counts.seekr")) == edge["npy_suffix_written"]
+    out = str(tmp_path / "plain.csv")
+    BasicCounter(example_fa, outfile=out, k=2, binary=False, label=False, silent=True, mean=False, std=False,
+                 log2="Log2.none").make_count_file()
+    assert open(out).readline().strip() == edge["plain_csv_first_line"]
+    out = str(tmp_path / "label.csv")
+    BasicCounter(example_fa, outfile=out, k=1, binary=False, label=True, silent=True, mean=False, std=False,
+                 log2="Log2.none").make_count_file()
+    assert open(out).read() == edge["label_csv_text"]
+    with pytest.raises(AssertionError):
+        BasicCounter(example_fa, outfile=out, k=1, binary=True, label=True, silent=True).save()
+
+
+# ------------------------------------------------------------------ seeded sweeps vs the oracle
+def ragged_set(seed, n, lo, hi, n_rate=0.002):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        length = int(rng.integers(lo, hi + 1))
+        s = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=length)
+        bad = rng.random(length) < (n_rate if i % 3 == 0 else 0.0)
+        s = np.where(bad, ord("N"), s).astype(np.uint8)
+        out.append(s.tobytes().decode())
+    # adversarial rows: homopolymer, dinucleotide repeat, all-N, shorter than k, exactly k
+    out += ["A" * 5000, "AC" * 3000, "N" * 300, "ACG", "ACGTACG", "T" * 70000, "ACGT" * 16 + "N" + "ACGT" * 16]
+    return out
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6, 7])
+def test_counts_bitexact_vs_oracle_ragged(k, L, ctx):
+    seqs = [s for s in ragged_set(11 + k, 300, 1, 3000) if len(s) != k - 1]
+    packed = ctx.pack(seqs, "AGTC")
+    n_gpu = L.count_u32(ctx, packed, k).to_numpy()
+    n_ref = orc.count_kmers_u32(seqs, k)
+    assert np.array_equal(n_gpu, n_ref)
+    raw_gpu = L.count_per_kb(ctx, packed, k).to_numpy()
+    assert_bits(raw_gpu, orc.per_kb_from_counts(n_ref, [len(s) for s in seqs], k), "per-kb k=%d" % k)
+    f64 = L.count_per_kb(ctx, packed, k, dtype=np.float64).to_numpy()
+    assert np.array_equal(f64, orc.per_kb_from_counts(n_ref, [len(s) for s in seqs], k, dtype=np.float64))
+
+
+def test_normalize_bitexact_vs_oracle_odd_shapes(L, ctx):
+    rng = np.random.default_rng(3)
+    for rows, cols in ((7, 4), (300, 16), (1025, 64), (513, 100), (2500, 1024)):
+        x = (rng.binomial(40, 0.05, size=(rows, cols)) * np.float32(1000 / 397)).astype(np.float32)
+        x[:, 0] += 1.0  # no zero-variance columns -> no NaN
+        z_ref, mean_ref, std_ref = orc.normalize(x, log2="Log2.none")
+        dev = ctx.from_numpy(x)
+        mean_out, std_out, has_nan = L.normalize(ctx, dev, "Log2.none", 1, None, 1, None)
+        assert not has_nan
+        assert_bits(mean_out.vector(), mean_ref, "mean %dx%d" % (rows, cols))
+        assert_bits(std_out.vector(), std_ref, "std %dx%d" % (rows, cols))
+        assert_bits(dev.to_numpy(), z_ref, "z %dx%d" % (rows, cols))
+        post_ref, _, _ = orc.normalize(x, log2="Log2.post")
+        dev = ctx.from_numpy(x)
+        L.normalize(ctx, dev, "Log2.post", 1, None, 1, None)
+        assert np.allclose(dev.to_numpy(), post_ref, rtol=RTOL, atol=2e-6)
+
+
+def test_colsum_chain_carry_equals_single_pass(L, ctx):
+    """Splitting the rows over shards and passing the accumulator on (the multi-GPU chain)
+    gives the same bits as one pass."""
+    x = big_count_matrix(seed=9, n=6000, k_cols=256)
+    whole = ctx.zeros(1, 256)
+    L.colsum_seq(ctx, ctx.from_numpy(x), whole)
+    acc = ctx.zeros(1, 256)
+    for lo, hi in ((0, 1), (1, 2049), (2049, 2050), (2050, 6000)):
+        L.colsum_seq(ctx, ctx.from_numpy(x[lo:hi]), acc)
+    assert_bits(acc.vector(), whole.vector(), "chained colsum")
+    assert_bits(whole.vector(), orc.seqsum_f32(x), "colsum vs oracle")
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 4), (5, 7, 16), (130, 257, 64), (300, 200, 100), (640, 515, 4096)])
+def test_pearson_fp32_vs_oracle(shape, L, ctx):
+    m, n, k = shape
+    rng = np.random.default_rng(m * 1000 + n)
+    a = rng.gamma(2.0, 1.0, size=(m, k)).astype(np.float32)
+    b = rng.gamma(2.0, 1.0, size=(n, k)).astype(np.float32)
+    if k > 16:
+        b[: min(n, m)] = 0.9 * a[: min(n, m)] + 0.1 * b[: min(n, m)]  # some strongly correlated pairs
+    from seekr_amd.pearson import pearson
+    with np.errstate(all="ignore"):
+        got = pearson(a, b)
+        ref = orc.pearson(a, b)
+        truth = orc.pearson_f64_truth(a, b)
+    assert got.dtype == np.float32 and got.shape == (m, n)
+    assert np.allclose(got, ref, rtol=RTOL, atol=ATOL_R, equal_nan=True)
+    if k > 4:
+        assert np.nanmax(np.abs(got - truth)) < 2e-6
+    got_raw = pearson(a, b, row_standardize=False)
+    assert np.allclose(got_raw, orc.pearson(a, b, row_standardize=False), rtol=RTOL, atol=1e-5)
+    a64 = pearson(a.astype(np.float64), b.astype(np.float64))
+    assert np.allclose(a64, truth, rtol=1e-11, atol=1e-13, equal_nan=True)
+
+
+# ------------------------------------------------------------------ full-size properties (config 2)
+def test_cfg2_full_size_properties(L, ctx):
+    """50 000 x 2 kb, k=6: size-independent properties at BASELINE size + oracle on a prefix."""
+    n_seqs, length, k = 50_000, 2000, 6
+    codes = orc.synthetic_codes(2, n_seqs, length)
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    blob = letters[codes].reshape(-1)
+    offsets = np.arange(n_seqs + 1, dtype=np.int64) * length
+    packed = L.PackedSeqs.from_buffer(ctx, blob, offsets, "AGTC")
+    assert packed.n == n_seqs and packed.total_bases == n_seqs * length
+    n = L.count_u32(ctx, packed, k)
+    n_host = n.to_numpy()
+    assert (n_host.sum(axis=1) == length - k + 1).all()          # every window lands in exactly one bin
+    prefix = orc.codes_to_seqs(codes[:300])
+    assert np.array_equal(n_host[:300], orc.count_kmers_u32(prefix, k))
+    x = L.count_per_kb(ctx, packed, k)
+    raw_head = x.to_numpy(0, 300)
+    assert_bits(raw_head, orc.per_kb_from_counts(n_host[:300], [length] * 300, k), "per-kb prefix")
+    # linearity of the integer surface: counts of a concatenated set = stacked counts
+    sub = L.PackedSeqs.from_buffer(ctx, blob[1000 * length:1300 * length], offsets[:301], "AGTC")
+    assert np.array_equal(L.count_u32(ctx, sub, k).to_numpy(), n_host[1000:1300])
+    del n, n_host
+    mean_out, std_out, has_nan = L.normalize(ctx, x, "Log2.post", 1, None, 1, None)
+    assert not has_nan
+    raw = np.empty((n_seqs, 4 ** k), dtype=np.float32)
+    L.count_per_kb(ctx, packed, k).to_numpy(out=raw)
+    assert_bits(mean_out.vector(), orc.column_mean_f32(raw), "mean 50k x 4096")
+    raw -= mean_out.vector()
+    assert_bits(std_out.vector(), orc.column_std_f32(raw), "std 50k x 4096")
+    del raw
+    # Pearson on a 4096-row slab against float64 truth, plus structural properties
+    slab = ctx.from_numpy(x.to_numpy(0, 4096))
+    r = L.pearson(ctx, slab, slab).to_numpy()
+    assert np.allclose(np.diag(r), 1.0, atol=2e-6)
+    assert np.array_equal(r, r.T)  # same products, same k order: exactly symmetric
+    xs = slab.to_numpy()
+    truth = orc.pearson_f64_truth(xs[:512], xs[:700])
+    assert np.max(np.abs(r[:512, :700] - truth)) < 2e-6
+    assert np.allclose(r[:512, :700], orc.pearson(xs[:512], xs[:700]), rtol=RTOL, atol=ATOL_R)
