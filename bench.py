@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Benchmark of the SEEKR hot path on MI355X: k-mer counting -> numpy-order normalisation
+(Log2.post) -> row standardisation -> all-pairs Pearson of the set against itself.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" is one pass of that pipeline over one synthetic transcript set whose packed bases
+are already resident in HBM; the correlation row block stays in HBM.  Work per GPU is fixed in
+the metric's unit (ordered sequence pairs): N_rows(G) = 50 000 * sqrt(G), so G=1 is
+BASELINE.json configs[1] (50k x 2 kb, k=6) and scaling is weak.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from seekr_amd import _lib, launch  # noqa: E402
+from seekr_amd.distributed import HipEngine, shard_bounds, sharded_normalize, sharded_pearson_rowblock  # noqa: E402
+from seekr_amd.synthetic import synthetic_ascii, synthetic_codes  # noqa: E402
+
+PEAK = {"hbm_gbs": 8000.0, "fp32_mfma_tflops": 157.3, "bf16_mfma_tflops": 2500.0}  # MI355X_MICROARCH.md
+SEED = 2
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--rows", type=int, default=0, help="total transcripts (default 50000*sqrt(gpus))")
+    ap.add_argument("--length", type=int, default=2000)
+    ap.add_argument("-k", type=int, default=6)
+    ap.add_argument("--precision", default=os.environ.get("SEEKR_PRECISION", "fp32"), choices=["fp32", "bf16x3"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(k, length, x_norm_head):
+    """The oracle (a port with the reference's structure: per-window dict increments in pure
+    Python, numpy row standardisation + np.inner) timed on a bounded prefix of the workload."""
+    from oracle import seekr_oracle as orc
+    n_count = 3000
+    seqs = orc.codes_to_seqs(synthetic_codes(SEED, n_count, length))
+    t0 = time.perf_counter()
+    orc.raw_counts_py(seqs, k)
+    t_count = time.perf_counter() - t0
+    rate_bases = n_count * length / t_count
+    n_p = x_norm_head.shape[0]
+    orc.pearson(x_norm_head[:512], x_norm_head[:512])  # BLAS warm-up
+    t0 = time.perf_counter()
+    orc.pearson(x_norm_head, x_norm_head)
+    t_p = time.perf_counter() - t0
+    rate_pairs = n_p * n_p / t_p
+    try:
+        from threadpoolctl import threadpool_info
+        blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:  # noqa: BLE001
+        blas_threads = os.cpu_count()
+    return {"rate_bases": rate_bases, "rate_pairs": rate_pairs, "t_count": t_count, "t_pearson": t_p,
+            "n_count": n_count, "n_pearson": n_p, "blas_threads": blas_threads}
+
+
+def main():
+    args = parse()
+    rank, size, _ = launch.world()
+    if size != args.gpus:
+        raise SystemExit("--gpus {} but WORLD_SIZE={} (launch with torch.distributed.run)".format(args.gpus, size))
+    ctx, comm = launch.init()
+    k, length = args.k, args.length
+    n_cols = 4 ** k
+    n_total = args.rows or int(round(50_000 * math.sqrt(size) / size)) * size
+    bounds = shard_bounds(n_total, size)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    n_loc = hi - lo
+    engine = HipEngine(ctx, _lib.PRECISIONS[args.precision])
+
+    # ---- synthetic input, packed and resident in HBM before the timed region
+    blob, offsets = synthetic_ascii(SEED, n_loc, length, start=lo)
+    packed = _lib.PackedSeqs.from_buffer(ctx, blob, offsets, "AGTC")
+    del blob
+    x = ctx.empty(n_loc, n_cols)
+    z = ctx.empty(n_loc, n_cols)
+    r = ctx.empty(n_loc, n_total)
+    max_shard = max(bounds[g + 1] - bounds[g] for g in range(size))
+    recv = [ctx.empty(max_shard, n_cols), ctx.empty(max_shard, n_cols)] if size > 1 else [None, None]
+
+    def step():
+        _lib.count_per_kb(ctx, packed, k, out=x)
+        sharded_normalize(engine, comm, x, n_total, "Log2.post", True, True)
+        engine.row_standardize(x, z)
+        sharded_pearson_rowblock(engine, comm, z, bounds, r, recv)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.sync()
+    comm.barrier()
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.sync()
+    comm.barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.prof_enable(False)
+    elapsed = comm.allreduce([elapsed], "max")[0]
+
+    # ---- per-kernel device times of the timed region (HIP events on the ctx stream)
+    kern = {}
+    for name in ctx.prof_names():
+        ms, cnt = ctx.prof_query(name)
+        kern[name] = {"ms_total": ms, "launches": cnt}
+    gemm_name = "pearson_gemm_f32" if args.precision == "fp32" else "pearson_gemm_bf16x3"
+    gemm = kern.get(gemm_name, {"ms_total": 0.0, "launches": 0})
+    count = kern.get("count_kmers_f32", {"ms_total": 0.0, "launches": 0})
+
+    if rank != 0:
+        return
+    steps = args.steps
+    pairs_per_step = float(n_total) * n_total
+    value = pairs_per_step * steps / elapsed / 1e6
+    # dominant kernel: the Pearson contraction (MFMA bound). algorithmic flops = 2*K per ordered pair
+    gemm_launch_pairs = float(n_loc) * n_total / max(size, 1) if size > 1 else pairs_per_step
+    gemm_avg_ms = gemm["ms_total"] / max(gemm["launches"], 1)
+    flops_per_launch = 2.0 * n_cols * (float(n_loc) * max_shard if size > 1 else pairs_per_step)
+    achieved_tf = flops_per_launch / (gemm_avg_ms * 1e-3) / 1e12 if gemm_avg_ms > 0 else 0.0
+    peak_tf = PEAK["fp32_mfma_tflops"] if args.precision == "fp32" else PEAK["bf16_mfma_tflops"]
+    roofline = {"kernel": gemm_name, "bound": "mfma", "achieved": round(achieved_tf, 2), "peak": peak_tf,
+                "unit": "TFLOP/s", "frac": round(achieved_tf / peak_tf, 4), "traffic": None,
+                "avg_launch_ms": round(gemm_avg_ms, 4), "launches": gemm["launches"],
+                "note": "algorithmic 2*4^k flop per ordered pair" + (
+                    "; split-bf16 executes 3 MFMA products per algorithmic product" if args.precision != "fp32" else "")}
+    # counting kernel: HBM bound, 0.25 B/base packed in + 4*4^k B per sequence out
+    count_avg_ms = count["ms_total"] / max(count["launches"], 1)
+    count_bytes = n_loc * (length * 0.25 + 8 + 4.0 * n_cols)
+    count_gbs = count_bytes / (count_avg_ms * 1e-3) / 1e9 if count_avg_ms > 0 else 0.0
+    mbases = n_loc * length / (count_avg_ms * 1e-3) / 1e6 if count_avg_ms > 0 else 0.0
+    roofline_count = {"kernel": "count_kmers_f32", "bound": "hbm", "achieved": round(count_gbs, 1),
+                      "peak": PEAK["hbm_gbs"], "unit": "GB/s", "frac": round(count_gbs / PEAK["hbm_gbs"], 4),
+                      "traffic": None, "avg_launch_ms": round(count_avg_ms, 4),
+                      "bytes_per_base": round(count_bytes / (n_loc * length), 3)}
+    out = {
+        "metric": "Mbases/s k-mer counted + M seq-pairs/s Pearson, k=6, 1/2/4/8 GPU",
+        "value": round(value, 2),
+        "unit": "M seq-pairs/s (whole step: count + normalise + Pearson)",
+        "n_gpus": size, "steps": steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.precision == "fp32" else "bf16x3(f32 accumulate)", "data": "synthetic",
+        "config": {"workload": "{} synthetic {} nt transcripts, k={}, counts + Log2.post normalisation + "
+                               "self Pearson ({} x {} r matrix, row-sharded)".format(n_total, length, k, n_total, n_total),
+                   "rows_total": n_total, "rows_per_gpu": n_loc, "length": length, "k": k,
+                   "precision": args.precision, "sharding": "rows x{}".format(size)},
+        "mbases_per_s_counted": round(mbases * size, 1),
+        "pearson_kernel_mpairs_per_s": round(pairs_per_step / size / (gemm["ms_total"] / steps * 1e-3) / 1e6 * size, 1)
+        if gemm["ms_total"] > 0 else None,
+        "roofline": roofline, "roofline_count": roofline_count,
+        "kernels_ms_per_step": {n: round(v["ms_total"] / steps, 4) for n, v in sorted(kern.items())},
+    }
+    if size == 1 and not args.no_cpu_baseline:
+        head = x.to_numpy(0, min(8000, n_loc))
+        cb = cpu_baseline(k, length, head)
+        t_cpu = n_total * length / cb["rate_bases"] + pairs_per_step / cb["rate_pairs"]
+        out["cpu_baseline"] = {
+            "value": round(pairs_per_step / t_cpu / 1e6, 3), "unit": "M seq-pairs/s (whole step, extrapolated)",
+            "cores": cb["blas_threads"], "kind": "port",
+            "sample": "oracle (pure-Python per-window counting, 1 core) on the first {} sequences: {:.2f} s = {:.3f} "
+                      "Mbases/s; oracle numpy Pearson ({} BLAS threads of {} cores) on the first {} rows: {:.2f} s = "
+                      "{:.2f} M pairs/s; T_cpu(N) = bases/rate_count + N^2/rate_pairs".format(
+                          cb["n_count"], cb["t_count"], cb["rate_bases"] / 1e6, cb["blas_threads"], os.cpu_count(),
+                          cb["n_pearson"], cb["t_pearson"], cb["rate_pairs"] / 1e6),
+            "count_mbases_per_s": round(cb["rate_bases"] / 1e6, 4),
+            "pearson_mpairs_per_s": round(cb["rate_pairs"] / 1e6, 3),
+        }
+        out["speedup_vs_cpu_port"] = round(value / out["cpu_baseline"]["value"], 1)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -83,6 +83,8 @@ int skr_mat_shape(const skr_mat* m, int64_t* rows, int64_t* cols, int* dtype);
 int skr_mat_upload(skr_mat* m, const void* host, int64_t row0, int64_t nrows);
 int skr_mat_download(const skr_mat* m, void* host, int64_t row0, int64_t nrows);
 int skr_mat_fill_zero(skr_mat* m);
+/* non-owning view of rows [row0, row0+nrows) of `parent`; free it with skr_mat_free before the parent */
+int skr_mat_view(const skr_mat* parent, int64_t row0, int64_t nrows, skr_mat** out);
 /* raw device pointer (for RCCL / interop); valid until skr_mat_free */
 int skr_mat_device_ptr(const skr_mat* m, void** ptr);
 

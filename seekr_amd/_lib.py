@@ -4,6 +4,7 @@ There is deliberately NO fallback: if the HIP library is missing or no MI355X is
 every compute entry point raises.  `import seekr_amd` itself stays importable on a CPU-only
 box so that the build step and the host-logic tests can run there.
 """
+import atexit
 import ctypes as C
 import os
 import threading
@@ -45,6 +46,7 @@ SIGNATURES = {
     "skr_mat_upload": (_int, [_p, _p, _i64, _i64]),
     "skr_mat_download": (_int, [_p, _p, _i64, _i64]),
     "skr_mat_fill_zero": (_int, [_p]),
+    "skr_mat_view": (_int, [_p, _i64, _i64, C.POINTER(_p)]),
     "skr_mat_device_ptr": (_int, [_p, C.POINTER(_p)]),
     "skr_seqs_pack": (_int, [_p, _p, _p, _i64, C.c_char_p, C.POINTER(_p)]),
     "skr_seqs_from_fasta": (_int, [_p, C.c_char_p, C.c_char_p, C.POINTER(_p)]),
@@ -73,6 +75,17 @@ SIGNATURES = {
 
 _lib = None
 _lock = threading.Lock()
+_shutdown = False
+
+
+def _mark_shutdown():
+    # at interpreter exit the HIP runtime reclaims everything; explicit frees in arbitrary
+    # finaliser order would race its own teardown
+    global _shutdown
+    _shutdown = True
+
+
+atexit.register(_mark_shutdown)
 
 
 class SeekrHipError(RuntimeError):
@@ -137,7 +150,7 @@ class Context:
         check(lib().skr_ctx_create(int(device), C.byref(self._h)))
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and not _shutdown:
             lib().skr_ctx_destroy(self._h)
             self._h = None
 
@@ -208,21 +221,29 @@ def default_context():
 class Matrix:
     """Row-major device matrix (skr_mat)."""
 
-    def __init__(self, ctx, rows, cols, dtype=np.float32):
+    def __init__(self, ctx, rows, cols, dtype=np.float32, _view_of=None, _row0=0):
         code = _CODE_OF.get(np.dtype(dtype))
         if code is None:
             raise TypeError("device matrices are float32, float64 or uint32 (got {})".format(dtype))
         self.ctx = ctx
         self.rows, self.cols, self.dtype = int(rows), int(cols), np.dtype(dtype)
         self._h = _p()
-        check(lib().skr_mat_create(ctx._h, self.rows, self.cols, code, C.byref(self._h)))
+        self._parent = _view_of  # keeps the owner alive
+        if _view_of is None:
+            check(lib().skr_mat_create(ctx._h, self.rows, self.cols, code, C.byref(self._h)))
+        else:
+            check(lib().skr_mat_view(_view_of._h, int(_row0), self.rows, C.byref(self._h)))
+
+    def view(self, row0, nrows):
+        """Non-owning view of rows [row0, row0+nrows)."""
+        return Matrix(self.ctx, nrows, self.cols, self.dtype, _view_of=self, _row0=row0)
 
     @property
     def shape(self):
         return (self.rows, self.cols)
 
     def free(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and not _shutdown:
             lib().skr_mat_free(self._h)
             self._h = None
 
@@ -321,7 +342,7 @@ class PackedSeqs:
         return text.split("\n") if text else []
 
     def free(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and not _shutdown:
             lib().skr_seqs_free(self._h)
             self._h = None
 

@@ -40,6 +40,7 @@ struct skr_mat {
     int64_t rows = 0, cols = 0;
     int dtype = SKR_F32;
     void* data = nullptr;
+    bool owner = true;  // views created by skr_mat_view do not own `data`
     size_t bytes() const { return (size_t)rows * (size_t)cols * elem(); }
     size_t elem() const { return dtype == SKR_F64 ? 8 : 4; }
 };
@@ -92,3 +93,9 @@ struct SkrProfScope {
 
 int skr_ctx_workspace(skr_ctx* ctx, size_t bytes, void** out);
 int skr_activate(const skr_ctx* ctx);
+
+// float32 log2 rounded from a float64 evaluation: correctly rounded except for near-ties of the
+// f64 result, which is the closest a device can get to numpy's log2 (SVML / libm are correctly
+// rounded for >90 % of inputs; ocml's f32 log2f is systematically 1 ulp off on many of the
+// discrete per-kb count values, which shifts the float32 column statistics of Log2.pre by >1e-5).
+__device__ __forceinline__ float skr_log2_cr(float x) { return (float)log2((double)x); }

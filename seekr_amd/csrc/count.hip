@@ -123,10 +123,10 @@ __global__ __launch_bounds__(kThreads) void count_kmers_kernel(
                 v.z = per_kb_value(c.z, inc);
                 v.w = per_kb_value(c.w, inc);
                 if (OUT == OUT_F32_LOG2) {  // kmer_counts.py:189-192: counts += 1; log2
-                    v.x = log2f(v.x + 1.0f);
-                    v.y = log2f(v.y + 1.0f);
-                    v.z = log2f(v.z + 1.0f);
-                    v.w = log2f(v.w + 1.0f);
+                    v.x = skr_log2_cr(v.x + 1.0f);
+                    v.y = skr_log2_cr(v.y + 1.0f);
+                    v.z = skr_log2_cr(v.z + 1.0f);
+                    v.w = skr_log2_cr(v.w + 1.0f);
                 }
                 *reinterpret_cast<float4*>(&row[b]) = v;
             }

@@ -209,11 +209,29 @@ extern "C" int skr_mat_create(skr_ctx* ctx, int64_t rows, int64_t cols, int dtyp
 
 extern "C" int skr_mat_free(skr_mat* m) {
     if (!m) return SKR_OK;
-    (void)hipSetDevice(m->ctx->device);
-    (void)hipStreamSynchronize(m->ctx->stream);
-    (void)hipStreamSynchronize(m->ctx->comm_stream);
-    if (m->data) (void)hipFree(m->data);
+    if (m->owner) {  // views own nothing: no synchronisation needed to drop them
+        (void)hipSetDevice(m->ctx->device);
+        (void)hipStreamSynchronize(m->ctx->stream);
+        (void)hipStreamSynchronize(m->ctx->comm_stream);
+        if (m->data) (void)hipFree(m->data);
+    }
     delete m;
+    return SKR_OK;
+}
+
+extern "C" int skr_mat_view(const skr_mat* parent, int64_t row0, int64_t nrows, skr_mat** out) {
+    SKR_REQUIRE(parent && out, "NULL argument");
+    *out = nullptr;
+    SKR_REQUIRE(row0 >= 0 && nrows >= 0 && row0 + nrows <= parent->rows, "view rows [%lld, %lld) outside 0..%lld",
+                (long long)row0, (long long)(row0 + nrows), (long long)parent->rows);
+    skr_mat* v = new skr_mat();
+    v->ctx = parent->ctx;
+    v->rows = nrows;
+    v->cols = parent->cols;
+    v->dtype = parent->dtype;
+    v->owner = false;
+    v->data = (char*)parent->data + (size_t)row0 * (size_t)parent->cols * parent->elem();
+    *out = v;
     return SKR_OK;
 }
 

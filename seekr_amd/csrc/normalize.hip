@@ -135,7 +135,9 @@ __global__ void vec_finish_kernel(float* v, int64_t cols, float n, int take_sqrt
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= cols) return;
     float q = __fdiv_rn(v[i], n);
-    if (take_sqrt) q = __fsqrt_rn(q);
+    // correctly rounded f32 sqrt: f64 sqrt then one rounding (53 >= 2*24+2 bits: double rounding is innocuous);
+    // __fsqrt_rn would lower to the ~1 ulp native v_sqrt_f32 here
+    if (take_sqrt) q = (float)sqrt((double)q);
     v[i] = q;
 }
 
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(256) void elementwise_kernel(const float* __restric
     float vmin = INFINITY;
     bool any_nan = false;
     auto one = [&](float v, int64_t c) -> float {
-        if (PRE) v = log2f(__fadd_rn(v, 1.0f));
+        if (PRE) v = skr_log2_cr(__fadd_rn(v, 1.0f));
         v = sub_center<CK>(v, center, c);
         v = div_scale<SK>(v, scale, c);
         if (v != v) any_nan = true;
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(256) void elementwise_kernel(const float* __restric
         if (POST) {
             v = __fadd_rn(v, shift);
             v = __fadd_rn(v, 1.0f);
-            v = log2f(v);
+            v = skr_log2_cr(v);
         }
         return v;
     };

@@ -166,6 +166,29 @@ __global__ __launch_bounds__(256, 2) void pearson_gemm_f32_kernel(const float* _
         }
     };
 
+    // A single f32 accumulator over K = 4096 strictly sequential FMAs drifts by ~2e-6 on r ~ 1
+    // (error grows like sqrt(K)); BLAS in the reference sums in blocks.  Every kFlush k-tiles
+    // the running tile sum is folded into `total`, which cuts the drift by the block count.
+    constexpr int kFlush = 16;  // 16 * BK = 512 k per partial sum
+    f32x16 total[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) total[i][j][e] = 0.f;
+    auto flush = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    total[i][j][e] += acc[i][j][e];
+                    acc[i][j][e] = 0.f;
+                }
+    };
+
     const int64_t nk = K / BK;
     stage(0, 0);
     __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes the tile
@@ -173,10 +196,12 @@ __global__ __launch_bounds__(256, 2) void pearson_gemm_f32_kernel(const float* _
     for (int64_t t = 0; t + 1 < nk; t++) {
         stage(cur ^ 1, (t + 1) * BK);
         compute(cur);
+        if ((t + 1) % kFlush == 0) flush();
         __syncthreads();
         cur ^= 1;
     }
     compute(cur);
+    flush();
 
     // ---- epilogue: r = acc / K, C/D layout col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 h
 #pragma unroll
@@ -187,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void pearson_gemm_f32_kernel(const float* _
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const int64_t m = row_base + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (m < M && n < N) C[(size_t)m * ldc + n] = __fdiv_rn(acc[mt][nt][e], kdiv);
+                if (m < M && n < N) C[(size_t)m * ldc + n] = __fdiv_rn(total[mt][nt][e], kdiv);
             }
         }
 }

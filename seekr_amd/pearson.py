@@ -41,12 +41,25 @@ def pearson(counts1, counts2, row_standardize=True, outfile=None):
             c1.shape, c2.shape, c1.shape[1], c2.shape[1]))
     # numpy promotion of the reference: f32 with f32 stays f32, everything else becomes f64
     # (np.mean of an integer matrix is float64)
-    work = np.float32 if (c1.dtype == np.float32 and c2.dtype == np.float32) else np.float64
+    w1 = np.float32 if c1.dtype == np.float32 else np.float64
+    w2 = np.float32 if c2.dtype == np.float32 else np.float64
     ctx = _lib.default_context()
-    same = c1 is c2 or (c1.shape == c2.shape and c1.ctypes.data == c2.ctypes.data and c1.strides == c2.strides)
-    d1 = ctx.from_numpy(c1.astype(work, copy=False))
-    d2 = d1 if same else ctx.from_numpy(c2.astype(work, copy=False))
-    r = _lib.pearson(ctx, d1, d2, row_standardize=row_standardize, precision=_precision_for(np.dtype(work)))
+    same = c1 is c2 or (c1.shape == c2.shape and c1.dtype == c2.dtype and c1.ctypes.data == c2.ctypes.data
+                        and c1.strides == c2.strides)
+    d1 = ctx.from_numpy(c1.astype(w1, copy=False))
+    d2 = d1 if same else ctx.from_numpy(c2.astype(w2, copy=False))
+    if w1 == w2:
+        r = _lib.pearson(ctx, d1, d2, row_standardize=row_standardize, precision=_precision_for(np.dtype(w1)))
+    else:
+        # mixed float32 / float64: the reference standardises each operand in its own dtype and
+        # only the inner product promotes (pearson.py:35-41)
+        if row_standardize:
+            d1, d2 = _lib.row_standardize(ctx, d1), _lib.row_standardize(ctx, d2)
+        if w1 == np.float32:
+            d1 = ctx.from_numpy(d1.to_numpy().astype(np.float64))
+        else:
+            d2 = ctx.from_numpy(d2.to_numpy().astype(np.float64))
+        r = _lib.pearson(ctx, d1, d2, row_standardize=False, precision=_lib.PREC_F64)
     dist = r.to_numpy()
     if outfile:
         np.save(outfile, dist)
