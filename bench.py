@@ -39,8 +39,10 @@ def parse():
     ap.add_argument("--rows", type=int, default=0, help="total transcripts (default 50000*sqrt(gpus))")
     ap.add_argument("--length", type=int, default=2000)
     ap.add_argument("-k", type=int, default=6)
-    ap.add_argument("--precision", default=os.environ.get("SEEKR_PRECISION", "fp32"), choices=["fp32", "bf16x3"])
+    ap.add_argument("--precision", default=os.environ.get("SEEKR_PRECISION", "fp32"), choices=["fp32", "bf16x3", "bf16x4"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-symmetry", action="store_true",
+                    help="compute both triangles of the self-comparison block instead of mirroring one")
     return ap.parse_args()
 
 
@@ -81,7 +83,7 @@ def main():
     bounds = shard_bounds(n_total, size)
     lo, hi = bounds[rank], bounds[rank + 1]
     n_loc = hi - lo
-    engine = HipEngine(ctx, _lib.PRECISIONS[args.precision])
+    engine = HipEngine(ctx, _lib.PRECISIONS[args.precision], use_symmetry=not args.no_symmetry)
 
     # ---- synthetic input, packed and resident in HBM before the timed region
     blob, offsets = synthetic_ascii(SEED, n_loc, length, start=lo)
@@ -119,7 +121,7 @@ def main():
     for name in ctx.prof_names():
         ms, cnt = ctx.prof_query(name)
         kern[name] = {"ms_total": ms, "launches": cnt}
-    gemm_name = "pearson_gemm_f32" if args.precision == "fp32" else "pearson_gemm_bf16x3"
+    gemm_name = {"fp32": "pearson_gemm_f32", "bf16x3": "pearson_gemm_bf16x3", "bf16x4": "pearson_gemm_bf16x4"}[args.precision]
     gemm = kern.get(gemm_name, {"ms_total": 0.0, "launches": 0})
     count = kern.get("count_kmers_f32", {"ms_total": 0.0, "launches": 0})
 
@@ -128,17 +130,26 @@ def main():
     steps = args.steps
     pairs_per_step = float(n_total) * n_total
     value = pairs_per_step * steps / elapsed / 1e6
-    # dominant kernel: the Pearson contraction (MFMA bound). algorithmic flops = 2*K per ordered pair
-    gemm_launch_pairs = float(n_loc) * n_total / max(size, 1) if size > 1 else pairs_per_step
+    # Dominant kernel: the Pearson contraction (MFMA bound), 2*4^k algorithmic flop per pair it
+    # actually multiplies.  The self block mirrors one triangle on the bf16 path, so the pairs it
+    # multiplies are ~half of the pairs it delivers; both figures are reported.
+    sym = (not args.no_symmetry) and args.precision != "fp32"
+    tile = 128 if args.precision == "fp32" else 256
+    exec_pairs = (n_loc * (n_loc + tile) / 2.0 if sym else float(n_loc) * n_loc) + float(n_loc) * (n_total - n_loc)
+    gemm_ms_step = gemm["ms_total"] / steps
     gemm_avg_ms = gemm["ms_total"] / max(gemm["launches"], 1)
-    flops_per_launch = 2.0 * n_cols * (float(n_loc) * max_shard if size > 1 else pairs_per_step)
-    achieved_tf = flops_per_launch / (gemm_avg_ms * 1e-3) / 1e12 if gemm_avg_ms > 0 else 0.0
+    achieved_tf = 2.0 * n_cols * exec_pairs / (gemm_ms_step * 1e-3) / 1e12 if gemm_ms_step > 0 else 0.0
+    nprod = {"fp32": 1, "bf16x3": 3, "bf16x4": 4}[args.precision]
     peak_tf = PEAK["fp32_mfma_tflops"] if args.precision == "fp32" else PEAK["bf16_mfma_tflops"]
     roofline = {"kernel": gemm_name, "bound": "mfma", "achieved": round(achieved_tf, 2), "peak": peak_tf,
                 "unit": "TFLOP/s", "frac": round(achieved_tf / peak_tf, 4), "traffic": None,
-                "avg_launch_ms": round(gemm_avg_ms, 4), "launches": gemm["launches"],
-                "note": "algorithmic 2*4^k flop per ordered pair" + (
-                    "; split-bf16 executes 3 MFMA products per algorithmic product" if args.precision != "fp32" else "")}
+                "avg_launch_ms": round(gemm_avg_ms, 4), "launches_per_step": gemm["launches"] // max(steps, 1),
+                "mfma_executed_tflops": round(achieved_tf * nprod, 2),
+                "mfma_executed_frac": round(achieved_tf * nprod / peak_tf, 4),
+                "pairs_multiplied_per_step": exec_pairs, "pairs_delivered_per_step": float(n_loc) * n_total,
+                "note": "achieved = 2*4^k flop x pairs multiplied / kernel time (HIP events, summed over the "
+                        "step's launches); split-bf16 issues {} bf16 MFMA products per algorithmic product; "
+                        "symmetric self block: {}".format(nprod, sym)}
     # counting kernel: HBM bound, 0.25 B/base packed in + 4*4^k B per sequence out
     count_avg_ms = count["ms_total"] / max(count["launches"], 1)
     count_bytes = n_loc * (length * 0.25 + 8 + 4.0 * n_cols)
@@ -155,14 +166,13 @@ def main():
         "n_gpus": size, "steps": steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.precision == "fp32" else "bf16x3(f32 accumulate)", "data": "synthetic",
+        "dtype": "f32" if args.precision == "fp32" else "{} split-bf16 products, f32 accumulate".format(nprod), "data": "synthetic",
         "config": {"workload": "{} synthetic {} nt transcripts, k={}, counts + Log2.post normalisation + "
                                "self Pearson ({} x {} r matrix, row-sharded)".format(n_total, length, k, n_total, n_total),
                    "rows_total": n_total, "rows_per_gpu": n_loc, "length": length, "k": k,
                    "precision": args.precision, "sharding": "rows x{}".format(size)},
         "mbases_per_s_counted": round(mbases * size, 1),
-        "pearson_kernel_mpairs_per_s": round(pairs_per_step / size / (gemm["ms_total"] / steps * 1e-3) / 1e6 * size, 1)
-        if gemm["ms_total"] > 0 else None,
+        "pearson_kernel_mpairs_per_s": round(pairs_per_step / (gemm_ms_step * 1e-3) / 1e6, 1) if gemm_ms_step > 0 else None,
         "roofline": roofline, "roofline_count": roofline_count,
         "kernels_ms_per_step": {n: round(v["ms_total"] / steps, 4) for n, v in sorted(kern.items())},
     }

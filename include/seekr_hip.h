@@ -52,7 +52,8 @@ enum { SKR_LOG2_NONE = 0, SKR_LOG2_PRE = 1, SKR_LOG2_POST = 2 };
 enum {
     SKR_PREC_FP32 = 0,   /* v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulate           */
     SKR_PREC_BF16X3 = 1, /* split-bf16: hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16       */
-    SKR_PREC_F64 = 2     /* v_mfma_f64_16x16x4_f64 (float64 inputs: CSV / integer count files)   */
+    SKR_PREC_F64 = 2,    /* v_mfma_f64_16x16x4_f64 (float64 inputs: CSV / integer count files)   */
+    SKR_PREC_BF16X4 = 3  /* split-bf16 with the lo*lo term as well: float32-BLAS-grade accuracy  */
 };
 
 typedef struct skr_ctx skr_ctx;   /* one GPU + one stream + scratch + optional RCCL communicator */

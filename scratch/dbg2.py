@@ -1,0 +1,29 @@
+import sys
+sys.path.insert(0, '/root/repo')
+import numpy as np
+from seekr_amd import _lib as L
+
+ctx = L.default_context()
+rng = np.random.default_rng(0)
+m, k = 640, 4096
+a = rng.gamma(2.0, 1.0, size=(m, k)).astype(np.float32)
+da = ctx.from_numpy(a)
+z = L.row_standardize(ctx, da)
+zh = z.to_numpy()
+z2 = L.row_standardize(ctx, da)
+print('row_standardize deterministic:', np.array_equal(zh, z2.to_numpy()))
+for prec in ('bf16x3', 'fp32'):
+    P = L.PRECISIONS[prec]
+    outs = []
+    for sym in (False, False, True, True):
+        r = ctx.empty(m, m)
+        L.pearson_gemm(ctx, z, z, r, P, symmetric=sym)
+        outs.append(r.to_numpy())
+    print(prec, 'nosym run-to-run equal:', np.array_equal(outs[0], outs[1]),
+          'sym run-to-run equal:', np.array_equal(outs[2], outs[3]),
+          'sym==nosym upper:', np.array_equal(np.triu(outs[0]), np.triu(outs[2])),
+          'nosym symmetric:', np.array_equal(outs[0], outs[0].T), 'sym symmetric:', np.array_equal(outs[2], outs[2].T))
+    d = outs[0] != outs[2]
+    print('   differing cells', d.sum(), 'in diag tile(0,0):', d[:256, :256].sum(), 'upper', np.triu(d).sum())
+    d2 = outs[0] != outs[0].T
+    print('   nosym asym cells', d2.sum(), 'within tile00', d2[:256, :256].sum())

@@ -15,9 +15,13 @@
 
 namespace {
 
-constexpr int kColsPerWG = 32;    // 128-byte column strip per workgroup
-constexpr int kTileRows = 256;    // rows staged in LDS per step
+constexpr int kColsPerWG = 16;    // 64-byte column strip per workgroup: 4^6 columns -> 256 workgroups, one per CU
+constexpr int kTileRows = 512;    // rows staged in LDS per step (32 KiB)
+constexpr int kDepth = 4;         // tiles in flight per workgroup (register ring): 128 KiB of HBM loads
 constexpr int kThreads = 256;
+constexpr int kLanesPerRow = kColsPerWG / 4;             // 16-byte loads
+constexpr int kRowsPerPass = kThreads / kLanesPerRow;    // rows covered by one load instruction
+constexpr int kLoads = kTileRows / kRowsPerPass;         // loads per thread per tile
 
 enum CenterKind { C_NONE = 0, C_F32 = 1, C_F64 = 2 };
 
@@ -36,53 +40,64 @@ __device__ __forceinline__ float div_scale(float x, const void* vec, int64_t col
 }
 
 // ---------------------------------------------------------------------------------------
-// Sequential column sums.  A workgroup owns a strip of 32 columns.  All 256 threads stream
-// tiles of 256 rows x 32 columns into LDS (8 lanes x 16 B per row: full 128-B lines, the
-// t() transform applied on the way), double-buffered through registers so the next tile's
-// HBM loads are in flight while lanes 0..31 of wave 0 walk the current tile row by row, each
-// extending one column's float32 chain.
+// Sequential column sums.  The chain acc = fl32(acc + x[i, j]) over i is inherently serial per
+// column, so the kernel is organised around keeping HBM busy while one lane per column walks:
+//   * a workgroup owns a strip of 16 columns (64 B per row); 4^6 columns give 256 workgroups;
+//   * all 256 threads stream tiles of 512 rows x 16 columns (16-byte loads, t() applied on the
+//     way) through a ring of kDepth register tiles into a double-buffered LDS tile, so 128 KiB
+//     of loads per workgroup are in flight while the walk proceeds;
+//   * lanes 0..15 of wave 0 walk the current LDS tile row by row, each extending one column's
+//     float32 chain (~5 cycles per row: the walk, not HBM latency, paces a tile).
 // ---------------------------------------------------------------------------------------
 template <int CK, bool SQUARE>
 __global__ __launch_bounds__(kThreads) void colsum_seq_kernel(const float* __restrict__ x, int64_t rows,
                                                               int64_t cols, const void* __restrict__ center,
                                                               const float* __restrict__ center2,
                                                               float* __restrict__ acc) {
-    __shared__ __attribute__((aligned(16))) float tile[2][kTileRows][kColsPerWG];
+    // column-major tile so that the walker fetches 4 consecutive rows of its column with one
+    // ds_read_b128; +4 floats of padding per column keep the 16 walker lanes on distinct banks
+    __shared__ __attribute__((aligned(16))) float tile[2][kColsPerWG][kTileRows + 4];
     const int tid = threadIdx.x;
     const int64_t col0 = (int64_t)blockIdx.x * kColsPerWG;
-    const int lane_c4 = (tid & 7) * 4;  // 4 consecutive columns handled by this thread
-    const int lane_r = tid >> 3;        // 0..31: row inside a 32-row slab
+    const int lane_c4 = (tid % kLanesPerRow) * 4;  // 4 consecutive columns handled by this thread
+    const int lane_r = tid / kLanesPerRow;         // row inside a kRowsPerPass-row slab
     const bool vec_ok = (cols % 4 == 0) && (col0 + kColsPerWG <= cols);
 
-    float c1[4] = {0, 0, 0, 0}, c2[4] = {0, 0, 0, 0};
-    (void)c1;
+    float c2[4] = {0, 0, 0, 0};
     if (SQUARE && center2) {
         for (int j = 0; j < 4; j++)
             if (col0 + lane_c4 + j < cols) c2[j] = center2[col0 + lane_c4 + j];
     }
 
-    auto load_tile = [&](int64_t row_base, float4 (&regs)[kTileRows / 32]) {
+    // Loads are unconditional (row index clamped; rows past the end are never walked): a branch
+    // around a load would make hipcc drain vmcnt(0) at every join and serialise the ring.
+    auto load_tile = [&](int64_t row_base, float4 (&regs)[kLoads]) {
+        if (vec_ok) {
 #pragma unroll
-        for (int s = 0; s < kTileRows / 32; s++) {
-            const int64_t r = row_base + s * 32 + lane_r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < rows) {
-                const float* p = x + (size_t)r * cols + col0 + lane_c4;
-                if (vec_ok) {
-                    v = *reinterpret_cast<const float4*>(p);
-                } else {
-                    if (col0 + lane_c4 + 0 < cols) v.x = p[0];
-                    if (col0 + lane_c4 + 1 < cols) v.y = p[1];
-                    if (col0 + lane_c4 + 2 < cols) v.z = p[2];
-                    if (col0 + lane_c4 + 3 < cols) v.w = p[3];
-                }
+            for (int s = 0; s < kLoads; s++) {
+                int64_t r = row_base + s * kRowsPerPass + lane_r;
+                r = r < rows ? r : rows - 1;
+                regs[s] = *reinterpret_cast<const float4*>(x + (size_t)r * cols + col0 + lane_c4);
             }
-            regs[s] = v;
+        } else {  // ragged strip / odd column count: element-wise, guarded (small matrices only)
+#pragma unroll
+            for (int s = 0; s < kLoads; s++) {
+                int64_t r = row_base + s * kRowsPerPass + lane_r;
+                r = r < rows ? r : rows - 1;
+                const float* p = x + (size_t)r * cols;
+                const int64_t c = col0 + lane_c4;
+                float4 v;
+                v.x = p[c + 0 < cols ? c + 0 : cols - 1];
+                v.y = p[c + 1 < cols ? c + 1 : cols - 1];
+                v.z = p[c + 2 < cols ? c + 2 : cols - 1];
+                v.w = p[c + 3 < cols ? c + 3 : cols - 1];
+                regs[s] = v;
+            }
         }
     };
     auto transform = [&](float v, int j) -> float {
-        const int64_t c = col0 + lane_c4 + j;
-        if (c >= cols) return 0.f;
+        int64_t c = col0 + lane_c4 + j;
+        c = c < cols ? c : cols - 1;  // columns past the end are computed but never written back
         float t = sub_center<CK>(v, center, c);
         if (SQUARE) {
             const float d = center2 ? __fsub_rn(t, c2[j]) : t;
@@ -90,9 +105,9 @@ __global__ __launch_bounds__(kThreads) void colsum_seq_kernel(const float* __res
         }
         return t;
     };
-    auto store_tile = [&](int buf, int64_t row_base, const float4 (&regs)[kTileRows / 32]) {
+    auto store_tile = [&](int buf, const float4 (&regs)[kLoads]) {
 #pragma unroll
-        for (int s = 0; s < kTileRows / 32; s++) {
+        for (int s = 0; s < kLoads; s++) {
             float4 v = regs[s];
             if (CK != C_NONE || SQUARE) {
                 v.x = transform(v.x, 0);
@@ -100,33 +115,60 @@ __global__ __launch_bounds__(kThreads) void colsum_seq_kernel(const float* __res
                 v.z = transform(v.z, 2);
                 v.w = transform(v.w, 3);
             }
-            *reinterpret_cast<float4*>(&tile[buf][s * 32 + lane_r][lane_c4]) = v;
+            const int r = s * kRowsPerPass + lane_r;
+            tile[buf][lane_c4 + 0][r] = v.x;
+            tile[buf][lane_c4 + 1][r] = v.y;
+            tile[buf][lane_c4 + 2][r] = v.z;
+            tile[buf][lane_c4 + 3][r] = v.w;
         }
-        (void)row_base;
     };
 
     float running = 0.f;
     if (tid < kColsPerWG && col0 + tid < cols) running = acc[col0 + tid];
 
-    float4 regs[kTileRows / 32];
+    float4 ring[kDepth][kLoads];
     const int64_t n_tiles = (rows + kTileRows - 1) / kTileRows;
-    if (n_tiles > 0) load_tile(0, regs);
-    for (int64_t t = 0; t < n_tiles; t++) {
-        const int buf = (int)(t & 1);
-        store_tile(buf, t * kTileRows, regs);
-        __syncthreads();
-        if (t + 1 < n_tiles) load_tile((t + 1) * kTileRows, regs);  // in flight during the walk
-        if (tid < kColsPerWG) {
-            const int64_t left = rows - t * kTileRows;
-            const int nr = (int)(left < kTileRows ? left : kTileRows);
-            if (nr == kTileRows) {
-#pragma unroll 32
-                for (int r = 0; r < kTileRows; r++) running = __fadd_rn(running, tile[buf][r][tid]);
-            } else {
-                for (int r = 0; r < nr; r++) running = __fadd_rn(running, tile[buf][r][tid]);
+#pragma unroll
+    for (int d = 0; d < kDepth; d++)
+        if (d < n_tiles) load_tile((int64_t)d * kTileRows, ring[d]);
+    for (int64_t t0 = 0; t0 < n_tiles; t0 += kDepth) {
+#pragma unroll
+        for (int d = 0; d < kDepth; d++) {  // static ring index: the tiles stay in registers
+            const int64_t t = t0 + d;
+            if (t < n_tiles) {
+                const int buf = d & 1;  // kDepth is even, so this is t & 1
+                store_tile(buf, ring[d]);  // waits only for this tile's (oldest) loads
+                __syncthreads();
+                if (t + kDepth < n_tiles) load_tile((t + kDepth) * kTileRows, ring[d]);
+                if (tid < kColsPerWG) {
+                    const int64_t left = rows - t * kTileRows;
+                    const int nr = (int)(left < kTileRows ? left : kTileRows);
+                    const float* colp = &tile[buf][tid][0];
+                    const int nr4 = nr & ~3;
+                    if (nr == kTileRows) {
+#pragma unroll 16
+                        for (int r = 0; r < kTileRows; r += 4) {
+                            const float4 q = *reinterpret_cast<const float4*>(colp + r);
+                            running = __fadd_rn(running, q.x);
+                            running = __fadd_rn(running, q.y);
+                            running = __fadd_rn(running, q.z);
+                            running = __fadd_rn(running, q.w);
+                        }
+                    } else {
+                        for (int r = 0; r < nr4; r += 4) {
+                            const float4 q = *reinterpret_cast<const float4*>(colp + r);
+                            running = __fadd_rn(running, q.x);
+                            running = __fadd_rn(running, q.y);
+                            running = __fadd_rn(running, q.z);
+                            running = __fadd_rn(running, q.w);
+                        }
+                        for (int r = nr4; r < nr; r++) running = __fadd_rn(running, colp[r]);
+                    }
+                }
+                // buffer `buf` is rewritten two tiles later, after the walker has passed the next
+                // barrier: one barrier per tile is enough
             }
         }
-        // the other buffer is rewritten next iteration; this one the iteration after: one barrier per tile
     }
     if (tid < kColsPerWG && col0 + tid < cols) acc[col0 + tid] = running;
 }

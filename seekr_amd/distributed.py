@@ -35,9 +35,10 @@ def shard_bounds(n_rows, size):
 class HipEngine:
     """The production engine: every op is a kernel launch through libseekr_hip."""
 
-    def __init__(self, ctx, precision=_lib.PREC_FP32):
+    def __init__(self, ctx, precision=_lib.PREC_FP32, use_symmetry=True):
         self.ctx = ctx
         self.precision = precision
+        self.use_symmetry = use_symmetry  # self-blocks compute one triangle and mirror it
 
     def zeros_vec(self, n):
         return self.ctx.zeros(1, n)
@@ -75,8 +76,8 @@ class HipEngine:
     def row_standardize(self, x, z=None):
         return _lib.row_standardize(self.ctx, x, z)
 
-    def gemm(self, a, b, r, col0):
-        _lib.pearson_gemm(self.ctx, a, b, r, self.precision, False, 0, col0)
+    def gemm(self, a, b, r, col0, symmetric=False):
+        _lib.pearson_gemm(self.ctx, a, b, r, self.precision, symmetric and self.use_symmetry, 0, col0)
 
 
 class RcclComm:
@@ -182,7 +183,7 @@ def sharded_pearson_rowblock(engine, comm, z, bounds, r, recv_bufs):
     if size > 1:
         src = (rank - 1) % size
         tickets[1] = comm.shift(z, (rank + 1) % size, recv_bufs[1 % 2], bounds[src + 1] - bounds[src], src)
-    engine.gemm(z, z, r, bounds[rank])
+    engine.gemm(z, z, r, bounds[rank], symmetric=True)
     for s in range(1, size):
         src = (rank - s) % size
         comm.wait(tickets.pop(s))

@@ -475,3 +475,70 @@ def test_cfg2_full_size_properties(L, ctx):
     truth = orc.pearson_f64_truth(xs[:512], xs[:700])
     assert np.max(np.abs(r[:512, :700] - truth)) < 2e-6
     assert np.allclose(r[:512, :700], orc.pearson(xs[:512], xs[:700]), rtol=RTOL, atol=ATOL_R)
+
+
+# ------------------------------------------------------------------ split-bf16 MFMA path
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16x4"])
+@pytest.mark.parametrize("shape", [(5, 7, 16), (130, 257, 64), (300, 200, 100), (640, 515, 4096), (1000, 1000, 1024)])
+def test_pearson_split_bf16_vs_oracle(prec, shape, L, ctx):
+    m, n, k = shape
+    rng = np.random.default_rng(m * 7 + n)
+    a = rng.gamma(2.0, 1.0, size=(m, k)).astype(np.float32)
+    b = rng.gamma(2.0, 1.0, size=(n, k)).astype(np.float32)
+    if k > 16:
+        b[: min(n, m)] = 0.9 * a[: min(n, m)] + 0.1 * b[: min(n, m)]
+    da, db = ctx.from_numpy(a), ctx.from_numpy(b)
+    got = L.pearson(ctx, da, db, precision=L.PRECISIONS[prec]).to_numpy()
+    ref = orc.pearson(a, b)
+    truth = orc.pearson_f64_truth(a, b)
+    assert np.allclose(got, ref, rtol=RTOL, atol=ATOL_R), np.abs(got - ref).max()
+    err = np.abs(got - truth)
+    if k >= 1024:  # the split path proper (K < 1024 is routed to the fp32 MFMA kernel)
+        assert err.max() < (6e-6 if prec == "bf16x3" else 2.5e-6), err.max()  # error vs float64 truth, on r ~ 1 pairs
+    else:
+        assert err.max() < 1.5e-6, err.max()
+    # self comparison: the mirrored triangle equals the computed one bit for bit
+    rs = L.pearson(ctx, da, da, precision=L.PRECISIONS[prec]).to_numpy()
+    assert np.array_equal(rs, rs.T)
+    assert np.allclose(rs, orc.pearson(a, a), rtol=RTOL, atol=ATOL_R)
+    z = L.row_standardize(ctx, da)
+    full = ctx.empty(m, m)
+    L.pearson_gemm(ctx, z, z, full, L.PRECISIONS[prec], symmetric=False)
+    full = full.to_numpy()
+    # computing both triangles gives the upper one bit for bit; the lower differs only in the
+    # order the hi*lo and lo*hi cross terms enter the float32 accumulator
+    assert np.array_equal(np.triu(full), np.triu(rs))
+    assert np.allclose(full, rs, rtol=1e-6, atol=2e-7)
+
+
+def test_pearson_split_bf16_nan_rows(L, ctx):
+    m = np.array([[1, 2, 3, 4], [5, 5, 5, 5], [4, 1, 3, 2]], dtype=np.float32)
+    ref = orc.pearson(m, m)
+    for prec in ("bf16x3", "bf16x4"):
+        d = ctx.from_numpy(m)
+        got = L.pearson(ctx, d, d, precision=L.PRECISIONS[prec]).to_numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        assert np.allclose(got, ref, rtol=RTOL, atol=ATOL_R, equal_nan=True)
+
+
+def test_cfg2_slab_split_bf16(L, ctx):
+    """8192 normalised 2 kb transcripts (config-2 data): bf16x3 / bf16x4 against float64 truth."""
+    n_seqs, length, k = 8192, 2000, 6
+    blob, offsets = __import__("seekr_amd.synthetic", fromlist=["x"]).synthetic_ascii(2, n_seqs, length)
+    packed = L.PackedSeqs.from_buffer(ctx, blob, offsets, "AGTC")
+    x = L.count_per_kb(ctx, packed, k)
+    L.normalize(ctx, x, "Log2.post", 1, None, 1, None)
+    xs = x.to_numpy()
+    truth = orc.pearson_f64_truth(xs[:1024], xs[:2048])
+    ref = orc.pearson(xs[:1024], xs[:2048])
+    # bound = worst |r - truth|, reached on the r = 1 diagonal (4096 positive terms chained in one
+    # float32 accumulator); off-diagonal errors are ~1e-7
+    for prec, bound in (("bf16x3", 6e-6), ("bf16x4", 6e-6), ("fp32", 1.2e-6)):
+        r = L.pearson(ctx, x, x, precision=L.PRECISIONS[prec]).to_numpy()
+        assert np.array_equal(r, r.T)
+        blk = r[:1024, :2048]
+        assert np.abs(blk - truth).max() < bound, (prec, np.abs(blk - truth).max())
+        off = ~np.eye(1024, 2048, dtype=bool)
+        assert np.abs(blk - truth)[off].max() < 1.2e-6, (prec, np.abs(blk - truth)[off].max())
+        assert np.allclose(blk, ref, rtol=RTOL, atol=ATOL_R), prec
+        assert np.allclose(np.diag(r), 1.0, atol=4e-6)
