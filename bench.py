@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--rows", type=int, default=0, help="total transcripts (default 50000*sqrt(gpus))")
     ap.add_argument("--length", type=int, default=2000)
     ap.add_argument("-k", type=int, default=6)
-    ap.add_argument("--precision", default=os.environ.get("SEEKR_PRECISION", "fp32"), choices=["fp32", "bf16x3", "bf16x4"])
+    ap.add_argument("--precision", default=os.environ.get("SEEKR_PRECISION", "fp32"), choices=["fp32", "bf16x3", "bf16x4", "f16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-symmetry", action="store_true",
                     help="compute both triangles of the self-comparison block instead of mirroring one")
@@ -121,7 +121,8 @@ def main():
     for name in ctx.prof_names():
         ms, cnt = ctx.prof_query(name)
         kern[name] = {"ms_total": ms, "launches": cnt}
-    gemm_name = {"fp32": "pearson_gemm_f32", "bf16x3": "pearson_gemm_bf16x3", "bf16x4": "pearson_gemm_bf16x4"}[args.precision]
+    gemm_name = {"fp32": "pearson_gemm_f32", "bf16x3": "pearson_gemm_bf16x3", "bf16x4": "pearson_gemm_bf16x4",
+                 "f16x3": "pearson_gemm_f16x3"}[args.precision]
     gemm = kern.get(gemm_name, {"ms_total": 0.0, "launches": 0})
     count = kern.get("count_kmers_f32", {"ms_total": 0.0, "launches": 0})
 
@@ -139,7 +140,7 @@ def main():
     gemm_ms_step = gemm["ms_total"] / steps
     gemm_avg_ms = gemm["ms_total"] / max(gemm["launches"], 1)
     achieved_tf = 2.0 * n_cols * exec_pairs / (gemm_ms_step * 1e-3) / 1e12 if gemm_ms_step > 0 else 0.0
-    nprod = {"fp32": 1, "bf16x3": 3, "bf16x4": 4}[args.precision]
+    nprod = {"fp32": 1, "bf16x3": 3, "bf16x4": 4, "f16x3": 3}[args.precision]
     peak_tf = PEAK["fp32_mfma_tflops"] if args.precision == "fp32" else PEAK["bf16_mfma_tflops"]
     roofline = {"kernel": gemm_name, "bound": "mfma", "achieved": round(achieved_tf, 2), "peak": peak_tf,
                 "unit": "TFLOP/s", "frac": round(achieved_tf / peak_tf, 4), "traffic": None,

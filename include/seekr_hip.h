@@ -53,7 +53,9 @@ enum {
     SKR_PREC_FP32 = 0,   /* v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulate           */
     SKR_PREC_BF16X3 = 1, /* split-bf16: hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16       */
     SKR_PREC_F64 = 2,    /* v_mfma_f64_16x16x4_f64 (float64 inputs: CSV / integer count files)   */
-    SKR_PREC_BF16X4 = 3  /* split-bf16 with the lo*lo term as well: float32-BLAS-grade accuracy  */
+    SKR_PREC_BF16X4 = 3, /* split-bf16 with the lo*lo term as well                                */
+    SKR_PREC_F16X3 = 4   /* split-fp16 (11-bit halves), 3 products on v_mfma_f32_32x32x16_f16:   */
+                         /* float32-grade products at the bf16x3 cost                            */
 };
 
 typedef struct skr_ctx skr_ctx;   /* one GPU + one stream + scratch + optional RCCL communicator */

@@ -17,9 +17,9 @@ LIB_PATH = os.path.join(_HERE, "libseekr_hip.so")
 SKR_OK = 0
 F32, F64, U32 = 0, 1, 2
 LOG2_NONE, LOG2_PRE, LOG2_POST = 0, 1, 2
-PREC_FP32, PREC_BF16X3, PREC_F64, PREC_BF16X4 = 0, 1, 2, 3
+PREC_FP32, PREC_BF16X3, PREC_F64, PREC_BF16X4, PREC_F16X3 = 0, 1, 2, 3, 4
 LOG2_CODES = {"Log2.none": LOG2_NONE, "Log2.pre": LOG2_PRE, "Log2.post": LOG2_POST}
-PRECISIONS = {"fp32": PREC_FP32, "bf16x3": PREC_BF16X3, "bf16x4": PREC_BF16X4, "f64": PREC_F64}
+PRECISIONS = {"fp32": PREC_FP32, "bf16x3": PREC_BF16X3, "bf16x4": PREC_BF16X4, "f16x3": PREC_F16X3, "f64": PREC_F64}
 _NP_OF = {F32: np.float32, F64: np.float64, U32: np.uint32}
 _CODE_OF = {np.dtype(np.float32): F32, np.dtype(np.float64): F64, np.dtype(np.uint32): U32}
 

@@ -92,9 +92,9 @@ struct SkrProfScope {
 };
 
 int skr_ctx_workspace(skr_ctx* ctx, size_t bytes, void** out);
-// split-bf16 MFMA contraction (pearson_bf16.hip); nprod = 3 or 4 products per k
-int skr_pearson_gemm_bf16(skr_ctx* ctx, const skr_mat* a, const skr_mat* b, int nprod, int symmetric, skr_mat* r,
-                          int64_t row0, int64_t col0);
+// split-operand MFMA contraction (pearson_bf16.hip); precision = SKR_PREC_BF16X3 / BF16X4 / F16X3
+int skr_pearson_gemm_split(skr_ctx* ctx, const skr_mat* a, const skr_mat* b, int precision, int symmetric, skr_mat* r,
+                           int64_t row0, int64_t col0);
 int skr_activate(const skr_ctx* ctx);
 
 // float32 log2 rounded from a float64 evaluation: correctly rounded except for near-ties of the

@@ -318,14 +318,15 @@ extern "C" int skr_pearson_gemm(skr_ctx* ctx, const skr_mat* a, const skr_mat* b
         SKR_HIP(hipGetLastError());
         return SKR_OK;
     }
-    SKR_REQUIRE(precision == SKR_PREC_FP32 || precision == SKR_PREC_BF16X3 || precision == SKR_PREC_BF16X4,
-                "float32 operands need SKR_PREC_FP32, SKR_PREC_BF16X3 or SKR_PREC_BF16X4");
+    SKR_REQUIRE(precision == SKR_PREC_FP32 || precision == SKR_PREC_BF16X3 || precision == SKR_PREC_BF16X4 ||
+                    precision == SKR_PREC_F16X3,
+                "float32 operands need SKR_PREC_FP32, SKR_PREC_BF16X3, SKR_PREC_BF16X4 or SKR_PREC_F16X3");
     if (K == 0) return skr_set_error(SKR_ERR_INVALID, "matrices have no columns");
     // The split-bf16 error averages out like 1/sqrt(K): at K >= 1024 (k >= 5) it is inside the
     // parity bar (|dr| <= 2e-6 + 1e-5 |r|); below that the exact-product fp32 MFMA is used, where
     // it is cheap anyway.
     if (precision != SKR_PREC_FP32 && K >= 1024)
-        return skr_pearson_gemm_bf16(ctx, a, b, precision == SKR_PREC_BF16X3 ? 3 : 4, symmetric, r, row0, col0);
+        return skr_pearson_gemm_split(ctx, a, b, precision, symmetric, r, row0, col0);
     // the MFMA kernel wants K % 32 == 0: stage zero-padded copies when it is not
     const float* A = (const float*)a->data;
     const float* B = (const float*)b->data;

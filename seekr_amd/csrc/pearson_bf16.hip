@@ -12,16 +12,12 @@
 // k tile of a row is one full cache line and a 1-KiB LDS-DMA piece covers 8 rows.
 //
 // Geometry: block tile 256 x 256, BK = 32, LDS 2 stages x (256+256) rows x 128 B = 128 KiB, one
-// workgroup per CU.  Two wave layouts are built:
-//   W8: 8 waves as 2 (M) x 4 (N), wave tile 128 x 64  (4 x 2 MFMA tiles, 128 accumulator regs),
-//       two waves per SIMD cover each other's LDS waits;
-//   W4: 4 waves as 2 x 2, wave tile 128 x 128 (4 x 4 MFMA tiles, 256 accumulator regs), one wave
-//       per SIMD with the whole register file; the fragments of the next 16-k step are fetched
-//       while the MFMAs of the current one issue (explicit two-deep fragment pipeline).
+// workgroup per CU; 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 (4 x 2 MFMA tiles, 128
+// accumulator registers, 184 VGPRs), two waves per SIMD cover each other's LDS waits.  Per 16-k
+// step a wave issues 12 ds_read_b128 and 8*NPROD MFMAs.
 // The LDS image is lane-linear (LDS-DMA), so the bank swizzle chunk ^= (row >> 1) & 7 is applied
 // on the source address and again on the read (same involution), as in the fp32 kernel.
 #include <algorithm>
-#include <cstdlib>
 
 #include "common.hpp"
 
@@ -30,8 +26,18 @@ namespace {
 constexpr int TM = 256, TN = 256;
 constexpr int kRowBytes = 128;                       // one k tile of one row: 32 hi + 32 lo bf16
 constexpr int kStageBytes = (TM + TN) * kRowBytes;   // 64 KiB
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <typename T>
+using vec8 = T __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// T = __bf16 (8-bit significand halves) or _Float16 (11-bit halves: hi + lo carry 22 bits, so the
+// three-product sum is float32-grade; |z| <= sqrt(K) << 65504 and fp16 subnormals are kept)
+__device__ __forceinline__ f32x16 mfma16(vec8<__bf16> a, vec8<__bf16> b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma16(vec8<_Float16> a, vec8<_Float16> b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
 
 __device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -39,8 +45,9 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst_wave_b
 }
 
 // z (f32, [rows, cols]) -> split-interleaved bf16 [rows, kt, {hi,lo}, 32]; k >= cols padded with 0
-__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ z, int64_t rows, int64_t cols,
-                                                         int64_t kt, __bf16* __restrict__ out) {
+template <typename T>
+__global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ z, int64_t rows, int64_t cols,
+                                                    int64_t kt, T* __restrict__ out) {
     const int64_t groups_per_row = kt * 4;  // 8 k per thread
     const int64_t total = rows * groups_per_row;
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
@@ -58,16 +65,16 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
 #pragma unroll
             for (int j = 0; j < 8; j++) v[j] = (k0 + j < cols) ? src[j] : 0.f;
         }
-        bf16x8 hi, lo;
+        vec8<T> hi, lo;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const __bf16 h = (__bf16)v[j];       // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+            const T h = (T)v[j];            // hardware convert: RNE, NaN stays NaN
             hi[j] = h;
-            lo[j] = (__bf16)(v[j] - (float)h);   // exact difference, then RNE
+            lo[j] = (T)(v[j] - (float)h);   // exact difference, then RNE
         }
-        __bf16* dst = out + ((size_t)row * kt + tile) * 64 + sub * 8;
-        *reinterpret_cast<bf16x8*>(dst) = hi;
-        *reinterpret_cast<bf16x8*>(dst + 32) = lo;
+        T* dst = out + ((size_t)row * kt + tile) * 64 + sub * 8;
+        *reinterpret_cast<vec8<T>*>(dst) = hi;
+        *reinterpret_cast<vec8<T>*>(dst + 32) = lo;
     }
 }
 
@@ -86,29 +93,28 @@ __device__ __forceinline__ bool tile_of_block(int64_t bid, int64_t super_n, int6
     return *tm < tiles_m && *tn < tiles_n;
 }
 
-template <int NPROD, int MT, int NT>
-__device__ __forceinline__ void mma_step(f32x16 (&acc)[MT][NT], const bf16x8 (&ahi)[MT], const bf16x8 (&alo)[MT],
-                                         const bf16x8 (&bhi)[NT], const bf16x8 (&blo)[NT]) {
+template <typename T, int NPROD, int MT, int NT>
+__device__ __forceinline__ void mma_step(f32x16 (&acc)[MT][NT], const vec8<T> (&ahi)[MT], const vec8<T> (&alo)[MT],
+                                         const vec8<T> (&bhi)[NT], const vec8<T> (&blo)[NT]) {
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
-            if (NPROD >= 4) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[mt], blo[nt], acc[mt][nt], 0, 0, 0);
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[mt], bhi[nt], acc[mt][nt], 0, 0, 0);
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[mt], blo[nt], acc[mt][nt], 0, 0, 0);
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[mt], bhi[nt], acc[mt][nt], 0, 0, 0);
+            if (NPROD >= 4) acc[mt][nt] = mfma16(alo[mt], blo[nt], acc[mt][nt]);
+            acc[mt][nt] = mfma16(alo[mt], bhi[nt], acc[mt][nt]);
+            acc[mt][nt] = mfma16(ahi[mt], blo[nt], acc[mt][nt]);
+            acc[mt][nt] = mfma16(ahi[mt], bhi[nt], acc[mt][nt]);
         }
 }
 
 // WM x WN waves; each wave owns (256/WM) x (256/WN) of the block tile.
-template <int NPROD, bool SYM, int WM, int WN>
+template <typename T, int NPROD, bool SYM, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4) void pearson_gemm_bf16s_kernel(
-    const __bf16* __restrict__ A, const __bf16* __restrict__ B, float* __restrict__ C, float* __restrict__ Ct,
+    const T* __restrict__ A, const T* __restrict__ B, float* __restrict__ C, float* __restrict__ Ct,
     int64_t M, int64_t N, int64_t kt, int64_t ldc, float kdiv, int64_t tiles_m, int64_t tiles_n, int64_t super_n) {
     constexpr int NW = WM * WN;
     constexpr int MT = TM / WM / 32, NT = TN / WN / 32;
     constexpr int PP = 32 / NW;  // 1-KiB pieces per wave per operand per stage
-    constexpr bool PIPE = NW == 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int64_t tm, tn;
     if (!tile_of_block(blockIdx.x, super_n, tiles_m, tiles_n, &tm, &tn)) return;
@@ -120,8 +126,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4) void pearson_gemm_bf16
     const int64_t pitch = kt * 64;  // bf16 elements per row
 
     // ---- staging: wave w moves pieces PP*w .. PP*w+PP-1 (8 rows each) of the A tile and of the B tile
-    const __bf16* a_src[PP];
-    const __bf16* b_src[PP];
+    const T* a_src[PP];
+    const T* b_src[PP];
 #pragma unroll
     for (int p = 0; p < PP; p++) {
         const int row = (wave * PP + p) * 8 + (lane >> 3);
@@ -156,18 +162,18 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4) void pearson_gemm_bf16
         b_off[t] = TM * kRowBytes + rb * kRowBytes;
         b_swz[t] = (rb >> 1) & 7;
     }
-    auto load_frags = [&](int buf, int s, bf16x8 (&ahi)[MT], bf16x8 (&alo)[MT], bf16x8 (&bhi)[NT], bf16x8 (&blo)[NT]) {
+    auto load_frags = [&](int buf, int s, vec8<T> (&ahi)[MT], vec8<T> (&alo)[MT], vec8<T> (&bhi)[NT], vec8<T> (&blo)[NT]) {
         const char* base = smem + buf * kStageBytes;
         const int c_hi = 2 * s + h, c_lo = 4 + 2 * s + h;  // 16-byte chunk of the 128-byte row
 #pragma unroll
         for (int t = 0; t < MT; t++) {
-            ahi[t] = *reinterpret_cast<const bf16x8*>(base + a_off[t] + ((c_hi ^ a_swz[t]) << 4));
-            alo[t] = *reinterpret_cast<const bf16x8*>(base + a_off[t] + ((c_lo ^ a_swz[t]) << 4));
+            ahi[t] = *reinterpret_cast<const vec8<T>*>(base + a_off[t] + ((c_hi ^ a_swz[t]) << 4));
+            alo[t] = *reinterpret_cast<const vec8<T>*>(base + a_off[t] + ((c_lo ^ a_swz[t]) << 4));
         }
 #pragma unroll
         for (int t = 0; t < NT; t++) {
-            bhi[t] = *reinterpret_cast<const bf16x8*>(base + b_off[t] + ((c_hi ^ b_swz[t]) << 4));
-            blo[t] = *reinterpret_cast<const bf16x8*>(base + b_off[t] + ((c_lo ^ b_swz[t]) << 4));
+            bhi[t] = *reinterpret_cast<const vec8<T>*>(base + b_off[t] + ((c_hi ^ b_swz[t]) << 4));
+            blo[t] = *reinterpret_cast<const vec8<T>*>(base + b_off[t] + ((c_lo ^ b_swz[t]) << 4));
         }
     };
 
@@ -179,36 +185,25 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4) void pearson_gemm_bf16
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
+    // Two LDS stages: tile t+1 streams in by LDS-DMA while tile t is consumed; one barrier per
+    // k tile (its vmcnt(0) drain costs nothing: the fill was issued a whole iteration earlier).
+    // hipcc sinks the last 16 MFMAs of an iteration below the barrier, which covers the first
+    // fragment reads of the next tile.  (Measured alternatives that did not pay on gfx950: an
+    // explicit two-deep fragment pipeline at 248 VGPRs, -1 %; 4 waves x 128x128 with 256
+    // accumulator registers: hipcc spills the accumulators across the loop back-edge, 8x slower.)
+    int cur = 0;
     stage(0, 0);
     __syncthreads();  // vmcnt(0) drain of the LDS-DMA + barrier
-    int cur = 0;
-    if (PIPE) {
-        // one wave per SIMD: keep the MFMA pipe fed by fetching step s+1's fragments while step
-        // s's MFMAs issue; the k-tile hand-over barrier sits between the two steps of a tile
-        bf16x8 ahi0[MT], alo0[MT], bhi0[NT], blo0[NT], ahi1[MT], alo1[MT], bhi1[NT], blo1[NT];
-        load_frags(0, 0, ahi0, alo0, bhi0, blo0);
-        for (int64_t t = 0; t < kt; t++) {
-            const bool more = t + 1 < kt;
-            if (more) stage(cur ^ 1, t + 1);
-            load_frags(cur, 1, ahi1, alo1, bhi1, blo1);
-            mma_step<NPROD, MT, NT>(acc, ahi0, alo0, bhi0, blo0);
-            __syncthreads();  // tile t+1 has landed; every wave has read tile t
-            if (more) load_frags(cur ^ 1, 0, ahi0, alo0, bhi0, blo0);
-            mma_step<NPROD, MT, NT>(acc, ahi1, alo1, bhi1, blo1);
-            cur ^= 1;
-        }
-    } else {
-        for (int64_t t = 0; t < kt; t++) {
-            if (t + 1 < kt) stage(cur ^ 1, t + 1);
+    for (int64_t t = 0; t < kt; t++) {
+        if (t + 1 < kt) stage(cur ^ 1, t + 1);
 #pragma unroll
-            for (int s = 0; s < 2; s++) {
-                bf16x8 ahi[MT], alo[MT], bhi[NT], blo[NT];
-                load_frags(cur, s, ahi, alo, bhi, blo);
-                mma_step<NPROD, MT, NT>(acc, ahi, alo, bhi, blo);
-            }
-            __syncthreads();
-            cur ^= 1;
+        for (int s = 0; s < 2; s++) {
+            vec8<T> ahi[MT], alo[MT], bhi[NT], blo[NT];
+            load_frags(cur, s, ahi, alo, bhi, blo);
+            mma_step<T, NPROD, MT, NT>(acc, ahi, alo, bhi, blo);
         }
+        __syncthreads();
+        cur ^= 1;
     }
 
     // ---- epilogue.  C/D layout: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 h
@@ -254,13 +249,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4) void pearson_gemm_bf16
         }
 }
 
-template <int NPROD, bool SYM, int WM, int WN>
-int launch(skr_ctx* ctx, const __bf16* A, const __bf16* B, float* C, int64_t M, int64_t N, int64_t kt, int64_t ldc,
+template <typename T, int NPROD, bool SYM, int WM, int WN>
+int launch(skr_ctx* ctx, const T* A, const T* B, float* C, int64_t M, int64_t N, int64_t kt, int64_t ldc,
            int64_t K, const char* name) {
     const int64_t tiles_m = (M + TM - 1) / TM, tiles_n = (N + TN - 1) / TN;
     const int64_t super_m = (tiles_m + 15) / 16, super_n = (tiles_n + 15) / 16;
     const int64_t grid = super_m * super_n * 256;
-    auto kern = pearson_gemm_bf16s_kernel<NPROD, SYM, WM, WN>;
+    auto kern = pearson_gemm_bf16s_kernel<T, NPROD, SYM, WM, WN>;
     SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 2 * kStageBytes));
     SkrProfScope prof(ctx, name);
@@ -270,36 +265,25 @@ int launch(skr_ctx* ctx, const __bf16* A, const __bf16* B, float* C, int64_t M, 
     return SKR_OK;
 }
 
-template <int NPROD, bool SYM>
-int launch_layout(skr_ctx* ctx, int layout, const __bf16* A, const __bf16* B, float* C, int64_t M, int64_t N,
-                  int64_t kt, int64_t ldc, int64_t K, const char* name) {
-    if (layout == 4) return launch<NPROD, SYM, 2, 2>(ctx, A, B, C, M, N, kt, ldc, K, name);
-    return launch<NPROD, SYM, 2, 4>(ctx, A, B, C, M, N, kt, ldc, K, name);
-}
-
-}  // namespace
-
-int skr_pearson_gemm_bf16(skr_ctx* ctx, const skr_mat* a, const skr_mat* b, int nprod, int symmetric, skr_mat* r,
-                          int64_t row0, int64_t col0) {
+template <typename T>
+int gemm_split(skr_ctx* ctx, const skr_mat* a, const skr_mat* b, int nprod, int symmetric, skr_mat* r, int64_t row0,
+               int64_t col0, const char* name) {
     const int64_t M = a->rows, N = b->rows, K = a->cols;
     const int64_t kt = (K + 31) / 32;
     const bool same = a->data == b->data && M == N;
     const bool sym = symmetric && same;  // mirror is relative to the block's own base pointer
-    // wave layout: SEEKR_GEMM_WAVES=4|8 (development knob; default below)
-    int layout = 8;
-    if (const char* e = getenv("SEEKR_GEMM_WAVES")) layout = atoi(e) == 4 ? 4 : 8;
     // split-interleaved operands in the ctx workspace
     const size_t a_bytes = (size_t)M * kt * kRowBytes, b_bytes = same ? 0 : (size_t)N * kt * kRowBytes;
     void* ws = nullptr;
     SKR_TRY(skr_ctx_workspace(ctx, a_bytes + b_bytes + 256, &ws));
-    __bf16* As = (__bf16*)ws;
-    __bf16* Bs = same ? As : (__bf16*)((char*)ws + ((a_bytes + 255) & ~(size_t)255));
-    auto split = [&](const skr_mat* m, __bf16* dst) -> int {
+    T* As = (T*)ws;
+    T* Bs = same ? As : (T*)((char*)ws + ((a_bytes + 255) & ~(size_t)255));
+    auto split = [&](const skr_mat* m, T* dst) -> int {
         const int64_t total = m->rows * kt * 4;
         const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, (int64_t)ctx->num_cu * 16));
-        SkrProfScope prof(ctx, "split_bf16");
-        hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
-                           (const float*)m->data, m->rows, m->cols, kt, dst);
+        SkrProfScope prof(ctx, "split_halves");
+        hipLaunchKernelGGL(split_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)m->data,
+                           m->rows, m->cols, kt, dst);
         SKR_HIP(hipGetLastError());
         return SKR_OK;
     };
@@ -307,9 +291,21 @@ int skr_pearson_gemm_bf16(skr_ctx* ctx, const skr_mat* a, const skr_mat* b, int 
     if (!same) SKR_TRY(split(b, Bs));
     float* C = (float*)r->data + (size_t)row0 * r->cols + col0;
     if (nprod == 3) {
-        if (sym) return launch_layout<3, true>(ctx, layout, As, Bs, C, M, N, kt, r->cols, K, "pearson_gemm_bf16x3");
-        return launch_layout<3, false>(ctx, layout, As, Bs, C, M, N, kt, r->cols, K, "pearson_gemm_bf16x3");
+        if (sym) return launch<T, 3, true, 2, 4>(ctx, As, Bs, C, M, N, kt, r->cols, K, name);
+        return launch<T, 3, false, 2, 4>(ctx, As, Bs, C, M, N, kt, r->cols, K, name);
     }
-    if (sym) return launch_layout<4, true>(ctx, layout, As, Bs, C, M, N, kt, r->cols, K, "pearson_gemm_bf16x4");
-    return launch_layout<4, false>(ctx, layout, As, Bs, C, M, N, kt, r->cols, K, "pearson_gemm_bf16x4");
+    if (sym) return launch<T, 4, true, 2, 4>(ctx, As, Bs, C, M, N, kt, r->cols, K, name);
+    return launch<T, 4, false, 2, 4>(ctx, As, Bs, C, M, N, kt, r->cols, K, name);
+}
+
+}  // namespace
+
+int skr_pearson_gemm_split(skr_ctx* ctx, const skr_mat* a, const skr_mat* b, int precision, int symmetric, skr_mat* r,
+                           int64_t row0, int64_t col0) {
+    switch (precision) {
+        case SKR_PREC_BF16X3: return gemm_split<__bf16>(ctx, a, b, 3, symmetric, r, row0, col0, "pearson_gemm_bf16x3");
+        case SKR_PREC_BF16X4: return gemm_split<__bf16>(ctx, a, b, 4, symmetric, r, row0, col0, "pearson_gemm_bf16x4");
+        case SKR_PREC_F16X3: return gemm_split<_Float16>(ctx, a, b, 3, symmetric, r, row0, col0, "pearson_gemm_f16x3");
+        default: return skr_set_error(SKR_ERR_INVALID, "not a split precision: %d", precision);
+    }
 }

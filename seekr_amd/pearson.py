@@ -24,8 +24,8 @@ def _precision_for(dtype):
     if dtype == np.float64:
         return _lib.PREC_F64
     name = os.environ.get("SEEKR_PRECISION", "fp32").lower()
-    if name not in ("fp32", "bf16x3", "bf16x4"):
-        raise ValueError("SEEKR_PRECISION must be fp32, bf16x3 or bf16x4, got {!r}".format(name))
+    if name not in ("fp32", "bf16x3", "bf16x4", "f16x3"):
+        raise ValueError("SEEKR_PRECISION must be fp32, bf16x3, bf16x4 or f16x3, got {!r}".format(name))
     return _lib.PRECISIONS[name]
 
 

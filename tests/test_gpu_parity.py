@@ -451,6 +451,11 @@ def test_cfg2_full_size_properties(L, ctx):
     assert (n_host.sum(axis=1) == length - k + 1).all()          # every window lands in exactly one bin
     prefix = orc.codes_to_seqs(codes[:300])
     assert np.array_equal(n_host[:300], orc.count_kmers_u32(prefix, k))
+    from oracle import c_oracle as co  # C restatement: 12 000 rows spread over the set, bit-exact
+    for first in (0, 23_456, 46_000):
+        sl = slice(first, first + 4000)
+        ref_n = co.count_u32(blob[first * length:(first + 4000) * length], offsets[:4001], k)
+        assert np.array_equal(n_host[sl], ref_n)
     x = L.count_per_kb(ctx, packed, k)
     raw_head = x.to_numpy(0, 300)
     assert_bits(raw_head, orc.per_kb_from_counts(n_host[:300], [length] * 300, k), "per-kb prefix")
@@ -478,7 +483,7 @@ def test_cfg2_full_size_properties(L, ctx):
 
 
 # ------------------------------------------------------------------ split-bf16 MFMA path
-@pytest.mark.parametrize("prec", ["bf16x3", "bf16x4"])
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16x4", "f16x3"])
 @pytest.mark.parametrize("shape", [(5, 7, 16), (130, 257, 64), (300, 200, 100), (640, 515, 4096), (1000, 1000, 1024)])
 def test_pearson_split_bf16_vs_oracle(prec, shape, L, ctx):
     m, n, k = shape
@@ -514,7 +519,7 @@ def test_pearson_split_bf16_vs_oracle(prec, shape, L, ctx):
 def test_pearson_split_bf16_nan_rows(L, ctx):
     m = np.array([[1, 2, 3, 4], [5, 5, 5, 5], [4, 1, 3, 2]], dtype=np.float32)
     ref = orc.pearson(m, m)
-    for prec in ("bf16x3", "bf16x4"):
+    for prec in ("bf16x3", "bf16x4", "f16x3"):
         d = ctx.from_numpy(m)
         got = L.pearson(ctx, d, d, precision=L.PRECISIONS[prec]).to_numpy()
         assert np.array_equal(np.isnan(got), np.isnan(ref))
@@ -533,7 +538,7 @@ def test_cfg2_slab_split_bf16(L, ctx):
     ref = orc.pearson(xs[:1024], xs[:2048])
     # bound = worst |r - truth|, reached on the r = 1 diagonal (4096 positive terms chained in one
     # float32 accumulator); off-diagonal errors are ~1e-7
-    for prec, bound in (("bf16x3", 6e-6), ("bf16x4", 6e-6), ("fp32", 1.2e-6)):
+    for prec, bound in (("bf16x3", 6e-6), ("bf16x4", 6e-6), ("f16x3", 6e-6), ("fp32", 1.2e-6)):
         r = L.pearson(ctx, x, x, precision=L.PRECISIONS[prec]).to_numpy()
         assert np.array_equal(r, r.T)
         blk = r[:1024, :2048]

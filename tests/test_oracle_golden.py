@@ -246,6 +246,28 @@ def test_g6_edges(example_seqs, gold, tmp_path):
         orc.normalize(np.zeros((2, 4), np.float32), log2="log2")
 
 
+def test_c_restatement_matches_numpy_oracle_and_golden(gold):
+    """oracle/seekr_oracle.c (used for full-size checks) is pinned the same way."""
+    from oracle import c_oracle as co
+    meta = gold["meta"]
+    seqs = synth_2000()
+    blob, off = co.seqs_to_blob(seqs)
+    n = co.count_u32(blob, off, 6)
+    assert sha16(n) == meta["g4_u32_sha"]
+    raw = co.per_kb_f32(n, np.diff(off), 6)
+    assert sha16(raw) == meta["g4_raw_sha"]
+    edge = meta["edge"]["edge_seqs"]
+    blob, off = co.seqs_to_blob(edge)
+    n3 = co.count_u32(blob, off, 3)
+    assert np.array_equal(n3, orc.count_kmers_u32(edge, 3))
+    assert np.array_equal(bits(co.per_kb_f32(n3, np.diff(off), 3)), bits(gold["g6_edges"]["edge_raw_k3"]))
+    with pytest.raises(ZeroDivisionError):
+        co.per_kb_f32(n3, np.diff(off) * 0 + 2, 3)
+    big = big_count_matrix(seed=9, n=5000, k_cols=512)
+    assert np.array_equal(bits(co.colsum_seq_f32(big)), bits(orc.seqsum_f32(big)))
+    assert np.array_equal(bits(co.colsum_seq_f32(big) / np.float32(5000)), bits(np.mean(big, axis=0)))
+
+
 def test_synthetic_prefix_property():
     a = orc.synthetic_codes(2, 25, 100, start=9_990)
     b = orc.synthetic_codes(2, 10_015, 100)
