@@ -414,7 +414,8 @@ def test_colsum_chain_carry_equals_single_pass(L, ctx):
 
 
 @pytest.mark.parametrize("shape", [(1, 1, 4), (5, 7, 16), (130, 257, 64), (300, 200, 100), (640, 515, 4096)])
-def test_pearson_fp32_vs_oracle(shape, L, ctx):
+def test_pearson_fp32_vs_oracle(shape, L, ctx, monkeypatch):
+    monkeypatch.setenv("SEEKR_PRECISION", "fp32")
     m, n, k = shape
     rng = np.random.default_rng(m * 1000 + n)
     a = rng.gamma(2.0, 1.0, size=(m, k)).astype(np.float32)
