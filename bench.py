@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from seekr_amd import _lib, launch  # noqa: E402
-from seekr_amd.distributed import HipEngine, shard_bounds, sharded_normalize, sharded_pearson_rowblock  # noqa: E402
+from seekr_amd.distributed import HipEngine, shard_bounds, sharded_normalize_prepare, sharded_pearson_rowblock  # noqa: E402
 from seekr_amd.synthetic import synthetic_ascii, synthetic_codes  # noqa: E402
 
 PEAK = {"hbm_gbs": 8000.0, "fp32_mfma_tflops": 157.3, "bf16_mfma_tflops": 2500.0}  # MI355X_MICROARCH.md
@@ -93,15 +93,15 @@ def main():
     packed = _lib.PackedSeqs.from_buffer(ctx, blob, offsets, "AGTC")
     del blob
     x = ctx.empty(n_loc, n_cols)
-    z = ctx.empty(n_loc, n_cols)
+    z = engine.empty_operand(n_loc, n_cols)  # row-standardised shard in the contraction's operand layout
     r = ctx.empty(n_loc, n_total)
     max_shard = max(bounds[g + 1] - bounds[g] for g in range(size))
-    recv = [ctx.empty(max_shard, n_cols), ctx.empty(max_shard, n_cols)] if size > 1 else [None, None]
+    recv = [engine.empty_operand(max_shard, n_cols), engine.empty_operand(max_shard, n_cols)] if size > 1 else [None, None]
 
     def step():
         _lib.count_per_kb(ctx, packed, k, out=x)
-        sharded_normalize(engine, comm, x, n_total, "Log2.post", True, True)
-        engine.row_standardize(x, z)
+        # column statistics (rank-chained), then ONE pass: normalised counts -> x, standardised rows -> z
+        sharded_normalize_prepare(engine, comm, x, n_total, "Log2.post", True, True, keep_counts=True, op=z)
         sharded_pearson_rowblock(engine, comm, z, bounds, r, recv)
 
     for _ in range(args.warmup):

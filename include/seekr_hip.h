@@ -163,6 +163,30 @@ int skr_row_standardize(skr_ctx* ctx, const skr_mat* x, skr_mat* z);
  * row0 == col0, letting the kernel compute one triangle and mirror it.                      */
 int skr_pearson_gemm(skr_ctx* ctx, const skr_mat* a, const skr_mat* b, int precision, int symmetric,
                      skr_mat* r, int64_t row0, int64_t col0);
+/* Prepared operands.  A skr_operand holds rows in the layout the chosen contraction consumes
+ * (split-interleaved 16-bit halves for the split precisions at cols >= 1024, zero-padded
+ * float32 otherwise), so that standardised rows are produced once, exchanged between GPUs as
+ * they are, and multiplied any number of times.                                              */
+typedef struct skr_operand skr_operand;
+int skr_operand_create(skr_ctx* ctx, int64_t rows, int64_t cols, int precision, skr_operand** out);
+int skr_operand_free(skr_operand* op);
+/* non-owning view of rows [row0, row0+nrows) */
+int skr_operand_view(const skr_operand* parent, int64_t row0, int64_t nrows, skr_operand** out);
+/* the operand's storage as a float32-typed matrix view [rows, 32*ceil(cols/32)] (for
+ * skr_comm_sendrecv); free the view with skr_mat_free                                        */
+int skr_operand_as_mat(skr_operand* op, skr_mat** view);
+/* One fused pass over the float32 matrix x [rows, cols]:
+ *   y  = post(scale(center(x)))   — the elementwise tail of the normalisation, as skr_apply
+ *                                   (kmer_counts.py:169,175,208-209); written to `y` if non-NULL
+ *                                   (y may alias x); skipped when center, scale are NULL, post 0
+ *   z  = row-standardised y (pearson.py:35-38) if row_standardize, else y
+ *   op = z in the operand layout.
+ * has_nan (optional) as in skr_apply.                                                        */
+int skr_operand_fill(skr_ctx* ctx, const skr_mat* x, const skr_mat* center, const skr_mat* scale, int post,
+                     float shift, skr_mat* y, int row_standardize, skr_operand* op, int* has_nan);
+/* r[row0 + i, col0 + j] = <a_i, b_j> / K on prepared operands (same meaning as skr_pearson_gemm) */
+int skr_pearson_gemm_op(skr_ctx* ctx, const skr_operand* a, const skr_operand* b, int symmetric, skr_mat* r,
+                        int64_t row0, int64_t col0);
 /* pearson(counts1, counts2, row_standardize) end to end on device matrices                 */
 int skr_pearson(skr_ctx* ctx, const skr_mat* counts1, const skr_mat* counts2, int row_standardize,
                 int precision, skr_mat* r);

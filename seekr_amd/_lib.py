@@ -64,6 +64,12 @@ SIGNATURES = {
     "skr_row_standardize": (_int, [_p, _p, _p]),
     "skr_pearson_gemm": (_int, [_p, _p, _p, _int, _int, _p, _i64, _i64]),
     "skr_pearson": (_int, [_p, _p, _p, _int, _int, _p]),
+    "skr_operand_create": (_int, [_p, _i64, _i64, _int, C.POINTER(_p)]),
+    "skr_operand_free": (_int, [_p]),
+    "skr_operand_view": (_int, [_p, _i64, _i64, C.POINTER(_p)]),
+    "skr_operand_as_mat": (_int, [_p, C.POINTER(_p)]),
+    "skr_operand_fill": (_int, [_p, _p, _p, _p, _int, C.c_float, _p, _int, _p, C.POINTER(_int)]),
+    "skr_pearson_gemm_op": (_int, [_p, _p, _p, _int, _p, _i64, _i64]),
     "skr_comm_unique_id": (_int, [C.c_char_p]),
     "skr_comm_init": (_int, [_p, _int, _int, C.c_char_p]),
     "skr_comm_destroy": (_int, [_p]),
@@ -243,9 +249,10 @@ class Matrix:
         return (self.rows, self.cols)
 
     def free(self):
-        if getattr(self, "_h", None) and not _shutdown:
+        # a closed Context has been destroyed on the C side: its handles must not be touched
+        if getattr(self, "_h", None) and not _shutdown and getattr(self.ctx, "_h", None):
             lib().skr_mat_free(self._h)
-            self._h = None
+        self._h = None
 
     def __del__(self):
         try:
@@ -276,6 +283,47 @@ class Matrix:
         ptr = _p()
         check(lib().skr_mat_device_ptr(self._h, C.byref(ptr)))
         return ptr.value
+
+
+class Operand:
+    """Rows prepared for the Pearson contraction (skr_operand)."""
+
+    def __init__(self, ctx, rows, cols, precision=PREC_BF16X3, _view_of=None, _row0=0):
+        self.ctx, self.rows, self.cols, self.precision = ctx, int(rows), int(cols), int(precision)
+        self._h = _p()
+        self._parent = _view_of
+        self._mat = None
+        if _view_of is None:
+            check(lib().skr_operand_create(ctx._h, self.rows, self.cols, self.precision, C.byref(self._h)))
+        else:
+            check(lib().skr_operand_view(_view_of._h, int(_row0), self.rows, C.byref(self._h)))
+
+    def view(self, row0, nrows):
+        return Operand(self.ctx, nrows, self.cols, self.precision, _view_of=self, _row0=row0)
+
+    def as_matrix(self):
+        """float32-typed view of the storage, for the RCCL send/recv entry points."""
+        if self._mat is None:
+            h = _p()
+            check(lib().skr_operand_as_mat(self._h, C.byref(h)))
+            m = Matrix.__new__(Matrix)
+            m.ctx, m.rows, m.cols, m.dtype = self.ctx, self.rows, 32 * ((self.cols + 31) // 32), np.dtype(np.float32)
+            m._h, m._parent = h, self
+            self._mat = m
+        return self._mat
+
+    def free(self):
+        if getattr(self, "_h", None) and not _shutdown and getattr(self.ctx, "_h", None):
+            if self._mat is not None:
+                self._mat.free()
+            lib().skr_operand_free(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 def _h(m):
@@ -342,9 +390,9 @@ class PackedSeqs:
         return text.split("\n") if text else []
 
     def free(self):
-        if getattr(self, "_h", None) and not _shutdown:
+        if getattr(self, "_h", None) and not _shutdown and getattr(self.ctx, "_h", None):
             lib().skr_seqs_free(self._h)
-            self._h = None
+        self._h = None
 
     def __del__(self):
         try:
@@ -409,6 +457,21 @@ def row_standardize(ctx, x, z=None):
 
 def pearson_gemm(ctx, a, b, r, precision=PREC_FP32, symmetric=False, row0=0, col0=0):
     check(lib().skr_pearson_gemm(ctx._h, a._h, b._h, int(precision), 1 if symmetric else 0, r._h, int(row0), int(col0)))
+    return r
+
+
+def operand_fill(ctx, x, op=None, precision=PREC_BF16X3, center=None, scale=None, post=False, shift=0.0, y=None,
+                 row_standardize=True, want_nan=False):
+    """Fused normalisation tail + row standardisation + operand layout; returns (op, has_nan)."""
+    op = Operand(ctx, x.rows, x.cols, precision) if op is None else op
+    nan = _int(0)
+    check(lib().skr_operand_fill(ctx._h, x._h, _h(center), _h(scale), 1 if post else 0, C.c_float(shift), _h(y),
+                                 1 if row_standardize else 0, op._h, C.byref(nan) if want_nan else None))
+    return op, bool(nan.value)
+
+
+def pearson_gemm_op(ctx, a, b, r, symmetric=False, row0=0, col0=0):
+    check(lib().skr_pearson_gemm_op(ctx._h, a._h, b._h, 1 if symmetric else 0, r._h, int(row0), int(col0)))
     return r
 
 

@@ -92,9 +92,26 @@ struct SkrProfScope {
 };
 
 int skr_ctx_workspace(skr_ctx* ctx, size_t bytes, void** out);
-// split-operand MFMA contraction (pearson_bf16.hip); precision = SKR_PREC_BF16X3 / BF16X4 / F16X3
-int skr_pearson_gemm_split(skr_ctx* ctx, const skr_mat* a, const skr_mat* b, int precision, int symmetric, skr_mat* r,
-                           int64_t row0, int64_t col0);
+// GEMM launchers (pearson.hip, pearson_bf16.hip), used by operand.hip
+int skr_launch_gemm_f32(skr_ctx* ctx, const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kp,
+                        int64_t lda, int64_t ldb, int64_t ldc, int64_t K);
+int skr_launch_gemm_f64(skr_ctx* ctx, const double* A, const double* B, double* C, int64_t M, int64_t N, int64_t K,
+                        int64_t ldc);
+int skr_launch_gemm_split(skr_ctx* ctx, int precision, const void* As, const void* Bs, float* C, int64_t M, int64_t N,
+                          int64_t kt, int64_t ldc, int64_t K, int sym);
+
+// A Pearson operand prepared for the matrix cores.  Storage is kt*32 float-sized words per row
+// (kt = ceil(cols/32)) in both layouts: zero-padded float32, or split-interleaved 16-bit halves
+// (per 32-wide k tile: 32 hi then 32 lo = one 128-byte line).
+struct skr_operand {
+    skr_ctx* ctx = nullptr;
+    int64_t rows = 0, cols = 0, kt = 0;
+    int precision = SKR_PREC_FP32;
+    int kind = 0;  // 0 = float32 padded, 1 = bf16 halves, 2 = fp16 halves
+    void* data = nullptr;
+    bool owner = true;
+    size_t row_bytes() const { return (size_t)kt * 128; }
+};
 int skr_activate(const skr_ctx* ctx);
 
 // float32 log2 rounded from a float64 evaluation: correctly rounded except for near-ties of the
@@ -102,3 +119,6 @@ int skr_activate(const skr_ctx* ctx);
 // rounded for >90 % of inputs; ocml's f32 log2f is systematically 1 ulp off on many of the
 // discrete per-kb count values, which shifts the float32 column statistics of Log2.pre by >1e-5).
 __device__ __forceinline__ float skr_log2_cr(float x) { return (float)log2((double)x); }
+// Log2.post is the last step (no statistics are taken of its output), so the <= 1 ulp float32
+// log2 is enough there and an order of magnitude cheaper than the float64 evaluation.
+__device__ __forceinline__ float skr_log2_fast(float x) { return log2f(x); }

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void elementwise_kernel(const float* __restric
         if (POST) {
             v = __fadd_rn(v, shift);
             v = __fadd_rn(v, 1.0f);
-            v = skr_log2_cr(v);
+            v = skr_log2_fast(v);
         }
         return v;
     };

@@ -1,0 +1,369 @@
+// Pearson operands: one fused pass turns (raw or normalised) count rows into what the matrix
+// cores consume — optional elementwise normalisation tail (kmer_counts.py:169,175,208-209), row
+// standardisation (pearson.py:35-38) and the split into 16-bit halves — so the float32 z matrix
+// never makes a round trip through HBM, and a shard received from another GPU is used as is.
+#include <algorithm>
+#include <cmath>
+
+#include "common.hpp"
+
+namespace {
+
+template <typename T>
+using vec8 = T __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;  // every lane holds the total
+}
+
+struct FillArgs {
+    const float* x;
+    int64_t rows, cols, kt;
+    const void* center;  // ck: 0 none, 1 f32, 2 f64
+    const void* scale;
+    int ck, sk, post, row_standardize;
+    float shift;
+    float* y;  // optional normalised-count output (may alias x)
+    void* out;
+    uint32_t* flags;
+};
+
+// One WAVE per row (grid-stride over rows): the row is loaded once with 16-byte coalesced loads,
+// parked in a wave-private LDS slice between the passes, and all reductions are wave shuffles, so
+// there is no workgroup barrier anywhere.  T = float (zero-padded float32 operand), __bf16 or
+// _Float16 (split-interleaved halves).
+__device__ __forceinline__ float fill_tail(const FillArgs& a, float v, int64_t c, bool& any_nan) {
+    if (a.ck == 1) v = __fsub_rn(v, reinterpret_cast<const float*>(a.center)[c]);
+    else if (a.ck == 2) v = (float)((double)v - reinterpret_cast<const double*>(a.center)[c]);
+    if (a.sk == 1) v = __fdiv_rn(v, reinterpret_cast<const float*>(a.scale)[c]);
+    else if (a.sk == 2) v = (float)((double)v / reinterpret_cast<const double*>(a.scale)[c]);
+    if (v != v) any_nan = true;
+    if (a.post) {
+        v = __fadd_rn(v, a.shift);
+        v = __fadd_rn(v, 1.0f);
+        v = skr_log2_fast(v);
+    }
+    return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void operand_fill_kernel(FillArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    const int64_t K = a.cols, Kp = a.kt * 32;
+    float* row = lds + (size_t)wave * ((K + 3) & ~(int64_t)3);
+    const bool vec = (K & 3) == 0;
+    bool any_nan = false;
+    for (int64_t r = (int64_t)blockIdx.x * waves + wave; r < a.rows; r += (int64_t)gridDim.x * waves) {
+        const float* xr = a.x + (size_t)r * K;
+        // ---- pass 1: load, elementwise tail of the normalisation, optional write-back, row sum
+        float s = 0.f;
+        if (vec) {
+            for (int64_t c = lane * 4; c < K; c += 256) {
+                float4 v = *reinterpret_cast<const float4*>(xr + c);
+                v.x = fill_tail(a, v.x, c, any_nan);
+                v.y = fill_tail(a, v.y, c + 1, any_nan);
+                v.z = fill_tail(a, v.z, c + 2, any_nan);
+                v.w = fill_tail(a, v.w, c + 3, any_nan);
+                if (a.y) *reinterpret_cast<float4*>(a.y + (size_t)r * K + c) = v;
+                *reinterpret_cast<float4*>(row + c) = v;
+                s += (v.x + v.y) + (v.z + v.w);
+            }
+        } else {
+            for (int64_t c = lane; c < K; c += 64) {
+                const float v = fill_tail(a, xr[c], c, any_nan);
+                if (a.y) a.y[(size_t)r * K + c] = v;
+                row[c] = v;
+                s += v;
+            }
+        }
+        // ---- pass 2: row statistics in the order pearson.py:35-38 computes them
+        float mean = 0.f, sd = 1.f;
+        if (a.row_standardize) {
+            const float kf = (float)K;
+            mean = wave_sum(s) / kf;
+            s = 0.f;
+            for (int64_t c = lane; c < K; c += 64) s += row[c] - mean;
+            const float m2 = wave_sum(s) / kf;
+            s = 0.f;
+            for (int64_t c = lane; c < K; c += 64) {
+                const float d = (row[c] - mean) - m2;
+                s += d * d;
+            }
+            sd = sqrtf(wave_sum(s) / kf);
+        }
+        // ---- pass 3: emit the operand row, 8 k per lane and step
+        for (int64_t g = lane; g < a.kt * 4; g += 64) {
+            const int64_t tile = g >> 2, sub = g & 3, k0 = tile * 32 + sub * 8;
+            float z[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int64_t k = k0 + j;
+                float v = k < K ? row[k] : 0.f;
+                if (a.row_standardize && k < K) v = (v - mean) / sd;
+                z[j] = v;
+            }
+            if (sizeof(T) == 4) {
+                float* dst = reinterpret_cast<float*>(a.out) + (size_t)r * Kp + k0;
+                *reinterpret_cast<float4*>(dst) = make_float4(z[0], z[1], z[2], z[3]);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(z[4], z[5], z[6], z[7]);
+            } else {
+                vec8<T> hi, lo;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const T hh = (T)z[j];               // hardware convert: RNE, NaN stays NaN
+                    hi[j] = hh;
+                    lo[j] = (T)(z[j] - (float)hh);      // exact difference, then RNE
+                }
+                T* dst = reinterpret_cast<T*>(a.out) + ((size_t)r * a.kt + tile) * 64 + sub * 8;
+                *reinterpret_cast<vec8<T>*>(dst) = hi;
+                *reinterpret_cast<vec8<T>*>(dst + 32) = lo;
+            }
+        }
+    }
+    if (any_nan) atomicOr(&a.flags[1], 1u);
+}
+
+int vec_kind(const skr_mat* v, int64_t cols, const char* what, int* kind) {
+    *kind = 0;
+    if (!v) return SKR_OK;
+    SKR_REQUIRE(v->rows * v->cols == cols, "%s vector has %lld entries, matrix has %lld columns", what,
+                (long long)(v->rows * v->cols), (long long)cols);
+    SKR_REQUIRE(v->dtype == SKR_F32 || v->dtype == SKR_F64, "%s vector must be float32 or float64", what);
+    *kind = v->dtype == SKR_F32 ? 1 : 2;
+    return SKR_OK;
+}
+
+int check_pair(const skr_ctx* ctx, const skr_mat* a, const skr_mat* b) {
+    SKR_REQUIRE(ctx && a && b, "NULL argument");
+    SKR_REQUIRE(a->ctx == ctx && b->ctx == ctx, "matrix belongs to a different ctx");
+    SKR_REQUIRE(a->dtype == b->dtype && (a->dtype == SKR_F32 || a->dtype == SKR_F64),
+                "operands must both be float32 or both float64");
+    if (a->cols != b->cols)
+        return skr_set_error(SKR_ERR_INVALID, "shapes (%lld,%lld) and (%lld,%lld) not aligned: %lld (dim 1) != %lld (dim 1)",
+                             (long long)a->rows, (long long)a->cols, (long long)b->rows, (long long)b->cols,
+                             (long long)a->cols, (long long)b->cols);
+    return SKR_OK;
+}
+
+bool is_f32_precision(int p) {
+    return p == SKR_PREC_FP32 || p == SKR_PREC_BF16X3 || p == SKR_PREC_BF16X4 || p == SKR_PREC_F16X3;
+}
+
+}  // namespace
+
+extern "C" int skr_operand_create(skr_ctx* ctx, int64_t rows, int64_t cols, int precision, skr_operand** out) {
+    SKR_REQUIRE(ctx && out, "NULL argument");
+    *out = nullptr;
+    SKR_REQUIRE(rows >= 0 && cols > 0, "bad operand shape [%lld, %lld]", (long long)rows, (long long)cols);
+    SKR_REQUIRE(is_f32_precision(precision), "operands exist for float32 precisions only (got %d)", precision);
+    SKR_TRY(skr_activate(ctx));
+    skr_operand* op = new skr_operand();
+    op->ctx = ctx;
+    op->rows = rows;
+    op->cols = cols;
+    op->kt = (cols + 31) / 32;
+    op->precision = precision;
+    // The split error averages out like 1/sqrt(K): at K >= 1024 (k >= 5) it is inside the parity bar
+    // (|dr| <= 2e-6 + 1e-5 |r|); below that the exact-product fp32 MFMA is used, where it is cheap.
+    if (precision == SKR_PREC_FP32 || cols < 1024) op->kind = 0;
+    else op->kind = precision == SKR_PREC_F16X3 ? 2 : 1;
+    size_t bytes = std::max<size_t>((size_t)rows * op->row_bytes(), 16);
+    hipError_t e = hipMalloc(&op->data, bytes);
+    if (e != hipSuccess) {
+        delete op;
+        return skr_set_error(SKR_ERR_NOMEM, "hipMalloc(%zu bytes) for a %lld x %lld operand failed: %s", bytes,
+                             (long long)rows, (long long)cols, hipGetErrorString(e));
+    }
+    *out = op;
+    return SKR_OK;
+}
+
+extern "C" int skr_operand_free(skr_operand* op) {
+    if (!op) return SKR_OK;
+    if (op->owner) {
+        (void)hipSetDevice(op->ctx->device);
+        (void)hipStreamSynchronize(op->ctx->stream);
+        (void)hipStreamSynchronize(op->ctx->comm_stream);
+        if (op->data) (void)hipFree(op->data);
+    }
+    delete op;
+    return SKR_OK;
+}
+
+extern "C" int skr_operand_view(const skr_operand* parent, int64_t row0, int64_t nrows, skr_operand** out) {
+    SKR_REQUIRE(parent && out, "NULL argument");
+    *out = nullptr;
+    SKR_REQUIRE(row0 >= 0 && nrows >= 0 && row0 + nrows <= parent->rows, "view rows [%lld, %lld) outside 0..%lld",
+                (long long)row0, (long long)(row0 + nrows), (long long)parent->rows);
+    skr_operand* v = new skr_operand(*parent);
+    v->rows = nrows;
+    v->owner = false;
+    v->data = (char*)parent->data + (size_t)row0 * parent->row_bytes();
+    *out = v;
+    return SKR_OK;
+}
+
+extern "C" int skr_operand_as_mat(skr_operand* op, skr_mat** view) {
+    SKR_REQUIRE(op && view, "NULL argument");
+    skr_mat* m = new skr_mat();
+    m->ctx = op->ctx;
+    m->rows = op->rows;
+    m->cols = op->kt * 32;  // float-sized words per row in either layout
+    m->dtype = SKR_F32;
+    m->owner = false;
+    m->data = op->data;
+    *view = m;
+    return SKR_OK;
+}
+
+extern "C" int skr_operand_fill(skr_ctx* ctx, const skr_mat* x, const skr_mat* center, const skr_mat* scale, int post,
+                                float shift, skr_mat* y, int row_standardize, skr_operand* op, int* has_nan) {
+    SKR_REQUIRE(ctx && x && op, "NULL argument");
+    SKR_REQUIRE(x->ctx == ctx && op->ctx == ctx, "handle belongs to a different ctx");
+    SKR_REQUIRE(x->dtype == SKR_F32, "operands are filled from float32 matrices");
+    SKR_REQUIRE(x->rows == op->rows && x->cols == op->cols, "operand is [%lld, %lld], matrix is [%lld, %lld]",
+                (long long)op->rows, (long long)op->cols, (long long)x->rows, (long long)x->cols);
+    if (y) SKR_REQUIRE(y->ctx == ctx && y->dtype == SKR_F32 && y->rows == x->rows && y->cols == x->cols, "bad y");
+    FillArgs a;
+    a.x = (const float*)x->data;
+    a.rows = x->rows;
+    a.cols = x->cols;
+    a.kt = op->kt;
+    SKR_TRY(vec_kind(center, x->cols, "center", &a.ck));
+    SKR_TRY(vec_kind(scale, x->cols, "scale", &a.sk));
+    a.center = center ? center->data : nullptr;
+    a.scale = scale ? scale->data : nullptr;
+    a.post = post != 0;
+    a.shift = shift;
+    a.row_standardize = row_standardize != 0;
+    a.y = y ? (float*)y->data : nullptr;
+    a.out = op->data;
+    a.flags = ctx->d_flags;
+    SKR_TRY(skr_activate(ctx));
+    if (has_nan) *has_nan = 0;
+    if (x->rows == 0) return SKR_OK;
+    const size_t row_floats = (size_t)((x->cols + 3) & ~(int64_t)3);
+    if (row_floats * 4 > 150 * 1024)
+        return skr_set_error(SKR_ERR_UNSUPPORTED, "rows of %lld columns do not fit the LDS row buffer", (long long)x->cols);
+    const int waves = (int)std::max<size_t>(1, std::min<size_t>(4, (64 * 1024) / (row_floats * 4)));
+    const size_t lds = row_floats * 4 * waves;
+    SKR_HIP(hipMemsetAsync(ctx->d_flags + 1, 0, 4, ctx->stream));
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / lds));
+    const int64_t want = (x->rows + waves - 1) / waves;
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cu * per_cu));
+    {
+        SkrProfScope prof(ctx, "operand_fill");
+#define LAUNCH(T)                                                                                             \
+    do {                                                                                                      \
+        SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(operand_fill_kernel<T>),                    \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
+        hipLaunchKernelGGL(operand_fill_kernel<T>, dim3(grid), dim3(64 * waves), lds, ctx->stream, a);               \
+    } while (0)
+        if (op->kind == 0) LAUNCH(float);
+        else if (op->kind == 1) LAUNCH(__bf16);
+        else LAUNCH(_Float16);
+#undef LAUNCH
+        SKR_HIP(hipGetLastError());
+    }
+    if (has_nan) {
+        SKR_HIP(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        SKR_HIP(hipStreamSynchronize(ctx->stream));
+        *has_nan = ctx->h_flags[1] != 0;
+    }
+    return SKR_OK;
+}
+
+extern "C" int skr_pearson_gemm_op(skr_ctx* ctx, const skr_operand* a, const skr_operand* b, int symmetric, skr_mat* r,
+                                   int64_t row0, int64_t col0) {
+    SKR_REQUIRE(ctx && a && b && r, "NULL argument");
+    SKR_REQUIRE(a->ctx == ctx && b->ctx == ctx && r->ctx == ctx, "handle belongs to a different ctx");
+    SKR_REQUIRE(a->cols == b->cols && a->kind == b->kind && a->precision == b->precision,
+                "operands were prepared for different shapes or precisions");
+    SKR_REQUIRE(r->dtype == SKR_F32, "result matrix must be float32");
+    SKR_REQUIRE(row0 >= 0 && col0 >= 0 && row0 + a->rows <= r->rows && col0 + b->rows <= r->cols,
+                "result block [%lld+%lld, %lld+%lld] outside [%lld, %lld]", (long long)row0, (long long)a->rows,
+                (long long)col0, (long long)b->rows, (long long)r->rows, (long long)r->cols);
+    SKR_TRY(skr_activate(ctx));
+    const int64_t M = a->rows, N = b->rows, K = a->cols;
+    if (M == 0 || N == 0) return SKR_OK;
+    float* C = (float*)r->data + (size_t)row0 * r->cols + col0;
+    if (a->kind == 0) {
+        const int64_t Kp = a->kt * 32;
+        return skr_launch_gemm_f32(ctx, (const float*)a->data, (const float*)b->data, C, M, N, Kp, Kp, Kp, r->cols, K);
+    }
+    const bool sym = symmetric && a->data == b->data && M == N;
+    return skr_launch_gemm_split(ctx, a->precision, a->data, b->data, C, M, N, a->kt, r->cols, K, sym);
+}
+
+// ---- matrix-level entry points built on operands ------------------------------------------------
+extern "C" int skr_pearson_gemm(skr_ctx* ctx, const skr_mat* a, const skr_mat* b, int precision, int symmetric,
+                                skr_mat* r, int64_t row0, int64_t col0) {
+    SKR_TRY(check_pair(ctx, a, b));
+    SKR_REQUIRE(r && r->ctx == ctx && r->dtype == a->dtype, "result matrix missing or of the wrong dtype");
+    SKR_REQUIRE(row0 >= 0 && col0 >= 0 && row0 + a->rows <= r->rows && col0 + b->rows <= r->cols,
+                "result block [%lld+%lld, %lld+%lld] outside [%lld, %lld]", (long long)row0, (long long)a->rows,
+                (long long)col0, (long long)b->rows, (long long)r->rows, (long long)r->cols);
+    SKR_TRY(skr_activate(ctx));
+    if (a->rows == 0 || b->rows == 0) return SKR_OK;
+    if (a->cols == 0) return skr_set_error(SKR_ERR_INVALID, "matrices have no columns");
+    if (a->dtype == SKR_F64) {
+        SKR_REQUIRE(precision == SKR_PREC_F64, "float64 operands need SKR_PREC_F64");
+        return skr_launch_gemm_f64(ctx, (const double*)a->data, (const double*)b->data,
+                                   (double*)r->data + (size_t)row0 * r->cols + col0, a->rows, b->rows, a->cols, r->cols);
+    }
+    SKR_REQUIRE(is_f32_precision(precision),
+                "float32 operands need SKR_PREC_FP32, SKR_PREC_BF16X3, SKR_PREC_BF16X4 or SKR_PREC_F16X3");
+    const bool same = a->data == b->data && a->rows == b->rows;
+    skr_operand *oa = nullptr, *ob = nullptr;
+    int rc = skr_operand_create(ctx, a->rows, a->cols, precision, &oa);
+    if (rc == SKR_OK) rc = skr_operand_fill(ctx, a, nullptr, nullptr, 0, 0.f, nullptr, 0, oa, nullptr);
+    if (rc == SKR_OK && !same) {
+        rc = skr_operand_create(ctx, b->rows, b->cols, precision, &ob);
+        if (rc == SKR_OK) rc = skr_operand_fill(ctx, b, nullptr, nullptr, 0, 0.f, nullptr, 0, ob, nullptr);
+    }
+    if (rc == SKR_OK) rc = skr_pearson_gemm_op(ctx, oa, same ? oa : ob, symmetric, r, row0, col0);
+    skr_operand_free(oa);
+    skr_operand_free(ob);
+    return rc;
+}
+
+extern "C" int skr_pearson(skr_ctx* ctx, const skr_mat* counts1, const skr_mat* counts2, int row_standardize,
+                           int precision, skr_mat* r) {
+    SKR_TRY(check_pair(ctx, counts1, counts2));
+    SKR_REQUIRE(r, "result matrix is NULL");
+    SKR_REQUIRE(r->rows == counts1->rows && r->cols == counts2->rows, "result must be [%lld, %lld]",
+                (long long)counts1->rows, (long long)counts2->rows);
+    if (counts1->cols == 0) return skr_set_error(SKR_ERR_INVALID, "matrices have no columns");
+    const bool same = counts1 == counts2;
+    if (counts1->dtype == SKR_F64) {
+        if (!row_standardize) return skr_pearson_gemm(ctx, counts1, counts2, precision, 0, r, 0, 0);
+        skr_mat *z1 = nullptr, *z2 = nullptr;
+        int rc = skr_mat_create(ctx, counts1->rows, counts1->cols, SKR_F64, &z1);
+        if (rc == SKR_OK) rc = skr_row_standardize(ctx, counts1, z1);
+        if (rc == SKR_OK && !same) {
+            rc = skr_mat_create(ctx, counts2->rows, counts2->cols, SKR_F64, &z2);
+            if (rc == SKR_OK) rc = skr_row_standardize(ctx, counts2, z2);
+        }
+        if (rc == SKR_OK) rc = skr_pearson_gemm(ctx, z1, same ? z1 : z2, precision, same, r, 0, 0);
+        skr_mat_free(z1);
+        skr_mat_free(z2);
+        return rc;
+    }
+    SKR_REQUIRE(is_f32_precision(precision), "float32 counts need a float32 precision");
+    SKR_REQUIRE(r->dtype == SKR_F32 && r->ctx == ctx, "result matrix must be a float32 matrix of this ctx");
+    if (counts1->rows == 0 || counts2->rows == 0) return SKR_OK;
+    skr_operand *o1 = nullptr, *o2 = nullptr;
+    int rc = skr_operand_create(ctx, counts1->rows, counts1->cols, precision, &o1);
+    if (rc == SKR_OK) rc = skr_operand_fill(ctx, counts1, nullptr, nullptr, 0, 0.f, nullptr, row_standardize, o1, nullptr);
+    if (rc == SKR_OK && !same) {
+        rc = skr_operand_create(ctx, counts2->rows, counts2->cols, precision, &o2);
+        if (rc == SKR_OK) rc = skr_operand_fill(ctx, counts2, nullptr, nullptr, 0, 0.f, nullptr, row_standardize, o2, nullptr);
+    }
+    if (rc == SKR_OK) rc = skr_pearson_gemm_op(ctx, o1, same ? o1 : o2, same, r, 0, 0);
+    skr_operand_free(o1);
+    skr_operand_free(o2);
+    return rc;
+}

@@ -263,18 +263,6 @@ __global__ __launch_bounds__(256) void pearson_gemm_f64_kernel(const double* __r
             }
 }
 
-int check_pair(const skr_ctx* ctx, const skr_mat* a, const skr_mat* b) {
-    SKR_REQUIRE(ctx && a && b, "NULL argument");
-    SKR_REQUIRE(a->ctx == ctx && b->ctx == ctx, "matrix belongs to a different ctx");
-    SKR_REQUIRE(a->dtype == b->dtype && (a->dtype == SKR_F32 || a->dtype == SKR_F64),
-                "operands must both be float32 or both float64");
-    if (a->cols != b->cols)
-        return skr_set_error(SKR_ERR_INVALID, "shapes (%lld,%lld) and (%lld,%lld) not aligned: %lld (dim 1) != %lld (dim 1)",
-                             (long long)a->rows, (long long)a->cols, (long long)b->rows, (long long)b->cols,
-                             (long long)a->cols, (long long)b->cols);
-    return SKR_OK;
-}
-
 }  // namespace
 
 extern "C" int skr_row_standardize(skr_ctx* ctx, const skr_mat* x, skr_mat* z) {
@@ -296,83 +284,26 @@ extern "C" int skr_row_standardize(skr_ctx* ctx, const skr_mat* x, skr_mat* z) {
     return SKR_OK;
 }
 
-extern "C" int skr_pearson_gemm(skr_ctx* ctx, const skr_mat* a, const skr_mat* b, int precision, int symmetric,
-                                skr_mat* r, int64_t row0, int64_t col0) {
-    SKR_TRY(check_pair(ctx, a, b));
-    SKR_REQUIRE(r && r->ctx == ctx && r->dtype == a->dtype, "result matrix missing or of the wrong dtype");
-    SKR_REQUIRE(row0 >= 0 && col0 >= 0 && row0 + a->rows <= r->rows && col0 + b->rows <= r->cols,
-                "result block [%lld+%lld, %lld+%lld] outside [%lld, %lld]", (long long)row0, (long long)a->rows,
-                (long long)col0, (long long)b->rows, (long long)r->rows, (long long)r->cols);
-    (void)symmetric;
-    SKR_TRY(skr_activate(ctx));
-    const int64_t M = a->rows, N = b->rows, K = a->cols;
-    if (M == 0 || N == 0) return SKR_OK;
-    if (a->dtype == SKR_F64) {
-        SKR_REQUIRE(precision == SKR_PREC_F64, "float64 operands need SKR_PREC_F64");
-        const int64_t tiles_m = (M + 31) / 32, tiles_n = (N + 31) / 32;
-        const unsigned grid = (unsigned)((tiles_m * tiles_n + 3) / 4);
-        SkrProfScope prof(ctx, "pearson_gemm_f64");
-        hipLaunchKernelGGL(pearson_gemm_f64_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const double*)a->data,
-                           (const double*)b->data, (double*)r->data + (size_t)row0 * r->cols + col0, M, N, K, K, K,
-                           r->cols, (double)K, tiles_n);
-        SKR_HIP(hipGetLastError());
-        return SKR_OK;
-    }
-    SKR_REQUIRE(precision == SKR_PREC_FP32 || precision == SKR_PREC_BF16X3 || precision == SKR_PREC_BF16X4 ||
-                    precision == SKR_PREC_F16X3,
-                "float32 operands need SKR_PREC_FP32, SKR_PREC_BF16X3, SKR_PREC_BF16X4 or SKR_PREC_F16X3");
-    if (K == 0) return skr_set_error(SKR_ERR_INVALID, "matrices have no columns");
-    // The split-bf16 error averages out like 1/sqrt(K): at K >= 1024 (k >= 5) it is inside the
-    // parity bar (|dr| <= 2e-6 + 1e-5 |r|); below that the exact-product fp32 MFMA is used, where
-    // it is cheap anyway.
-    if (precision != SKR_PREC_FP32 && K >= 1024)
-        return skr_pearson_gemm_split(ctx, a, b, precision, symmetric, r, row0, col0);
-    // the MFMA kernel wants K % 32 == 0: stage zero-padded copies when it is not
-    const float* A = (const float*)a->data;
-    const float* B = (const float*)b->data;
-    int64_t lda = K, ldb = K, Kp = K;
-    if (K % BK != 0) {
-        Kp = (K + BK - 1) / BK * BK;
-        void* ws = nullptr;
-        const size_t need = (size_t)(M + N) * Kp * sizeof(float);
-        SKR_TRY(skr_ctx_workspace(ctx, need, &ws));
-        SKR_HIP(hipMemsetAsync(ws, 0, need, ctx->stream));
-        float* Ap = (float*)ws;
-        float* Bp = Ap + (size_t)M * Kp;
-        SKR_HIP(hipMemcpy2DAsync(Ap, Kp * 4, A, K * 4, K * 4, M, hipMemcpyDeviceToDevice, ctx->stream));
-        SKR_HIP(hipMemcpy2DAsync(Bp, Kp * 4, B, K * 4, K * 4, N, hipMemcpyDeviceToDevice, ctx->stream));
-        A = Ap;
-        B = Bp;
-        lda = ldb = Kp;
-    }
+// ---- launchers used by operand.hip -----------------------------------------------------------
+int skr_launch_gemm_f32(skr_ctx* ctx, const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kp,
+                        int64_t lda, int64_t ldb, int64_t ldc, int64_t K) {
     const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pearson_gemm_f32_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
     SkrProfScope prof(ctx, "pearson_gemm_f32");
     hipLaunchKernelGGL(pearson_gemm_f32_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 2 * kStageBytes,
-                       ctx->stream, A, B, (float*)r->data + (size_t)row0 * r->cols + col0, M, N, Kp, lda, ldb, r->cols,
-                       (float)K, tiles_m, tiles_n);
+                       ctx->stream, A, B, C, M, N, Kp, lda, ldb, ldc, (float)K, tiles_m, tiles_n);
     SKR_HIP(hipGetLastError());
     return SKR_OK;
 }
 
-extern "C" int skr_pearson(skr_ctx* ctx, const skr_mat* counts1, const skr_mat* counts2, int row_standardize,
-                           int precision, skr_mat* r) {
-    SKR_TRY(check_pair(ctx, counts1, counts2));
-    SKR_REQUIRE(r, "result matrix is NULL");
-    SKR_REQUIRE(r->rows == counts1->rows && r->cols == counts2->rows, "result must be [%lld, %lld]",
-                (long long)counts1->rows, (long long)counts2->rows);
-    if (!row_standardize) return skr_pearson_gemm(ctx, counts1, counts2, precision, 0, r, 0, 0);
-    const bool same = counts1 == counts2;
-    skr_mat *z1 = nullptr, *z2 = nullptr;
-    int rc = skr_mat_create(ctx, counts1->rows, counts1->cols, counts1->dtype, &z1);
-    if (rc == SKR_OK) rc = skr_row_standardize(ctx, counts1, z1);
-    if (rc == SKR_OK && !same) {
-        rc = skr_mat_create(ctx, counts2->rows, counts2->cols, counts2->dtype, &z2);
-        if (rc == SKR_OK) rc = skr_row_standardize(ctx, counts2, z2);
-    }
-    if (rc == SKR_OK) rc = skr_pearson_gemm(ctx, z1, same ? z1 : z2, precision, same, r, 0, 0);
-    skr_mat_free(z1);
-    skr_mat_free(z2);
-    return rc;
+int skr_launch_gemm_f64(skr_ctx* ctx, const double* A, const double* B, double* C, int64_t M, int64_t N, int64_t K,
+                        int64_t ldc) {
+    const int64_t tiles_m = (M + 31) / 32, tiles_n = (N + 31) / 32;
+    const unsigned grid = (unsigned)((tiles_m * tiles_n + 3) / 4);
+    SkrProfScope prof(ctx, "pearson_gemm_f64");
+    hipLaunchKernelGGL(pearson_gemm_f64_kernel, dim3(grid), dim3(256), 0, ctx->stream, A, B, C, M, N, K, K, K, ldc,
+                       (double)K, tiles_n);
+    SKR_HIP(hipGetLastError());
+    return SKR_OK;
 }

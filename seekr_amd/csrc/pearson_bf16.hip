@@ -18,6 +18,7 @@
 // The LDS image is lane-linear (LDS-DMA), so the bank swizzle chunk ^= (row >> 1) & 7 is applied
 // on the source address and again on the read (same involution), as in the fp32 kernel.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.hpp"
 
@@ -42,40 +43,6 @@ __device__ __forceinline__ f32x16 mfma16(vec8<_Float16> a, vec8<_Float16> b, f32
 __device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16, 0, 0);
-}
-
-// z (f32, [rows, cols]) -> split-interleaved bf16 [rows, kt, {hi,lo}, 32]; k >= cols padded with 0
-template <typename T>
-__global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ z, int64_t rows, int64_t cols,
-                                                    int64_t kt, T* __restrict__ out) {
-    const int64_t groups_per_row = kt * 4;  // 8 k per thread
-    const int64_t total = rows * groups_per_row;
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = g / groups_per_row, q = g % groups_per_row;
-        const int64_t tile = q >> 2, sub = q & 3;
-        const int64_t k0 = tile * 32 + sub * 8;
-        float v[8];
-        const float* src = z + (size_t)row * cols + k0;
-        if (k0 + 8 <= cols && (cols % 4) == 0) {
-            const float4 a = *reinterpret_cast<const float4*>(src);
-            const float4 b = *reinterpret_cast<const float4*>(src + 4);
-            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-            v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; j++) v[j] = (k0 + j < cols) ? src[j] : 0.f;
-        }
-        vec8<T> hi, lo;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const T h = (T)v[j];            // hardware convert: RNE, NaN stays NaN
-            hi[j] = h;
-            lo[j] = (T)(v[j] - (float)h);   // exact difference, then RNE
-        }
-        T* dst = out + ((size_t)row * kt + tile) * 64 + sub * 8;
-        *reinterpret_cast<vec8<T>*>(dst) = hi;
-        *reinterpret_cast<vec8<T>*>(dst + 32) = lo;
-    }
 }
 
 // Tile order.  Blocks are dealt round-robin to the 8 XCDs (b % 8 labels the XCD group); the i-th
@@ -249,6 +216,163 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4) void pearson_gemm_bf16
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Same contraction on the 16x16x32 MFMA shape.  Identical block tile, staging, LDS image, swizzle,
+// accumulator count (8 x 4 tiles x 4 regs = 128) and LDS bytes per flop; per 32-k tile a wave
+// issues 24 ds_read_b128 and 32*NPROD MFMAs of 16 cycles.  The chip holds a higher clock on this
+// shape under load (MI355X_MICROARCH.md, DVFS give-back item 7), which is the only reason to
+// prefer it.  Lane l holds A[row l&15][k = 8(l>>4)+j] / B likewise; D: col = l&15, row = 4(l>>4)+e.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4v mfma16x16(vec8<__bf16> a, vec8<__bf16> b, f32x4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4v mfma16x16(vec8<_Float16> a, vec8<_Float16> b, f32x4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+template <typename T, int NPROD, bool SYM>
+__global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
+    const T* __restrict__ A, const T* __restrict__ B, float* __restrict__ C, float* __restrict__ Ct,
+    int64_t M, int64_t N, int64_t kt, int64_t ldc, float kdiv, int64_t tiles_m, int64_t tiles_n, int64_t super_n) {
+    constexpr int WN = 4, MT = 8, NT = 4, PP = 4;  // 8 waves as 2 x 4, wave tile 128 x 64
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int64_t tm, tn;
+    if (!tile_of_block(blockIdx.x, super_n, tiles_m, tiles_n, &tm, &tn)) return;
+    if (SYM && tn < tm) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int64_t row_base = tm * TM, col_base = tn * TN;
+    const int64_t pitch = kt * 64;
+
+    const T* a_src[PP];
+    const T* b_src[PP];
+#pragma unroll
+    for (int p = 0; p < PP; p++) {
+        const int row = (wave * PP + p) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        const int64_t ra = std::min<int64_t>(row_base + row, M - 1);
+        const int64_t rb = std::min<int64_t>(col_base + row, N - 1);
+        a_src[p] = A + (size_t)ra * pitch + chunk * 8;
+        b_src[p] = B + (size_t)rb * pitch + chunk * 8;
+    }
+    auto stage = [&](int buf, int64_t tile) {
+        char* abase = smem + buf * kStageBytes;
+        char* bbase = abase + TM * kRowBytes;
+#pragma unroll
+        for (int p = 0; p < PP; p++) {
+            lds_dma16(a_src[p] + tile * 64, abase + (wave * PP + p) * 1024);
+            lds_dma16(b_src[p] + tile * 64, bbase + (wave * PP + p) * 1024);
+        }
+    };
+
+    const int q = lane >> 4;  // k quarter: this lane's fragment is k = 8q .. 8q+7 of the 32-k tile
+    int a_off[MT], a_swz[MT], b_off[NT], b_swz[NT];
+#pragma unroll
+    for (int t = 0; t < MT; t++) {
+        const int ra = wm * 128 + t * 16 + (lane & 15);
+        a_off[t] = ra * kRowBytes;
+        a_swz[t] = (ra >> 1) & 7;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const int rb = wn * 64 + t * 16 + (lane & 15);
+        b_off[t] = TM * kRowBytes + rb * kRowBytes;
+        b_swz[t] = (rb >> 1) & 7;
+    }
+
+    f32x4v acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[i][j][e] = 0.f;
+
+    int cur = 0;
+    stage(0, 0);
+    __syncthreads();
+    for (int64_t t = 0; t < kt; t++) {
+        if (t + 1 < kt) stage(cur ^ 1, t + 1);
+        const char* base = smem + cur * kStageBytes;
+        vec8<T> ahi[MT], alo[MT], bhi[NT], blo[NT];
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            bhi[i] = *reinterpret_cast<const vec8<T>*>(base + b_off[i] + ((q ^ b_swz[i]) << 4));
+            blo[i] = *reinterpret_cast<const vec8<T>*>(base + b_off[i] + (((4 + q) ^ b_swz[i]) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < MT; i++) {
+            ahi[i] = *reinterpret_cast<const vec8<T>*>(base + a_off[i] + ((q ^ a_swz[i]) << 4));
+            alo[i] = *reinterpret_cast<const vec8<T>*>(base + a_off[i] + (((4 + q) ^ a_swz[i]) << 4));
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                if (NPROD >= 4) acc[mt][nt] = mfma16x16(alo[mt], blo[nt], acc[mt][nt]);
+                acc[mt][nt] = mfma16x16(alo[mt], bhi[nt], acc[mt][nt]);
+                acc[mt][nt] = mfma16x16(ahi[mt], blo[nt], acc[mt][nt]);
+                acc[mt][nt] = mfma16x16(ahi[mt], bhi[nt], acc[mt][nt]);
+            }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    const bool mirror = SYM && tm != tn;
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            const int64_t n = col_base + wn * 64 + nt * 16 + (lane & 15);
+            const int64_t m0 = row_base + wm * 128 + mt * 16 + 4 * q;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = acc[mt][nt][e] / kdiv;
+            if (SYM && tm == tn) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int64_t m = m0 + e;
+                    if (n < N && m < M && n >= m) {
+                        C[(size_t)m * ldc + n] = v[e];
+                        if (n > m) Ct[(size_t)n * ldc + m] = v[e];
+                    }
+                }
+            } else if (n < N) {
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (m0 + e < M) C[(size_t)(m0 + e) * ldc + n] = v[e];
+                if (mirror) {
+                    float* dst = Ct + (size_t)n * ldc + m0;
+                    if (m0 + 3 < M && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            if (m0 + e < M) dst[e] = v[e];
+                    }
+                }
+            }
+        }
+}
+
+template <typename T, int NPROD, bool SYM>
+int launch16(skr_ctx* ctx, const T* A, const T* B, float* C, int64_t M, int64_t N, int64_t kt, int64_t ldc, int64_t K,
+             const char* name) {
+    const int64_t tiles_m = (M + TM - 1) / TM, tiles_n = (N + TN - 1) / TN;
+    const int64_t super_m = (tiles_m + 15) / 16, super_n = (tiles_n + 15) / 16;
+    const int64_t grid = super_m * super_n * 256;
+    auto kern = pearson_gemm_split16_kernel<T, NPROD, SYM>;
+    SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * kStageBytes));
+    SkrProfScope prof(ctx, name);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), 2 * kStageBytes, ctx->stream, A, B, C, C, M, N, kt, ldc,
+                       (float)K, tiles_m, tiles_n, super_n);
+    SKR_HIP(hipGetLastError());
+    return SKR_OK;
+}
+
 template <typename T, int NPROD, bool SYM, int WM, int WN>
 int launch(skr_ctx* ctx, const T* A, const T* B, float* C, int64_t M, int64_t N, int64_t kt, int64_t ldc,
            int64_t K, const char* name) {
@@ -266,46 +390,40 @@ int launch(skr_ctx* ctx, const T* A, const T* B, float* C, int64_t M, int64_t N,
 }
 
 template <typename T>
-int gemm_split(skr_ctx* ctx, const skr_mat* a, const skr_mat* b, int nprod, int symmetric, skr_mat* r, int64_t row0,
-               int64_t col0, const char* name) {
-    const int64_t M = a->rows, N = b->rows, K = a->cols;
-    const int64_t kt = (K + 31) / 32;
-    const bool same = a->data == b->data && M == N;
-    const bool sym = symmetric && same;  // mirror is relative to the block's own base pointer
-    // split-interleaved operands in the ctx workspace
-    const size_t a_bytes = (size_t)M * kt * kRowBytes, b_bytes = same ? 0 : (size_t)N * kt * kRowBytes;
-    void* ws = nullptr;
-    SKR_TRY(skr_ctx_workspace(ctx, a_bytes + b_bytes + 256, &ws));
-    T* As = (T*)ws;
-    T* Bs = same ? As : (T*)((char*)ws + ((a_bytes + 255) & ~(size_t)255));
-    auto split = [&](const skr_mat* m, T* dst) -> int {
-        const int64_t total = m->rows * kt * 4;
-        const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, (int64_t)ctx->num_cu * 16));
-        SkrProfScope prof(ctx, "split_halves");
-        hipLaunchKernelGGL(split_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)m->data,
-                           m->rows, m->cols, kt, dst);
-        SKR_HIP(hipGetLastError());
-        return SKR_OK;
-    };
-    SKR_TRY(split(a, As));
-    if (!same) SKR_TRY(split(b, Bs));
-    float* C = (float*)r->data + (size_t)row0 * r->cols + col0;
-    if (nprod == 3) {
-        if (sym) return launch<T, 3, true, 2, 4>(ctx, As, Bs, C, M, N, kt, r->cols, K, name);
-        return launch<T, 3, false, 2, 4>(ctx, As, Bs, C, M, N, kt, r->cols, K, name);
+int gemm_split(skr_ctx* ctx, const T* As, const T* Bs, float* C, int64_t M, int64_t N, int64_t kt, int64_t ldc, int64_t K,
+               int nprod, bool sym, const char* name) {
+    const char* shape_env = getenv("SEEKR_MFMA_SHAPE");  // "32" selects the 32x32x16 kernel (A/B knob)
+    if (!(shape_env && atoi(shape_env) == 32)) {
+        if (nprod == 3) {
+            if (sym) return launch16<T, 3, true>(ctx, As, Bs, C, M, N, kt, ldc, K, name);
+            return launch16<T, 3, false>(ctx, As, Bs, C, M, N, kt, ldc, K, name);
+        }
+        if (sym) return launch16<T, 4, true>(ctx, As, Bs, C, M, N, kt, ldc, K, name);
+        return launch16<T, 4, false>(ctx, As, Bs, C, M, N, kt, ldc, K, name);
     }
-    if (sym) return launch<T, 4, true, 2, 4>(ctx, As, Bs, C, M, N, kt, r->cols, K, name);
-    return launch<T, 4, false, 2, 4>(ctx, As, Bs, C, M, N, kt, r->cols, K, name);
+    if (nprod == 3) {
+        if (sym) return launch<T, 3, true, 2, 4>(ctx, As, Bs, C, M, N, kt, ldc, K, name);
+        return launch<T, 3, false, 2, 4>(ctx, As, Bs, C, M, N, kt, ldc, K, name);
+    }
+    if (sym) return launch<T, 4, true, 2, 4>(ctx, As, Bs, C, M, N, kt, ldc, K, name);
+    return launch<T, 4, false, 2, 4>(ctx, As, Bs, C, M, N, kt, ldc, K, name);
 }
 
 }  // namespace
 
-int skr_pearson_gemm_split(skr_ctx* ctx, const skr_mat* a, const skr_mat* b, int precision, int symmetric, skr_mat* r,
-                           int64_t row0, int64_t col0) {
+// A, B: split-interleaved operands ([rows, kt, {hi,lo}, 32] 16-bit halves) produced by operand.hip
+int skr_launch_gemm_split(skr_ctx* ctx, int precision, const void* As, const void* Bs, float* C, int64_t M, int64_t N,
+                          int64_t kt, int64_t ldc, int64_t K, int sym) {
     switch (precision) {
-        case SKR_PREC_BF16X3: return gemm_split<__bf16>(ctx, a, b, 3, symmetric, r, row0, col0, "pearson_gemm_bf16x3");
-        case SKR_PREC_BF16X4: return gemm_split<__bf16>(ctx, a, b, 4, symmetric, r, row0, col0, "pearson_gemm_bf16x4");
-        case SKR_PREC_F16X3: return gemm_split<_Float16>(ctx, a, b, 3, symmetric, r, row0, col0, "pearson_gemm_f16x3");
+        case SKR_PREC_BF16X3:
+            return gemm_split<__bf16>(ctx, (const __bf16*)As, (const __bf16*)Bs, C, M, N, kt, ldc, K, 3, sym != 0,
+                                      "pearson_gemm_bf16x3");
+        case SKR_PREC_BF16X4:
+            return gemm_split<__bf16>(ctx, (const __bf16*)As, (const __bf16*)Bs, C, M, N, kt, ldc, K, 4, sym != 0,
+                                      "pearson_gemm_bf16x4");
+        case SKR_PREC_F16X3:
+            return gemm_split<_Float16>(ctx, (const _Float16*)As, (const _Float16*)Bs, C, M, N, kt, ldc, K, 3, sym != 0,
+                                        "pearson_gemm_f16x3");
         default: return skr_set_error(SKR_ERR_INVALID, "not a split precision: %d", precision);
     }
 }

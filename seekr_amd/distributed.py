@@ -7,14 +7,15 @@ Counting and the elementwise steps are embarrassingly parallel.  Three steps exc
     the running sums are *passed along the ranks* (rank g continues where g-1 stopped) and the
     finished vector is sent back to everyone — bit-identical to the single-GPU result;
   * the global minimum of Log2.post (kmer_counts.py:208): NaN-propagating all-reduce(min);
-  * Pearson (pearson.py:41): every rank needs every other rank's standardised rows.  The
-    exchange is a sequence of P-1 pairwise shifts (xGMI is point-to-point: each shift uses one
-    link per direction); the GEMM on the shard received in shift s overlaps shift s+1.
+  * Pearson (pearson.py:41): every rank needs every other rank's standardised rows.  They are
+    exchanged as *prepared operands* (already split into 16-bit halves) in P-1 pairwise shifts
+    (xGMI is point-to-point: each shift uses one link per direction); the GEMM on the shard
+    received in shift s overlaps shift s+1.
 
 The orchestration is written against two small interfaces so the same code runs on the HIP
 engine with RCCL (production) and on numpy with gloo (CPU tests of the sharding logic):
 
-  engine: count / colsum / finish / min_nan / apply / row_standardize / gemm / vector I/O
+  engine: colsum / finish / min_nan / apply / prepare / view / gemm
   comm  : rank, size, send_vec, recv_vec, allreduce(values, op), shift(...) -> ticket, wait
 """
 import numpy as np
@@ -35,7 +36,7 @@ def shard_bounds(n_rows, size):
 class HipEngine:
     """The production engine: every op is a kernel launch through libseekr_hip."""
 
-    def __init__(self, ctx, precision=_lib.PREC_FP32, use_symmetry=True):
+    def __init__(self, ctx, precision=_lib.PREC_BF16X3, use_symmetry=True):
         self.ctx = ctx
         self.precision = precision
         self.use_symmetry = use_symmetry  # self-blocks compute one triangle and mirror it
@@ -43,23 +44,14 @@ class HipEngine:
     def zeros_vec(self, n):
         return self.ctx.zeros(1, n)
 
-    def vec_from_host(self, v):
-        return self.ctx.from_numpy(np.asarray(v))
-
-    def vec_to_host(self, v):
-        return v.vector()
-
-    def empty(self, rows, cols):
-        return self.ctx.empty(rows, cols)
+    def cols(self, x):
+        return x.cols
 
     def rows(self, x):
         return x.rows
 
     def view(self, x, row0, nrows):
         return x.view(row0, nrows)
-
-    def cols(self, x):
-        return x.cols
 
     def colsum(self, x, acc, center=None, center2=None, square=False):
         _lib.colsum_seq(self.ctx, x, acc, center, center2, square)
@@ -73,11 +65,18 @@ class HipEngine:
     def apply(self, x, center, scale, post, shift):
         return _lib.apply(self.ctx, x, center=center, scale=scale, post=post, shift=shift, want_nan=scale is not None)[1]
 
-    def row_standardize(self, x, z=None):
-        return _lib.row_standardize(self.ctx, x, z)
+    def empty_operand(self, rows, cols):
+        return _lib.Operand(self.ctx, rows, cols, self.precision)
+
+    def prepare(self, x, center=None, scale=None, post=False, shift=0.0, keep_counts=True, op=None):
+        """Normalisation tail + row standardisation + operand layout in one pass over `x`;
+        the normalised counts overwrite `x` when keep_counts.  Returns (operand, has_nan)."""
+        return _lib.operand_fill(self.ctx, x, op=op, precision=self.precision, center=center, scale=scale, post=post,
+                                 shift=shift, y=x if keep_counts else None, row_standardize=True,
+                                 want_nan=scale is not None)
 
     def gemm(self, a, b, r, col0, symmetric=False):
-        _lib.pearson_gemm(self.ctx, a, b, r, self.precision, symmetric and self.use_symmetry, 0, col0)
+        _lib.pearson_gemm_op(self.ctx, a, b, r, symmetric and self.use_symmetry, 0, col0)
 
 
 class RcclComm:
@@ -95,7 +94,8 @@ class RcclComm:
         return _lib.comm_allreduce(self.ctx, list(values), op)
 
     def shift(self, send, dst, recv, recv_rows, src):
-        return _lib.comm_sendrecv(self.ctx, send, 0, send.rows, dst, recv, 0, recv_rows, src)
+        """send: an Operand (all rows go to dst); recv: an Operand buffer (rows [0, recv_rows) filled from src)."""
+        return _lib.comm_sendrecv(self.ctx, send.as_matrix(), 0, send.rows, dst, recv.as_matrix(), 0, recv_rows, src)
 
     def wait(self, ticket):
         _lib.comm_wait(self.ctx, ticket)
@@ -134,12 +134,11 @@ def _chain_colsum(engine, comm, x, n_cols, center=None, center2=None, square=Fal
     return acc
 
 
-def sharded_normalize(engine, comm, x, n_total, log2="Log2.post", mean=True, std=True):
-    """kmer_counts.py:203-209 on a row shard `x` of a matrix with `n_total` rows, in place.
-
-    `mean` / `std`: True = compute over all ranks, False = skip, else an engine vector to use.
-    (Log2.pre is fused into counting and therefore not handled here.)
-    Returns (mean_vec, std_vec, has_nan)."""
+def sharded_stats(engine, comm, x, n_total, log2="Log2.post", mean=True, std=True):
+    """Everything of kmer_counts.py:203-209 that needs all rows: column mean (:168), the std of
+    the centred matrix (:174) and the Log2.post shift |min| (:208).  `x` (this rank's raw shard)
+    is only read.  `mean` / `std`: True = compute over all ranks, False = skip, else an engine
+    vector to use.  Returns (center, scale, post, shift) for the elementwise tail."""
     n_cols = engine.cols(x)
     center = None
     if mean is True:
@@ -164,20 +163,42 @@ def sharded_normalize(engine, comm, x, n_total, log2="Log2.post", mean=True, std
             gmin = comm.allreduce([float(local_min) if not local_nan else 0.0], "min")[0]
             local_min = np.float32(np.nan) if flag else np.float32(gmin)
         shift = float(np.abs(local_min))  # NaN stays NaN (np.abs(np.min(...)), :208)
+    return center, scale, post, shift
+
+
+def _any_rank(comm, flag):
+    if comm.size > 1:
+        return bool(comm.allreduce([1.0 if flag else 0.0], "max")[0])
+    return bool(flag)
+
+
+def sharded_normalize(engine, comm, x, n_total, log2="Log2.post", mean=True, std=True):
+    """kmer_counts.py:203-209 on a row shard `x` of a matrix with `n_total` rows, in place.
+    (Log2.pre is fused into counting and therefore not handled here.)
+    Returns (mean_vec, std_vec, has_nan)."""
+    center, scale, post, shift = sharded_stats(engine, comm, x, n_total, log2, mean, std)
     has_nan = False
     if center is not None or scale is not None or post:
         has_nan = engine.apply(x, center, scale, post, shift)
-    if comm.size > 1:
-        has_nan = bool(comm.allreduce([1.0 if has_nan else 0.0], "max")[0])
-    return center, scale, has_nan
+    return center, scale, _any_rank(comm, has_nan)
+
+
+def sharded_normalize_prepare(engine, comm, x, n_total, log2="Log2.post", mean=True, std=True, keep_counts=True,
+                              op=None):
+    """sharded_normalize fused with the Pearson preparation: one pass writes the normalised
+    counts (into `x`, when keep_counts) and the row-standardised operand.
+    Returns (mean_vec, std_vec, has_nan, operand)."""
+    center, scale, post, shift = sharded_stats(engine, comm, x, n_total, log2, mean, std)
+    operand, has_nan = engine.prepare(x, center, scale, post, shift, keep_counts=keep_counts, op=op)
+    return center, scale, _any_rank(comm, has_nan), operand
 
 
 def sharded_pearson_rowblock(engine, comm, z, bounds, r, recv_bufs):
     """Row block r[n_g, N] = z_g . Z^T / K of the self-comparison, Z = all ranks' rows.
 
-    `z`: this rank's row-standardised shard; `bounds`: shard_bounds(N, size);
-    `recv_bufs`: two engine matrices with at least max-shard rows (double buffer).
-    Shift s sends our shard to rank+s and receives rank-s's; its GEMM overlaps shift s+1."""
+    `z`: this rank's prepared operand; `bounds`: shard_bounds(N, size); `recv_bufs`: two operand
+    buffers with at least max-shard rows (double buffer).  Shift s sends our shard to rank+s and
+    receives rank-s's; its GEMM overlaps shift s+1."""
     size, rank = comm.size, comm.rank
     tickets = {}
     if size > 1:

@@ -77,6 +77,14 @@ class NumpyEngine:
             return z
         return out
 
+    def empty_operand(self, rows, cols):
+        return np.zeros((rows, cols), dtype=np.float32)
+
+    def prepare(self, x, center=None, scale=None, post=False, shift=0.0, keep_counts=True, op=None):
+        y = x if keep_counts else x.copy()
+        has_nan = self.apply(y, center, scale, post, shift)
+        return self.row_standardize(y, op), has_nan
+
     def gemm(self, a, b, r, col0, symmetric=False):
         r[:, col0:col0 + b.shape[0]] = np.inner(a, b) / a.shape[1]
 
@@ -120,7 +128,7 @@ def run(rank, size, port, n_rows, n_cols, log2, out_dir, with_nan):
     os.environ["MASTER_PORT"] = str(port)
     import torch
     import torch.distributed as dist
-    from seekr_amd.distributed import shard_bounds, sharded_normalize, sharded_pearson_rowblock
+    from seekr_amd.distributed import shard_bounds, sharded_normalize, sharded_normalize_prepare, sharded_pearson_rowblock
 
     dist.init_process_group("gloo", rank=rank, world_size=size)
     try:
@@ -132,8 +140,11 @@ def run(rank, size, port, n_rows, n_cols, log2, out_dir, with_nan):
         lo, hi = bounds[rank], bounds[rank + 1]
         x = full[lo:hi].copy()
         engine, comm = NumpyEngine(), GlooComm(dist, torch)
-        mean, std, has_nan = sharded_normalize(engine, comm, x, n_rows, log2, True, True)
-        z = engine.row_standardize(x)
+        if rank % 2 == 0 or size == 2:  # both entry points must agree: fused on some ranks ...
+            mean, std, has_nan, z = sharded_normalize_prepare(engine, comm, x, n_rows, log2, True, True)
+        else:  # ... separate normalise + standardise on the others
+            mean, std, has_nan = sharded_normalize(engine, comm, x, n_rows, log2, True, True)
+            z = engine.row_standardize(x)
         r = np.zeros((hi - lo, n_rows), dtype=np.float32)
         max_shard = max(bounds[g + 1] - bounds[g] for g in range(size))
         recv = [np.zeros((max_shard, n_cols), np.float32), np.zeros((max_shard, n_cols), np.float32)]

@@ -483,6 +483,83 @@ def test_cfg2_full_size_properties(L, ctx):
     assert np.allclose(r[:512, :700], orc.pearson(xs[:512], xs[:700]), rtol=RTOL, atol=ATOL_R)
 
 
+# ------------------------------------------------------------------ fused operand preparation
+@pytest.mark.parametrize("cols", [16, 100, 1024, 4096])
+def test_operand_fill_equals_separate_kernels(cols, L, ctx):
+    """skr_operand_fill (normalisation tail + row standardisation + operand layout in one pass)
+    must give the normalised counts of skr_apply bit for bit and the r of the unfused path."""
+    rng = np.random.default_rng(cols)
+    x = (rng.binomial(30, 0.1, size=(257, cols)) * np.float32(1000 / 1995)).astype(np.float32)
+    x[:, 0] += 0.25
+    _, mean, std = orc.normalize(x, log2="Log2.none")
+    dmean, dstd = ctx.from_numpy(mean), ctx.from_numpy(std)
+    for post in (False, True):
+        shift = 0.0
+        if post:
+            shift = float(np.abs(L.min_nan(ctx, ctx.from_numpy(x), dmean, dstd)[0]))
+        ref_y = ctx.from_numpy(x)
+        L.apply(ctx, ref_y, center=dmean, scale=dstd, post=post, shift=shift)
+        for prec in ("fp32", "bf16x3", "f16x3"):
+            y = ctx.from_numpy(x)
+            op, has_nan = L.operand_fill(ctx, y, precision=L.PRECISIONS[prec], center=dmean, scale=dstd, post=post,
+                                         shift=shift, y=y, row_standardize=True, want_nan=True)
+            assert not has_nan
+            assert_bits(y.to_numpy(), ref_y.to_numpy(), "fused counts cols=%d post=%s" % (cols, post))
+            r = ctx.empty(257, 257)
+            L.pearson_gemm_op(ctx, op, op, r, symmetric=True)
+            want = L.pearson(ctx, ref_y, ref_y, precision=L.PRECISIONS[prec]).to_numpy()
+            assert np.array_equal(r.to_numpy(), want)
+            assert np.allclose(want, orc.pearson(ref_y.to_numpy(), ref_y.to_numpy()), rtol=RTOL, atol=ATOL_R)
+    # NaN reporting: a zero-variance column divides 0 by 0
+    x[:, 3] = 1.0
+    _, mean, std = orc.normalize(x, log2="Log2.none")
+    y = ctx.from_numpy(x)
+    _, has_nan = L.operand_fill(ctx, y, center=ctx.from_numpy(mean), scale=ctx.from_numpy(std), y=y, want_nan=True)
+    assert has_nan and np.isnan(y.to_numpy()[:, 3]).all()
+
+
+# ------------------------------------------------------------------ RCCL plumbing on one rank
+def test_rccl_single_rank_plumbing(L):
+    """A 1-rank communicator exercises librccl loading, init, the ticketed send/recv to self on
+    the communication stream, the compute-stream wait and the host all-reduce (the N>1 schedule
+    itself is covered by the gloo tests; 8-GPU runs are the driver's)."""
+    ctx = L.Context(0)
+    L.comm_init(ctx, 1, 0, L.comm_unique_id())
+    try:
+        assert L.comm_allreduce(ctx, [3.5, -1.0], "max") == [3.5, -1.0]
+        assert L.comm_allreduce(ctx, [2.0], "sum") == [2.0]
+        L.comm_barrier(ctx)
+        src = ctx.from_numpy(np.arange(6 * 64, dtype=np.float32).reshape(6, 64))
+        dst = ctx.zeros(8, 64)
+        t = L.comm_sendrecv(ctx, src, 1, 4, 0, dst, 2, 4, 0)  # rows 1..4 -> rows 2..5 of dst
+        L.comm_wait(ctx, t)
+        got = dst.to_numpy()
+        assert np.array_equal(got[2:6], src.to_numpy()[1:5]) and not got[:2].any() and not got[6:].any()
+        from seekr_amd.distributed import (HipEngine, RcclComm, shard_bounds, sharded_normalize_prepare,
+                                           sharded_pearson_rowblock)
+        x = (np.random.default_rng(0).binomial(50, 0.05, size=(300, 1024)) * np.float32(2.5)).astype(np.float32)
+        ref, mref, sref = orc.normalize(x, log2="Log2.post")
+        for prec in (L.PREC_FP32, L.PREC_BF16X3):
+            dev = ctx.from_numpy(x)
+            eng, comm = HipEngine(ctx, prec), RcclComm(ctx, 0, 1)
+            mean, std, has_nan, z = sharded_normalize_prepare(eng, comm, dev, 300, "Log2.post", True, True)
+            assert_bits(mean.vector(), mref, "mean via RcclComm")
+            assert_bits(std.vector(), sref, "std via RcclComm")
+            assert not has_nan and np.allclose(dev.to_numpy(), ref, rtol=RTOL, atol=2e-6)
+            # operand storage round trip through the send/recv path (what a peer GPU would receive)
+            buf = eng.empty_operand(320, 1024)
+            t = comm.shift(z, 0, buf, 300, 0)
+            comm.wait(t)
+            r = ctx.empty(300, 300)
+            eng.gemm(z, eng.view(buf, 0, 300), r, 0)
+            assert np.allclose(r.to_numpy(), orc.pearson(ref, ref), rtol=RTOL, atol=ATOL_R)
+            r2 = ctx.empty(300, 300)
+            sharded_pearson_rowblock(eng, comm, z, shard_bounds(300, 1), r2, [None, None])
+            assert np.allclose(r2.to_numpy(), r.to_numpy(), rtol=1e-6, atol=2e-7)
+    finally:
+        ctx.close()
+
+
 # ------------------------------------------------------------------ split-bf16 MFMA path
 @pytest.mark.parametrize("prec", ["bf16x3", "bf16x4", "f16x3"])
 @pytest.mark.parametrize("shape", [(5, 7, 16), (130, 257, 64), (300, 200, 100), (640, 515, 4096), (1000, 1000, 1024)])
@@ -507,9 +584,9 @@ def test_pearson_split_bf16_vs_oracle(prec, shape, L, ctx):
     rs = L.pearson(ctx, da, da, precision=L.PRECISIONS[prec]).to_numpy()
     assert np.array_equal(rs, rs.T)
     assert np.allclose(rs, orc.pearson(a, a), rtol=RTOL, atol=ATOL_R)
-    z = L.row_standardize(ctx, da)
+    op, _ = L.operand_fill(ctx, da, precision=L.PRECISIONS[prec], row_standardize=True)
     full = ctx.empty(m, m)
-    L.pearson_gemm(ctx, z, z, full, L.PRECISIONS[prec], symmetric=False)
+    L.pearson_gemm_op(ctx, op, op, full, symmetric=False)
     full = full.to_numpy()
     # computing both triangles gives the upper one bit for bit; the lower differs only in the
     # order the hi*lo and lo*hi cross terms enter the float32 accumulator
