@@ -339,11 +339,8 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
                         if (n > m) Ct[(size_t)n * ldc + m] = v[e];
                     }
                 }
-            } else if (n < N) {
-#pragma unroll
-                for (int e = 0; e < 4; e++)
-                    if (m0 + e < M) C[(size_t)(m0 + e) * ldc + n] = v[e];
-                if (mirror) {
+            } else {
+                if (mirror && n < N) {  // r[n, m0..m0+3]: the lane's 4 rows are contiguous in the mirror
                     float* dst = Ct + (size_t)n * ldc + m0;
                     if (m0 + 3 < M && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
                         *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
@@ -351,6 +348,33 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
 #pragma unroll
                         for (int e = 0; e < 4; e++)
                             if (m0 + e < M) dst[e] = v[e];
+                    }
+                }
+                // direct tile: transpose 4x4 inside each quad of lanes (lane j of a quad ends up with
+                // row m0+j, columns c0..c0+3) so it is written with 16-byte stores too — the epilogue
+                // is store-issue bound and this quarters its instruction count
+                const int j = lane & 3;
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    const float send = (j & 1) ? v[e] : v[e + 1];
+                    const float recv = __shfl_xor(send, 1, 64);
+                    if (j & 1) v[e] = recv; else v[e + 1] = recv;
+                }
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const float send = (j & 2) ? v[e] : v[e + 2];
+                    const float recv = __shfl_xor(send, 2, 64);
+                    if (j & 2) v[e] = recv; else v[e + 2] = recv;
+                }
+                const int64_t mrow = m0 + j, ncol = n - j;
+                float* dst = C + (size_t)mrow * ldc + ncol;
+                if (mrow < M) {
+                    if (ncol + 3 < N && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            if (ncol + e < N) dst[e] = v[e];
                     }
                 }
             }
