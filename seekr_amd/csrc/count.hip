@@ -50,88 +50,110 @@ __global__ __launch_bounds__(kThreads) void count_kmers_kernel(
     const uint32_t idx_mask = nbins - 1u;
     const uint32_t win_mask = (1u << k) - 1u;  // k consecutive validity bits
 
-    for (int64_t seq = blockIdx.x; seq < n_seqs; seq += gridDim.x) {
-        // ---- zero the histogram (16 B per lane per step)
-        for (uint32_t b = tid * 4; b < nbins; b += kThreads * 4) {
-            if (nbins >= 4) {
-                *reinterpret_cast<uint4*>(&hist[b]) = make_uint4(0, 0, 0, 0);
-            } else {
-                hist[b] = 0;  // k == 0 is rejected on the host; nbins >= 4 always
+    // 16 windows that start in one packed word: bins of a 64-bit pair, runs of equal bins merged
+    auto count_word = [&](uint32_t hi, uint32_t lo, uint32_t invalid, int lim) {
+        const unsigned long long pair = ((unsigned long long)hi << 32) | lo;
+        uint32_t run_idx = 0xFFFFFFFFu, run_len = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if (j < lim && ((invalid >> j) & win_mask) == 0) {
+                const uint32_t idx = (uint32_t)(pair >> (64 - 2 * j - 2 * k)) & idx_mask;
+                if (idx == run_idx) {
+                    run_len++;
+                } else {
+                    if (run_len) atomicAdd(&hist[run_idx], run_len);
+                    run_idx = idx;
+                    run_len = 1;
+                }
             }
         }
-        __syncthreads();
+        if (run_len) atomicAdd(&hist[run_idx], run_len);
+    };
 
-        const int64_t L = len[seq];
+    // The words of the NEXT sequence (first sweep: 4096 bases) are fetched while the current one
+    // is flushed, so the HBM latency of the tiny input never sits on a workgroup's critical path.
+    // The loads are unconditional (indices clamped into the padded arrays): a branch around them
+    // would make hipcc drain vmcnt(0) at the join.
+    int64_t nL = 0, n_woff = 0, n_moff = -1;
+    uint32_t n_hi = 0, n_lo = 0, n_m0 = 0, n_m1 = 0;
+    auto prefetch = [&](int64_t s) {
+        s = s < n_seqs ? s : n_seqs - 1;
+        nL = len[s];
+        n_woff = word_off[s];
+        n_moff = mask_off[s];
+        const int64_t W = nL - k + 1;
+        const int64_t nww = W > 0 ? (W + 15) >> 4 : 0;
+        const int64_t w = tid < nww ? tid : nww;
+        n_hi = packed[n_woff + w];
+        n_lo = packed[n_woff + w + 1];
+        const int64_t mb = n_moff >= 0 ? n_moff + (w >> 1) : 0;
+        n_m0 = mask[mb];
+        n_m1 = mask[mb + 1];
+    };
+
+    for (uint32_t b = tid * 4; b < nbins; b += kThreads * 4) *reinterpret_cast<uint4*>(&hist[b]) = make_uint4(0, 0, 0, 0);
+    prefetch(blockIdx.x);
+    __syncthreads();
+
+    for (int64_t seq = blockIdx.x; seq < n_seqs; seq += gridDim.x) {
+        const int64_t L = nL, woff = n_woff, moff = n_moff;
+        const uint32_t c_hi = n_hi, c_lo = n_lo, c_m0 = n_m0, c_m1 = n_m1;
         const int64_t W = L - k + 1;  // windows, counting every character (kmer_counts.py:143-144)
         if (W == 0 && tid == 0) atomicOr(&flags[2], 1u);  // ZeroDivisionError in the reference
-        if (W > 0) {
-            const uint32_t* words = packed + word_off[seq];
-            const int64_t moff = mask_off[seq];
-            const uint32_t* mwords = moff >= 0 ? mask + moff : nullptr;
-            const int64_t n_win_words = (W + 15) >> 4;
-            for (int64_t w = tid; w < n_win_words; w += kThreads) {
-                const uint32_t hi = words[w];
-                const uint32_t lo = words[w + 1];  // pad word keeps this in bounds
-                const unsigned long long pair = ((unsigned long long)hi << 32) | lo;
-                uint32_t invalid = 0;  // bit j: base 16w+j is not in the alphabet
-                if (mwords) {
-                    const int64_t mw = w >> 1;
-                    const unsigned long long mpair =
-                        (unsigned long long)mwords[mw] | ((unsigned long long)mwords[mw + 1] << 32);
-                    invalid = (uint32_t)(mpair >> ((w & 1) * 16));
-                }
-                const int64_t first = w << 4;
-                const int lim = (int)((W - first) < 16 ? (W - first) : 16);
-                uint32_t run_idx = 0xFFFFFFFFu, run_len = 0;
-#pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    if (j < lim) {
-                        const bool ok = ((invalid >> j) & win_mask) == 0;
-                        if (ok) {
-                            const uint32_t idx = (uint32_t)(pair >> (64 - 2 * j - 2 * k)) & idx_mask;
-                            if (idx == run_idx) {
-                                run_len++;
-                            } else {
-                                if (run_len) atomicAdd(&hist[run_idx], run_len);
-                                run_idx = idx;
-                                run_len = 1;
-                            }
-                        }
-                    }
-                }
-                if (run_len) atomicAdd(&hist[run_idx], run_len);
-            }
+        const int64_t n_win_words = W > 0 ? (W + 15) >> 4 : 0;
+        if (tid < n_win_words) {  // first sweep from the prefetched registers
+            uint32_t invalid = 0;  // bit j: base 16w+j is not in the alphabet
+            if (moff >= 0)
+                invalid = (uint32_t)(((unsigned long long)c_m0 | ((unsigned long long)c_m1 << 32)) >> ((tid & 1) * 16));
+            const int64_t left = W - ((int64_t)tid << 4);
+            count_word(c_hi, c_lo, invalid, (int)(left < 16 ? left : 16));
         }
+        for (int64_t w = tid + kThreads; w < n_win_words; w += kThreads) {  // sequences longer than 4096 bases
+            const uint32_t* words = packed + woff;
+            uint32_t invalid = 0;
+            if (moff >= 0) {
+                const uint32_t* mwords = mask + moff;
+                const int64_t mw = w >> 1;
+                invalid = (uint32_t)(((unsigned long long)mwords[mw] | ((unsigned long long)mwords[mw + 1] << 32)) >>
+                                     ((w & 1) * 16));
+            }
+            const int64_t left = W - (w << 4);
+            count_word(words[w], words[w + 1], invalid, (int)(left < 16 ? left : 16));
+        }
+        prefetch(seq + gridDim.x);  // in flight across the barrier and the flush
         __syncthreads();
 
-        // ---- flush: bins -> per-kb values, dense row to HBM
+        // ---- flush: bins -> per-kb values, dense row to HBM; the bins are zeroed on the way out
         const double inc = W > 0 ? 1000.0 / (double)W : 0.0;
-        if (OUT == OUT_U32) {
-            uint32_t* row = reinterpret_cast<uint32_t*>(out) + (size_t)seq * nbins;
-            for (uint32_t b = tid * 4; b < nbins; b += kThreads * 4)
-                *reinterpret_cast<uint4*>(&row[b]) = *reinterpret_cast<const uint4*>(&hist[b]);
-        } else if (OUT == OUT_F64) {
+        if (OUT == OUT_F64) {
             double* row = reinterpret_cast<double*>(out) + (size_t)seq * nbins;
-            for (uint32_t b = tid; b < nbins; b += kThreads) row[b] = per_kb_value_f64(hist[b], inc);
+            for (uint32_t b = tid; b < nbins; b += kThreads) {
+                row[b] = per_kb_value_f64(hist[b], inc);
+                hist[b] = 0;
+            }
         } else {
-            float* row = reinterpret_cast<float*>(out) + (size_t)seq * nbins;
             for (uint32_t b = tid * 4; b < nbins; b += kThreads * 4) {
                 const uint4 c = *reinterpret_cast<const uint4*>(&hist[b]);
-                float4 v;
-                v.x = per_kb_value(c.x, inc);
-                v.y = per_kb_value(c.y, inc);
-                v.z = per_kb_value(c.z, inc);
-                v.w = per_kb_value(c.w, inc);
-                if (OUT == OUT_F32_LOG2) {  // kmer_counts.py:189-192: counts += 1; log2
-                    v.x = skr_log2_cr(v.x + 1.0f);
-                    v.y = skr_log2_cr(v.y + 1.0f);
-                    v.z = skr_log2_cr(v.z + 1.0f);
-                    v.w = skr_log2_cr(v.w + 1.0f);
+                *reinterpret_cast<uint4*>(&hist[b]) = make_uint4(0, 0, 0, 0);
+                if (OUT == OUT_U32) {
+                    *reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(out) + (size_t)seq * nbins + b) = c;
+                } else {
+                    float4 v;
+                    v.x = per_kb_value(c.x, inc);
+                    v.y = per_kb_value(c.y, inc);
+                    v.z = per_kb_value(c.z, inc);
+                    v.w = per_kb_value(c.w, inc);
+                    if (OUT == OUT_F32_LOG2) {  // kmer_counts.py:189-192: counts += 1; log2
+                        v.x = skr_log2_cr(v.x + 1.0f);
+                        v.y = skr_log2_cr(v.y + 1.0f);
+                        v.z = skr_log2_cr(v.z + 1.0f);
+                        v.w = skr_log2_cr(v.w + 1.0f);
+                    }
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)seq * nbins + b) = v;
                 }
-                *reinterpret_cast<float4*>(&row[b]) = v;
             }
         }
-        __syncthreads();  // the histogram is reused by the next sequence
+        __syncthreads();  // zeroed bins visible before the next sequence is counted
     }
 }
 

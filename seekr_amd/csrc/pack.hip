@@ -113,7 +113,8 @@ int upload_seqs(skr_ctx* ctx, const std::vector<SeqView>& seqs, const Lut& lut, 
             mask_words += (len[s] + 31) / 32 + 1;
         }
     }
-    std::vector<uint32_t> packed((size_t)word_off[n] + 1, 0), mask((size_t)mask_words + 1, 0);
+    // +2: the counting kernel prefetches word w+1 / mask word mw+1 unconditionally
+    std::vector<uint32_t> packed((size_t)word_off[n] + 2, 0), mask((size_t)mask_words + 2, 0);
     {
         std::vector<std::thread> th;
         for (int t = 0; t < nthreads; t++)
