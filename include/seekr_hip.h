@@ -191,6 +191,20 @@ int skr_pearson_gemm_op(skr_ctx* ctx, const skr_operand* a, const skr_operand* b
 int skr_pearson(skr_ctx* ctx, const skr_mat* counts1, const skr_mat* counts2, int row_standardize,
                 int precision, skr_mat* r);
 
+/* ---------------------------------------------------------------- consumers of r -------- */
+/* In place: r[r < cutoff] = 0 (NaN stays), then the diagonal r[i, i + diag_col0] = 0
+ * (kmer_leiden.py:94-96; diag_col0 places the diagonal inside a row block).                 */
+int skr_threshold_zero_diag(skr_ctx* ctx, skr_mat* r, float cutoff, int64_t diag_col0);
+/* out = r[np.triu_indices(n, k)] for a square float32 r (find_dist.py:163 uses k = 1);
+ * out holds (n-k)(n-k+1)/2 values.                                                           */
+int skr_triu_flatten(skr_ctx* ctx, const skr_mat* r, int64_t k, skr_mat* out);
+/* out_host[i] = src.flat[idx_host[i]] — the device side of np.random.choice(values, size,
+ * replace=False) (find_dist.py:169): the host draws the indices with numpy's generator.     */
+int skr_gather_f32(skr_ctx* ctx, const skr_mat* src, const int64_t* idx_host, int64_t n, float* out_host);
+/* p[i,j] = float32(count(bg > r[i,j]) / total_len) (find_pval.py:158-164); sorted_bg: the
+ * background values ascending with NaNs removed, total_len: len(fitres) including NaNs.    */
+int skr_empirical_pvalues(skr_ctx* ctx, const skr_mat* r, const skr_mat* sorted_bg, int64_t total_len, skr_mat* p);
+
 /* ---------------------------------------------------------------- multi-GPU (C1, C2) ---- */
 /* One process per GPU.  Rank 0 creates an id and distributes the 128 bytes out of band.    */
 int skr_comm_unique_id(char id[128]);

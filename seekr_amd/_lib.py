@@ -70,6 +70,10 @@ SIGNATURES = {
     "skr_operand_as_mat": (_int, [_p, C.POINTER(_p)]),
     "skr_operand_fill": (_int, [_p, _p, _p, _p, _int, C.c_float, _p, _int, _p, C.POINTER(_int)]),
     "skr_pearson_gemm_op": (_int, [_p, _p, _p, _int, _p, _i64, _i64]),
+    "skr_threshold_zero_diag": (_int, [_p, _p, C.c_float, _i64]),
+    "skr_triu_flatten": (_int, [_p, _p, _i64, _p]),
+    "skr_gather_f32": (_int, [_p, _p, _p, _i64, _p]),
+    "skr_empirical_pvalues": (_int, [_p, _p, _p, _i64, _p]),
     "skr_comm_unique_id": (_int, [C.c_char_p]),
     "skr_comm_init": (_int, [_p, _int, _int, C.c_char_p]),
     "skr_comm_destroy": (_int, [_p]),

@@ -518,6 +518,30 @@ def test_operand_fill_equals_separate_kernels(cols, L, ctx):
     assert has_nan and np.isnan(y.to_numpy()[:, 3]).all()
 
 
+# ------------------------------------------------------------------ k = 7 (config 5 geometry)
+def test_k7_pipeline_16384_columns(L, ctx):
+    """k=7: 64 KiB LDS histogram per sequence, 16 384 columns through normalisation, the operand
+    fill (one wave per workgroup at this width) and every contraction mode."""
+    from seekr_amd.pearson import pearson
+    seqs = orc.codes_to_seqs(orc.synthetic_codes(5, 300, 5000)) + ["ACGTN" * 900, "G" * 4000]
+    c = run(seqs, k=7, log2="Log2.none", mean=True, std=False)
+    raw = orc.raw_counts(seqs, 7)
+    ref, mean, _ = orc.normalize(raw, mean=True, std=False, log2="Log2.none")
+    assert c.counts.shape == (302, 16384)
+    assert_bits(c.mean, mean, "k=7 mean")
+    assert_bits(c.counts, ref, "k=7 centred counts")
+    want = orc.pearson(ref, ref)
+    for prec in ("fp32", "bf16x3", "f16x3"):
+        d = ctx.from_numpy(ref)
+        got = L.pearson(ctx, d, d, precision=L.PRECISIONS[prec]).to_numpy()
+        assert np.allclose(got, want, rtol=RTOL, atol=ATOL_R), (prec, np.abs(got - want).max())
+    assert np.allclose(pearson(ref, ref[:100]), want[:, :100], rtol=RTOL, atol=ATOL_R)
+    with pytest.raises(NotImplementedError):
+        run(seqs[:3], k=8, mean=False, std=False, log2="Log2.none")
+    with pytest.raises(NotImplementedError):
+        run(seqs[:3], k=3, mean=False, std=False, log2="Log2.none", alphabet="ACGTN")
+
+
 # ------------------------------------------------------------------ RCCL plumbing on one rank
 def test_rccl_single_rank_plumbing(L):
     """A 1-rank communicator exercises librccl loading, init, the ticketed send/recv to self on
