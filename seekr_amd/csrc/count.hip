@@ -2,19 +2,22 @@
 // per-kb scaling fused into the histogram flush (kmer_counts.py:140-151, 194-202).
 //
 // One 256-thread workgroup owns one sequence at a time (persistent grid-stride loop over the
-// sequences).  Thread t of a sweep takes the 16 windows that start inside packed word
-// w = sweep*256 + t: it loads words w and w+1 (consecutive lanes -> consecutive words, fully
-// coalesced), and every window's column index is a bit-field of that 64-bit pair because the
-// packer stores the first base in the top bits.  Counts go to a 4^k-bin uint32 histogram in
-// LDS (16 KiB at k=6, 64 KiB at k=7) with ds_add_u32; runs of equal indices inside a thread
-// (homopolymers) are merged before the atomic.  The flush converts bins to the reference's
-// float32 per-kb values and streams the dense row to HBM as 16-byte stores — the row write
-// (4*4^k bytes per sequence) is the algorithmic traffic that bounds this kernel.
+// sequences, 8 workgroups per CU at k=6).  Two threads share a packed word: thread t of a sweep
+// takes 8 of the 16 windows that start inside word w = sweep*128 + t/2; it holds words w and w+1
+// (consecutive lanes -> consecutive words, coalesced; prefetched one sequence ahead), and every
+// window's column index is a bit-field of that 64-bit pair because the packer stores the first
+// base in the top bits.  Counts go to a 4^k-bin uint32 histogram in LDS (16 KiB at k=6, 64 KiB
+// at k=7) with ds_add_u32; runs of equal indices inside a thread (homopolymers) are merged
+// before the atomic.  The flush converts bins to the reference's float32 per-kb values (a
+// 16-entry per-sequence table covers almost every bin), zeroes them for the next sequence, and
+// streams the dense row to HBM as 16-byte stores — the row write (4*4^k bytes per sequence) is
+// the algorithmic traffic that bounds this kernel.  Two barriers per sequence.
 #include "common.hpp"
 
 namespace {
 
 constexpr int kThreads = 256;
+constexpr int kTabSize = 16;  // counts below this are looked up per sequence instead of recomputed
 
 // float32( n sequential float64 additions of `inc` ) — what kmer_counts.py:144-150 stores.
 // n*inc (one rounding) equals the sequential sum unless the product sits within the
@@ -45,17 +48,21 @@ __global__ __launch_bounds__(kThreads) void count_kmers_kernel(
     const uint32_t* __restrict__ mask, const int64_t* __restrict__ mask_off, int64_t n_seqs, int k, void* __restrict__ out,
     uint32_t* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    __shared__ float tab[kTabSize];  // 64 bytes: keeps the dynamic region 16-byte aligned
     const int tid = threadIdx.x;
     const uint32_t nbins = 1u << (2 * k);
     const uint32_t idx_mask = nbins - 1u;
     const uint32_t win_mask = (1u << k) - 1u;  // k consecutive validity bits
 
-    // 16 windows that start in one packed word: bins of a 64-bit pair, runs of equal bins merged
-    auto count_word = [&](uint32_t hi, uint32_t lo, uint32_t invalid, int lim) {
+    // 8 windows that start in one half of a packed word (windows j0 .. j0+7 of the word): bins of a
+    // 64-bit pair, runs of equal bins merged.  Two threads share a word, so all 256 threads of the
+    // workgroup count a 2 kb sequence in one sweep.
+    auto count_word = [&](uint32_t hi, uint32_t lo, uint32_t invalid, int j0, int lim) {
         const unsigned long long pair = ((unsigned long long)hi << 32) | lo;
         uint32_t run_idx = 0xFFFFFFFFu, run_len = 0;
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
+        for (int jj = 0; jj < 8; jj++) {
+            const int j = j0 + jj;
             if (j < lim && ((invalid >> j) & win_mask) == 0) {
                 const uint32_t idx = (uint32_t)(pair >> (64 - 2 * j - 2 * k)) & idx_mask;
                 if (idx == run_idx) {
@@ -83,7 +90,7 @@ __global__ __launch_bounds__(kThreads) void count_kmers_kernel(
         n_moff = mask_off[s];
         const int64_t W = nL - k + 1;
         const int64_t nww = W > 0 ? (W + 15) >> 4 : 0;
-        const int64_t w = tid < nww ? tid : nww;
+        const int64_t w = (tid >> 1) < nww ? (tid >> 1) : nww;
         n_hi = packed[n_woff + w];
         n_lo = packed[n_woff + w + 1];
         const int64_t mb = n_moff >= 0 ? n_moff + (w >> 1) : 0;
@@ -101,14 +108,24 @@ __global__ __launch_bounds__(kThreads) void count_kmers_kernel(
         const int64_t W = L - k + 1;  // windows, counting every character (kmer_counts.py:143-144)
         if (W == 0 && tid == 0) atomicOr(&flags[2], 1u);  // ZeroDivisionError in the reference
         const int64_t n_win_words = W > 0 ? (W + 15) >> 4 : 0;
-        if (tid < n_win_words) {  // first sweep from the prefetched registers
+        // the sequence's output value for every small count (almost all bins): 16 threads do the
+        // float64 work once, the flush just looks it up (visible after the barrier below)
+        const double inc = W > 0 ? 1000.0 / (double)W : 0.0;
+        if (OUT != OUT_U32 && OUT != OUT_F64 && tid < kTabSize) {
+            float t = per_kb_value((uint32_t)tid, inc);
+            if (OUT == OUT_F32_LOG2) t = skr_log2_cr(t + 1.0f);  // kmer_counts.py:189-192: counts += 1; log2
+            tab[tid] = t;
+        }
+        const int j0 = (tid & 1) * 8;  // which half of the word's 16 windows this thread takes
+        if ((tid >> 1) < n_win_words) {  // first sweep (2048 bases) from the prefetched registers
+            const int64_t w = tid >> 1;
             uint32_t invalid = 0;  // bit j: base 16w+j is not in the alphabet
             if (moff >= 0)
-                invalid = (uint32_t)(((unsigned long long)c_m0 | ((unsigned long long)c_m1 << 32)) >> ((tid & 1) * 16));
-            const int64_t left = W - ((int64_t)tid << 4);
-            count_word(c_hi, c_lo, invalid, (int)(left < 16 ? left : 16));
+                invalid = (uint32_t)(((unsigned long long)c_m0 | ((unsigned long long)c_m1 << 32)) >> ((w & 1) * 16));
+            const int64_t left = W - (w << 4);
+            count_word(c_hi, c_lo, invalid, j0, (int)(left < 16 ? left : 16));
         }
-        for (int64_t w = tid + kThreads; w < n_win_words; w += kThreads) {  // sequences longer than 4096 bases
+        for (int64_t w = (tid + kThreads) >> 1; w < n_win_words; w += kThreads / 2) {  // longer sequences
             const uint32_t* words = packed + woff;
             uint32_t invalid = 0;
             if (moff >= 0) {
@@ -118,13 +135,18 @@ __global__ __launch_bounds__(kThreads) void count_kmers_kernel(
                                      ((w & 1) * 16));
             }
             const int64_t left = W - (w << 4);
-            count_word(words[w], words[w + 1], invalid, (int)(left < 16 ? left : 16));
+            count_word(words[w], words[w + 1], invalid, j0, (int)(left < 16 ? left : 16));
         }
         prefetch(seq + gridDim.x);  // in flight across the barrier and the flush
         __syncthreads();
 
         // ---- flush: bins -> per-kb values, dense row to HBM; the bins are zeroed on the way out
-        const double inc = W > 0 ? 1000.0 / (double)W : 0.0;
+        auto value_of = [&](uint32_t n) -> float {
+            if (n < (uint32_t)kTabSize) return tab[n];
+            float t = per_kb_value(n, inc);
+            if (OUT == OUT_F32_LOG2) t = skr_log2_cr(t + 1.0f);
+            return t;
+        };
         if (OUT == OUT_F64) {
             double* row = reinterpret_cast<double*>(out) + (size_t)seq * nbins;
             for (uint32_t b = tid; b < nbins; b += kThreads) {
@@ -139,16 +161,10 @@ __global__ __launch_bounds__(kThreads) void count_kmers_kernel(
                     *reinterpret_cast<uint4*>(reinterpret_cast<uint32_t*>(out) + (size_t)seq * nbins + b) = c;
                 } else {
                     float4 v;
-                    v.x = per_kb_value(c.x, inc);
-                    v.y = per_kb_value(c.y, inc);
-                    v.z = per_kb_value(c.z, inc);
-                    v.w = per_kb_value(c.w, inc);
-                    if (OUT == OUT_F32_LOG2) {  // kmer_counts.py:189-192: counts += 1; log2
-                        v.x = skr_log2_cr(v.x + 1.0f);
-                        v.y = skr_log2_cr(v.y + 1.0f);
-                        v.z = skr_log2_cr(v.z + 1.0f);
-                        v.w = skr_log2_cr(v.w + 1.0f);
-                    }
+                    v.x = value_of(c.x);
+                    v.y = value_of(c.y);
+                    v.z = value_of(c.z);
+                    v.w = value_of(c.w);
                     *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)seq * nbins + b) = v;
                 }
             }
