@@ -126,6 +126,95 @@ __global__ __launch_bounds__(256) void operand_fill_kernel(FillArgs a) {
     if (any_nan) atomicOr(&a.flags[1], 1u);
 }
 
+// Register-resident variant for K = VPL * 256 columns (k = 5: VPL 4, k = 6: VPL 16): a wave keeps
+// its whole row in VPL float4 registers per lane — all loads of a row are in flight together, no
+// LDS, no barrier, ~100 VGPRs so 20 waves per CU stay resident.  Lane l owns columns
+// 256 i + 4 l .. +3, so its halves go out as 8-byte pieces (8 lanes fill the 64-byte hi part of a
+// 32-k tile; the lo store fills the other half of the same 128-byte line).
+template <typename T>
+using vec4h = T __attribute__((ext_vector_type(4)));
+
+// MODE 0: rows as they are; 1: float32 center + scale; 2: center + scale + Log2.post tail.
+// (Compile-time modes: with the runtime ck/sk/post switches of fill_tail inside the unrolled
+// row hipcc unswitches the loop into many copies and spills.)
+template <typename T, int VPL, int MODE>
+__global__ __launch_bounds__(256) void operand_fill_reg_kernel(FillArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    constexpr int64_t K = (int64_t)VPL * 256;
+    bool any_nan = false;
+    for (int64_t r = (int64_t)blockIdx.x * waves + wave; r < a.rows; r += (int64_t)gridDim.x * waves) {
+        const float* xr = a.x + (size_t)r * K;
+        float4 v[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; i++) v[i] = *reinterpret_cast<const float4*>(xr + i * 256 + lane * 4);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; i++) {
+            const int64_t c = i * 256 + lane * 4;
+            if (MODE >= 1) {
+                const float4 m = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.center) + c);
+                const float4 d = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.scale) + c);
+                v[i].x = __fdiv_rn(__fsub_rn(v[i].x, m.x), d.x);
+                v[i].y = __fdiv_rn(__fsub_rn(v[i].y, m.y), d.y);
+                v[i].z = __fdiv_rn(__fsub_rn(v[i].z, m.z), d.z);
+                v[i].w = __fdiv_rn(__fsub_rn(v[i].w, m.w), d.w);
+                any_nan |= (v[i].x != v[i].x) | (v[i].y != v[i].y) | (v[i].z != v[i].z) | (v[i].w != v[i].w);
+                if (MODE == 2) {
+                    v[i].x = skr_log2_fast(__fadd_rn(__fadd_rn(v[i].x, a.shift), 1.0f));
+                    v[i].y = skr_log2_fast(__fadd_rn(__fadd_rn(v[i].y, a.shift), 1.0f));
+                    v[i].z = skr_log2_fast(__fadd_rn(__fadd_rn(v[i].z, a.shift), 1.0f));
+                    v[i].w = skr_log2_fast(__fadd_rn(__fadd_rn(v[i].w, a.shift), 1.0f));
+                }
+                if (a.y) *reinterpret_cast<float4*>(a.y + (size_t)r * K + c) = v[i];
+            }
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+        if (a.row_standardize) {  // statistics in the order pearson.py:35-38 computes them
+            const float kf = (float)K;
+            const float mean = wave_sum(s) / kf;
+            s = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPL; i++) {
+                v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+                s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            }
+            const float m2 = wave_sum(s) / kf;
+            s = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPL; i++) {
+                const float dx = v[i].x - m2, dy = v[i].y - m2, dz = v[i].z - m2, dw = v[i].w - m2;
+                s += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+            const float sd = sqrtf(wave_sum(s) / kf);
+#pragma unroll
+            for (int i = 0; i < VPL; i++) {
+                v[i].x /= sd; v[i].y /= sd; v[i].z /= sd; v[i].w /= sd;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VPL; i++) {
+            const int64_t c = i * 256 + lane * 4;
+            if (sizeof(T) == 4) {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + (size_t)r * K + c) = v[i];
+            } else {
+                const float z[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+                vec4h<T> hi, lo;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const T hh = (T)z[j];
+                    hi[j] = hh;
+                    lo[j] = (T)(z[j] - (float)hh);
+                }
+                T* dst = reinterpret_cast<T*>(a.out) + ((size_t)r * a.kt + (c >> 5)) * 64 + (c & 31);
+                *reinterpret_cast<vec4h<T>*>(dst) = hi;
+                *reinterpret_cast<vec4h<T>*>(dst + 32) = lo;
+            }
+        }
+    }
+    if (any_nan) atomicOr(&a.flags[1], 1u);
+}
+
 int vec_kind(const skr_mat* v, int64_t cols, const char* what, int* kind) {
     *kind = 0;
     if (!v) return SKR_OK;
@@ -254,9 +343,34 @@ extern "C" int skr_operand_fill(skr_ctx* ctx, const skr_mat* x, const skr_mat* c
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / lds));
     const int64_t want = (x->rows + waves - 1) / waves;
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cu * per_cu));
-    {
+    // 4^6 / 4^5 columns with the usual vectors (float32 mean/std computed on the device, or none):
+    // the row fits the register file
+    int reg_mode = -1;
+    if (a.ck == 0 && a.sk == 0 && !a.post && !a.y) reg_mode = 0;
+    else if (a.ck == 1 && a.sk == 1) reg_mode = a.post ? 2 : 1;
+    if ((x->cols == 4096 || x->cols == 1024) && reg_mode >= 0) {
+        const unsigned rgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((x->rows + 3) / 4, (int64_t)ctx->num_cu * 5));
         SkrProfScope prof(ctx, "operand_fill");
-#define LAUNCH(T)                                                                                             \
+#define LAUNCH_REG2(T, V)                                                                                              \
+    do {                                                                                                               \
+        if (reg_mode == 0) hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 0>), dim3(rgrid), dim3(256), 0, ctx->stream, a);      \
+        else if (reg_mode == 1) hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 1>), dim3(rgrid), dim3(256), 0, ctx->stream, a); \
+        else hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 2>), dim3(rgrid), dim3(256), 0, ctx->stream, a);                    \
+    } while (0)
+#define LAUNCH_REG(T)                           \
+    do {                                        \
+        if (x->cols == 4096) LAUNCH_REG2(T, 16); \
+        else LAUNCH_REG2(T, 4);                  \
+    } while (0)
+        if (op->kind == 0) LAUNCH_REG(float);
+        else if (op->kind == 1) LAUNCH_REG(__bf16);
+        else LAUNCH_REG(_Float16);
+#undef LAUNCH_REG
+#undef LAUNCH_REG2
+        SKR_HIP(hipGetLastError());
+    } else {
+        SkrProfScope prof(ctx, "operand_fill");
+#define LAUNCH(T)                                                                                         \
     do {                                                                                                      \
         SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(operand_fill_kernel<T>),                    \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
