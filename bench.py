@@ -7,9 +7,15 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" is one pass of that pipeline over one synthetic transcript set whose packed bases
-are already resident in HBM; the correlation row block stays in HBM.  Work per GPU is fixed in
+are already resident in HBM; the correlation matrix stays in HBM.  Work per GPU is fixed in
 the metric's unit (ordered sequence pairs): N_rows(G) = 50 000 * sqrt(G), so G=1 is
 BASELINE.json configs[1] (50k x 2 kb, k=6) and scaling is weak.  Rank 0 prints one JSON line.
+
+On G > 1 GPUs the default result layout is the symmetric one (seekr_amd/distributed.py): each
+unordered pair of row shards is multiplied once, by one of its two ranks, which keeps the
+block and its transpose; every ordered pair ends up in exactly one GPU's HBM, as on one GPU
+(where the lower triangle is the mirror of the upper).  `--layout rowblock` gives every rank
+its full rows of r instead, multiplying each off-diagonal block twice across the node.
 """
 import argparse
 import json
@@ -24,7 +30,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from seekr_amd import _lib, launch  # noqa: E402
-from seekr_amd.distributed import HipEngine, shard_bounds, sharded_normalize_prepare, sharded_pearson_rowblock  # noqa: E402
+from seekr_amd.distributed import (HipEngine, half_ring_plan, shard_bounds, sharded_normalize_prepare,  # noqa: E402
+                                   sharded_pearson_rowblock, sharded_pearson_symmetric)
 from seekr_amd.synthetic import synthetic_ascii, synthetic_codes  # noqa: E402
 
 PEAK = {"hbm_gbs": 8000.0, "fp32_mfma_tflops": 157.3, "bf16_mfma_tflops": 2500.0}  # MI355X_MICROARCH.md
@@ -39,13 +46,15 @@ def parse():
     ap.add_argument("--rows", type=int, default=0, help="total transcripts (default 50000*sqrt(gpus))")
     ap.add_argument("--length", type=int, default=2000)
     ap.add_argument("-k", type=int, default=6)
-    ap.add_argument("--precision", default=os.environ.get("SEEKR_PRECISION", "bf16x3"),
+    ap.add_argument("--precision", default=os.environ.get("SEEKR_PRECISION", "f16x3"),
                     choices=["fp32", "bf16x3", "bf16x4", "f16x3"],
                     help="Pearson contraction arithmetic; every choice is inside the parity bar "
-                         "|dr| <= 2e-6 + 1e-5|r| (tests/test_gpu_parity.py), bf16x3 is the fastest")
+                         "|dr| <= 2e-6 + 1e-5|r| (tests/test_gpu_parity.py) on the bench data; f16x3 carries float32-grade operands, bf16x3 is ~5 % faster")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-symmetry", action="store_true",
                     help="compute both triangles of the self-comparison block instead of mirroring one")
+    ap.add_argument("--layout", default="symmetric", choices=["symmetric", "rowblock"],
+                    help="multi-GPU result layout (see module docstring); fp32 / --no-symmetry imply rowblock")
     return ap.parse_args()
 
 
@@ -94,7 +103,9 @@ def main():
     del blob
     x = ctx.empty(n_loc, n_cols)
     z = engine.empty_operand(n_loc, n_cols)  # row-standardised shard in the contraction's operand layout
-    r = ctx.empty(n_loc, n_total)
+    symmetric_layout = args.layout == "symmetric" and args.precision != "fp32" and not args.no_symmetry
+    r = ctx.zeros(n_loc, n_total)
+    r_col = ctx.zeros(n_total, n_loc) if (symmetric_layout and size > 1) else None  # mirrored blocks (h, g)
     max_shard = max(bounds[g + 1] - bounds[g] for g in range(size))
     recv = [engine.empty_operand(max_shard, n_cols), engine.empty_operand(max_shard, n_cols)] if size > 1 else [None, None]
 
@@ -102,7 +113,10 @@ def main():
         _lib.count_per_kb(ctx, packed, k, out=x)
         # column statistics (rank-chained), then ONE pass: normalised counts -> x, standardised rows -> z
         sharded_normalize_prepare(engine, comm, x, n_total, "Log2.post", True, True, keep_counts=True, op=z)
-        sharded_pearson_rowblock(engine, comm, z, bounds, r, recv)
+        if symmetric_layout:
+            sharded_pearson_symmetric(engine, comm, z, bounds, r, r_col, recv)
+        else:
+            sharded_pearson_rowblock(engine, comm, z, bounds, r, recv)
 
     for _ in range(args.warmup):
         step()
@@ -139,7 +153,11 @@ def main():
     # multiplies are ~half of the pairs it delivers; both figures are reported.
     sym = (not args.no_symmetry) and args.precision != "fp32"
     tile = 128 if args.precision == "fp32" else 256
-    exec_pairs = (n_loc * (n_loc + tile) / 2.0 if sym else float(n_loc) * n_loc) + float(n_loc) * (n_total - n_loc)
+    exec_pairs = n_loc * (n_loc + tile) / 2.0 if sym else float(n_loc) * n_loc
+    if symmetric_layout:
+        exec_pairs += sum(float(an) * bn for _, _, _, an, _, bn in half_ring_plan(size, rank, bounds))
+    else:
+        exec_pairs += float(n_loc) * (n_total - n_loc)
     gemm_ms_step = gemm["ms_total"] / steps
     gemm_avg_ms = gemm["ms_total"] / max(gemm["launches"], 1)
     achieved_tf = 2.0 * n_cols * exec_pairs / (gemm_ms_step * 1e-3) / 1e12 if gemm_ms_step > 0 else 0.0
@@ -152,7 +170,7 @@ def main():
                 "mfma_executed_frac": round(achieved_tf * nprod / peak_tf, 4),
                 "pairs_multiplied_per_step": exec_pairs, "pairs_delivered_per_step": float(n_loc) * n_total,
                 "note": "achieved = 2*4^k flop x pairs multiplied / kernel time (HIP events, summed over the "
-                        "step's launches); split-bf16 issues {} bf16 MFMA products per algorithmic product; "
+                        "step's launches); the split path issues {} 16-bit MFMA products per algorithmic product; "
                         "symmetric self block: {}".format(nprod, sym)}
     # counting kernel: HBM bound, 0.25 B/base packed in + 4*4^k B per sequence out
     count_avg_ms = count["ms_total"] / max(count["launches"], 1)
@@ -170,11 +188,14 @@ def main():
         "n_gpus": size, "steps": steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.precision == "fp32" else "{} split-bf16 products, f32 accumulate".format(nprod), "data": "synthetic",
+        "dtype": "f32" if args.precision == "fp32" else "f32 as {} split-{} MFMA products, f32 accumulate".format(
+            nprod, "fp16" if args.precision == "f16x3" else "bf16"),
+        "data": "synthetic",
         "config": {"workload": "{} synthetic {} nt transcripts, k={}, counts + Log2.post normalisation + "
                                "self Pearson ({} x {} r matrix, row-sharded)".format(n_total, length, k, n_total, n_total),
                    "rows_total": n_total, "rows_per_gpu": n_loc, "length": length, "k": k,
-                   "precision": args.precision, "sharding": "rows x{}".format(size)},
+                   "precision": args.precision, "sharding": "rows x{}".format(size),
+                   "layout": "symmetric half-ring: each ordered pair on one GPU" if symmetric_layout else "row blocks"},
         "mbases_per_s_counted": round(mbases * size, 1),
         "pearson_kernel_mpairs_per_s": round(pairs_per_step / (gemm_ms_step * 1e-3) / 1e6, 1) if gemm_ms_step > 0 else None,
         "roofline": roofline, "roofline_count": roofline_count,

@@ -187,6 +187,12 @@ int skr_operand_fill(skr_ctx* ctx, const skr_mat* x, const skr_mat* center, cons
 /* r[row0 + i, col0 + j] = <a_i, b_j> / K on prepared operands (same meaning as skr_pearson_gemm) */
 int skr_pearson_gemm_op(skr_ctx* ctx, const skr_operand* a, const skr_operand* b, int symmetric, skr_mat* r,
                         int64_t row0, int64_t col0);
+/* As skr_pearson_gemm_op without the symmetric shortcut, and additionally the transposed block
+ * rt[trow0 + j, tcol0 + i] = r[row0 + i, col0 + j].  r(b, a) = r(a, b)^T (np.inner is
+ * symmetric in its arguments, pearson.py:41), so a rank that multiplied shard a by shard b
+ * produces both blocks from one contraction.  The two blocks must not overlap.              */
+int skr_pearson_gemm_op_mirror(skr_ctx* ctx, const skr_operand* a, const skr_operand* b, skr_mat* r, int64_t row0,
+                               int64_t col0, skr_mat* rt, int64_t trow0, int64_t tcol0);
 /* pearson(counts1, counts2, row_standardize) end to end on device matrices                 */
 int skr_pearson(skr_ctx* ctx, const skr_mat* counts1, const skr_mat* counts2, int row_standardize,
                 int precision, skr_mat* r);

@@ -70,6 +70,7 @@ SIGNATURES = {
     "skr_operand_as_mat": (_int, [_p, C.POINTER(_p)]),
     "skr_operand_fill": (_int, [_p, _p, _p, _p, _int, C.c_float, _p, _int, _p, C.POINTER(_int)]),
     "skr_pearson_gemm_op": (_int, [_p, _p, _p, _int, _p, _i64, _i64]),
+    "skr_pearson_gemm_op_mirror": (_int, [_p, _p, _p, _p, _i64, _i64, _p, _i64, _i64]),
     "skr_threshold_zero_diag": (_int, [_p, _p, C.c_float, _i64]),
     "skr_triu_flatten": (_int, [_p, _p, _i64, _p]),
     "skr_gather_f32": (_int, [_p, _p, _p, _i64, _p]),
@@ -292,7 +293,7 @@ class Matrix:
 class Operand:
     """Rows prepared for the Pearson contraction (skr_operand)."""
 
-    def __init__(self, ctx, rows, cols, precision=PREC_BF16X3, _view_of=None, _row0=0):
+    def __init__(self, ctx, rows, cols, precision=PREC_F16X3, _view_of=None, _row0=0):
         self.ctx, self.rows, self.cols, self.precision = ctx, int(rows), int(cols), int(precision)
         self._h = _p()
         self._parent = _view_of
@@ -464,7 +465,7 @@ def pearson_gemm(ctx, a, b, r, precision=PREC_FP32, symmetric=False, row0=0, col
     return r
 
 
-def operand_fill(ctx, x, op=None, precision=PREC_BF16X3, center=None, scale=None, post=False, shift=0.0, y=None,
+def operand_fill(ctx, x, op=None, precision=PREC_F16X3, center=None, scale=None, post=False, shift=0.0, y=None,
                  row_standardize=True, want_nan=False):
     """Fused normalisation tail + row standardisation + operand layout; returns (op, has_nan)."""
     op = Operand(ctx, x.rows, x.cols, precision) if op is None else op
@@ -476,6 +477,12 @@ def operand_fill(ctx, x, op=None, precision=PREC_BF16X3, center=None, scale=None
 
 def pearson_gemm_op(ctx, a, b, r, symmetric=False, row0=0, col0=0):
     check(lib().skr_pearson_gemm_op(ctx._h, a._h, b._h, 1 if symmetric else 0, r._h, int(row0), int(col0)))
+    return r
+
+
+def pearson_gemm_op_mirror(ctx, a, b, r, row0, col0, rt, trow0, tcol0):
+    """r[row0+i, col0+j] = <a_i, b_j>/K and rt[trow0+j, tcol0+i] = the same value."""
+    check(lib().skr_pearson_gemm_op_mirror(ctx._h, a._h, b._h, r._h, int(row0), int(col0), rt._h, int(trow0), int(tcol0)))
     return r
 
 

@@ -409,7 +409,41 @@ extern "C" int skr_pearson_gemm_op(skr_ctx* ctx, const skr_operand* a, const skr
         return skr_launch_gemm_f32(ctx, (const float*)a->data, (const float*)b->data, C, M, N, Kp, Kp, Kp, r->cols, K);
     }
     const bool sym = symmetric && a->data == b->data && M == N;
-    return skr_launch_gemm_split(ctx, a->precision, a->data, b->data, C, M, N, a->kt, r->cols, K, sym);
+    return skr_launch_gemm_split(ctx, a->precision, a->data, b->data, C, M, N, a->kt, r->cols, K, sym ? 1 : 0, nullptr, 0);
+}
+
+extern "C" int skr_pearson_gemm_op_mirror(skr_ctx* ctx, const skr_operand* a, const skr_operand* b, skr_mat* r,
+                                          int64_t row0, int64_t col0, skr_mat* rt, int64_t trow0, int64_t tcol0) {
+    SKR_REQUIRE(ctx && a && b && r && rt, "NULL argument");
+    SKR_REQUIRE(a->ctx == ctx && b->ctx == ctx && r->ctx == ctx && rt->ctx == ctx, "handle belongs to a different ctx");
+    SKR_REQUIRE(a->cols == b->cols && a->kind == b->kind && a->precision == b->precision,
+                "operands were prepared for different shapes or precisions");
+    SKR_REQUIRE(r->dtype == SKR_F32 && rt->dtype == SKR_F32, "result matrices must be float32");
+    SKR_REQUIRE(row0 >= 0 && col0 >= 0 && row0 + a->rows <= r->rows && col0 + b->rows <= r->cols,
+                "result block [%lld+%lld, %lld+%lld] outside [%lld, %lld]", (long long)row0, (long long)a->rows,
+                (long long)col0, (long long)b->rows, (long long)r->rows, (long long)r->cols);
+    SKR_REQUIRE(trow0 >= 0 && tcol0 >= 0 && trow0 + b->rows <= rt->rows && tcol0 + a->rows <= rt->cols,
+                "mirror block [%lld+%lld, %lld+%lld] outside [%lld, %lld]", (long long)trow0, (long long)b->rows,
+                (long long)tcol0, (long long)a->rows, (long long)rt->rows, (long long)rt->cols);
+    SKR_TRY(skr_activate(ctx));
+    const int64_t M = a->rows, N = b->rows, K = a->cols;
+    if (M == 0 || N == 0) return SKR_OK;
+    float* C = (float*)r->data + (size_t)row0 * r->cols + col0;
+    float* Ct = (float*)rt->data + (size_t)trow0 * rt->cols + tcol0;
+    {   // the two blocks must not overlap (same matrix is fine as long as the blocks are disjoint)
+        const bool same = r->data == rt->data;
+        const bool rows_apart = row0 + M <= trow0 || trow0 + N <= row0;
+        const bool cols_apart = col0 + N <= tcol0 || tcol0 + M <= col0;
+        SKR_REQUIRE(!same || rows_apart || cols_apart, "block and mirror block overlap");
+    }
+    if (a->kind == 0) {
+        // float32 operands: a_i . b_j and b_j . a_i accumulate the same products in the same k
+        // order, so a second contraction gives the bit-identical transposed block
+        const int64_t Kp = a->kt * 32;
+        SKR_TRY(skr_launch_gemm_f32(ctx, (const float*)a->data, (const float*)b->data, C, M, N, Kp, Kp, Kp, r->cols, K));
+        return skr_launch_gemm_f32(ctx, (const float*)b->data, (const float*)a->data, Ct, N, M, Kp, Kp, Kp, rt->cols, K);
+    }
+    return skr_launch_gemm_split(ctx, a->precision, a->data, b->data, C, M, N, a->kt, r->cols, K, 2, Ct, rt->cols);
 }
 
 // ---- matrix-level entry points built on operands ------------------------------------------------

@@ -4,19 +4,25 @@
 // r = sum_k z1 z2 is then accumulated in float32 from NPROD bf16 products per k:
 //     NPROD = 3 : hi*hi + hi*lo + lo*hi            (|error| <= ~3e-6 on r ~ 1, ~2e-7 rms elsewhere)
 //     NPROD = 4 : ... + lo*lo                      (error ~4e-7 = what float32 BLAS gives)
-// on v_mfma_f32_32x32x16_bf16, which runs 16x the f32-input MFMA rate; a single bf16 product
-// (2.7e-4) is nowhere near the 1e-5 parity bar.
+// on v_mfma_f32_16x16x32_bf16 / _f16, which run 16x the f32-input MFMA rate; a single bf16
+// product (2.7e-4) is nowhere near the 1e-5 parity bar.
 //
-// Operand layout ("split-interleaved", produced by split_bf16_kernel): for every row and every
+// Operand layout ("split-interleaved", produced by operand.hip): for every row and every
 // 32-wide k tile, 32 hi values followed by 32 lo values — one 128-byte line — so that staging a
 // k tile of a row is one full cache line and a 1-KiB LDS-DMA piece covers 8 rows.
 //
 // Geometry: block tile 256 x 256, BK = 32, LDS 2 stages x (256+256) rows x 128 B = 128 KiB, one
-// workgroup per CU; 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 (4 x 2 MFMA tiles, 128
-// accumulator registers, 184 VGPRs), two waves per SIMD cover each other's LDS waits.  Per 16-k
-// step a wave issues 12 ds_read_b128 and 8*NPROD MFMAs.
+// workgroup per CU; 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 (8 x 4 MFMA tiles of 16 x 16,
+// 128 accumulator registers), two waves per SIMD cover each other's LDS waits.  Per 32-k tile a
+// wave issues 24 ds_read_b128 and 32*NPROD MFMAs of 16 cycles.  (The 32x32x16 shape has the same
+// LDS bytes per flop but the chip holds a lower clock on it: -13 % measured; see
+// MI355X_MICROARCH.md, DVFS give-back.)
 // The LDS image is lane-linear (LDS-DMA), so the bank swizzle chunk ^= (row >> 1) & 7 is applied
 // on the source address and again on the read (same involution), as in the fp32 kernel.
+//
+// Output modes: PLAIN writes C; SELF (a == b) computes the tiles on and above the diagonal and
+// mirrors them into the same matrix; CROSS writes C and the transposed block into a second
+// matrix Ct — r(h,g) = r(g,h)^T costs stores, not a second contraction (distributed half-ring).
 #include <algorithm>
 #include <cstdlib>
 
@@ -27,18 +33,9 @@ namespace {
 constexpr int TM = 256, TN = 256;
 constexpr int kRowBytes = 128;                       // one k tile of one row: 32 hi + 32 lo bf16
 constexpr int kStageBytes = (TM + TN) * kRowBytes;   // 64 KiB
+enum { PLAIN = 0, SELF = 1, CROSS = 2 };
 template <typename T>
 using vec8 = T __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-// T = __bf16 (8-bit significand halves) or _Float16 (11-bit halves: hi + lo carry 22 bits, so the
-// three-product sum is float32-grade; |z| <= sqrt(K) << 65504 and fp16 subnormals are kept)
-__device__ __forceinline__ f32x16 mfma16(vec8<__bf16> a, vec8<__bf16> b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x16 mfma16(vec8<_Float16> a, vec8<_Float16> b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
 
 __device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -60,169 +57,9 @@ __device__ __forceinline__ bool tile_of_block(int64_t bid, int64_t super_n, int6
     return *tm < tiles_m && *tn < tiles_n;
 }
 
-template <typename T, int NPROD, int MT, int NT>
-__device__ __forceinline__ void mma_step(f32x16 (&acc)[MT][NT], const vec8<T> (&ahi)[MT], const vec8<T> (&alo)[MT],
-                                         const vec8<T> (&bhi)[NT], const vec8<T> (&blo)[NT]) {
-#pragma unroll
-    for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) {
-            if (NPROD >= 4) acc[mt][nt] = mfma16(alo[mt], blo[nt], acc[mt][nt]);
-            acc[mt][nt] = mfma16(alo[mt], bhi[nt], acc[mt][nt]);
-            acc[mt][nt] = mfma16(ahi[mt], blo[nt], acc[mt][nt]);
-            acc[mt][nt] = mfma16(ahi[mt], bhi[nt], acc[mt][nt]);
-        }
-}
-
-// WM x WN waves; each wave owns (256/WM) x (256/WN) of the block tile.
-template <typename T, int NPROD, bool SYM, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN) / 4) void pearson_gemm_bf16s_kernel(
-    const T* __restrict__ A, const T* __restrict__ B, float* __restrict__ C, float* __restrict__ Ct,
-    int64_t M, int64_t N, int64_t kt, int64_t ldc, float kdiv, int64_t tiles_m, int64_t tiles_n, int64_t super_n) {
-    constexpr int NW = WM * WN;
-    constexpr int MT = TM / WM / 32, NT = TN / WN / 32;
-    constexpr int PP = 32 / NW;  // 1-KiB pieces per wave per operand per stage
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int64_t tm, tn;
-    if (!tile_of_block(blockIdx.x, super_n, tiles_m, tiles_n, &tm, &tn)) return;
-    if (SYM && tn < tm) return;  // the mirror block writes this tile
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int64_t row_base = tm * TM, col_base = tn * TN;
-    const int64_t pitch = kt * 64;  // bf16 elements per row
-
-    // ---- staging: wave w moves pieces PP*w .. PP*w+PP-1 (8 rows each) of the A tile and of the B tile
-    const T* a_src[PP];
-    const T* b_src[PP];
-#pragma unroll
-    for (int p = 0; p < PP; p++) {
-        const int row = (wave * PP + p) * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        const int64_t ra = std::min<int64_t>(row_base + row, M - 1);
-        const int64_t rb = std::min<int64_t>(col_base + row, N - 1);
-        a_src[p] = A + (size_t)ra * pitch + chunk * 8;
-        b_src[p] = B + (size_t)rb * pitch + chunk * 8;
-    }
-    auto stage = [&](int buf, int64_t tile) {
-        char* abase = smem + buf * kStageBytes;
-        char* bbase = abase + TM * kRowBytes;
-#pragma unroll
-        for (int p = 0; p < PP; p++) {
-            lds_dma16(a_src[p] + tile * 64, abase + (wave * PP + p) * 1024);
-            lds_dma16(b_src[p] + tile * 64, bbase + (wave * PP + p) * 1024);
-        }
-    };
-
-    // ---- fragment addresses
-    const int h = lane >> 5;
-    int a_off[MT], a_swz[MT], b_off[NT], b_swz[NT];
-#pragma unroll
-    for (int t = 0; t < MT; t++) {
-        const int ra = wm * (TM / WM) + t * 32 + (lane & 31);
-        a_off[t] = ra * kRowBytes;
-        a_swz[t] = (ra >> 1) & 7;
-    }
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
-        const int rb = wn * (TN / WN) + t * 32 + (lane & 31);
-        b_off[t] = TM * kRowBytes + rb * kRowBytes;
-        b_swz[t] = (rb >> 1) & 7;
-    }
-    auto load_frags = [&](int buf, int s, vec8<T> (&ahi)[MT], vec8<T> (&alo)[MT], vec8<T> (&bhi)[NT], vec8<T> (&blo)[NT]) {
-        const char* base = smem + buf * kStageBytes;
-        const int c_hi = 2 * s + h, c_lo = 4 + 2 * s + h;  // 16-byte chunk of the 128-byte row
-#pragma unroll
-        for (int t = 0; t < MT; t++) {
-            ahi[t] = *reinterpret_cast<const vec8<T>*>(base + a_off[t] + ((c_hi ^ a_swz[t]) << 4));
-            alo[t] = *reinterpret_cast<const vec8<T>*>(base + a_off[t] + ((c_lo ^ a_swz[t]) << 4));
-        }
-#pragma unroll
-        for (int t = 0; t < NT; t++) {
-            bhi[t] = *reinterpret_cast<const vec8<T>*>(base + b_off[t] + ((c_hi ^ b_swz[t]) << 4));
-            blo[t] = *reinterpret_cast<const vec8<T>*>(base + b_off[t] + ((c_lo ^ b_swz[t]) << 4));
-        }
-    };
-
-    f32x16 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; i++)
-#pragma unroll
-        for (int j = 0; j < NT; j++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
-
-    // Two LDS stages: tile t+1 streams in by LDS-DMA while tile t is consumed; one barrier per
-    // k tile (its vmcnt(0) drain costs nothing: the fill was issued a whole iteration earlier).
-    // hipcc sinks the last 16 MFMAs of an iteration below the barrier, which covers the first
-    // fragment reads of the next tile.  (Measured alternatives that did not pay on gfx950: an
-    // explicit two-deep fragment pipeline at 248 VGPRs, -1 %; 4 waves x 128x128 with 256
-    // accumulator registers: hipcc spills the accumulators across the loop back-edge, 8x slower.)
-    int cur = 0;
-    stage(0, 0);
-    __syncthreads();  // vmcnt(0) drain of the LDS-DMA + barrier
-    for (int64_t t = 0; t < kt; t++) {
-        if (t + 1 < kt) stage(cur ^ 1, t + 1);
-#pragma unroll
-        for (int s = 0; s < 2; s++) {
-            vec8<T> ahi[MT], alo[MT], bhi[NT], blo[NT];
-            load_frags(cur, s, ahi, alo, bhi, blo);
-            mma_step<T, NPROD, MT, NT>(acc, ahi, alo, bhi, blo);
-        }
-        __syncthreads();
-        cur ^= 1;
-    }
-
-    // ---- epilogue.  C/D layout: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 h
-    const bool mirror = SYM && tm != tn;
-#pragma unroll
-    for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) {
-            const int64_t n = col_base + wn * (TN / WN) + nt * 32 + (lane & 31);
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int64_t m0 = row_base + wm * (TM / WM) + mt * 32 + 8 * g + 4 * h;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = acc[mt][nt][4 * g + e] / kdiv;
-                if (SYM && tm == tn) {
-                    // diagonal tile: hi*lo and lo*hi enter the accumulator in a different order for
-                    // (i,j) and (j,i); keep the upper element and mirror it so r is exactly symmetric
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const int64_t m = m0 + e;
-                        if (n < N && m < M && n >= m) {
-                            C[(size_t)m * ldc + n] = v[e];
-                            if (n > m) Ct[(size_t)n * ldc + m] = v[e];
-                        }
-                    }
-                } else if (n < N) {
-#pragma unroll
-                    for (int e = 0; e < 4; e++)
-                        if (m0 + e < M) C[(size_t)(m0 + e) * ldc + n] = v[e];
-                    if (mirror) {  // r[n, m0..m0+3] = r[m0..m0+3, n]: 16 contiguous bytes per lane
-                        float* dst = Ct + (size_t)n * ldc + m0;
-                        if (m0 + 3 < M && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
-                            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; e++)
-                                if (m0 + e < M) dst[e] = v[e];
-                        }
-                    }
-                }
-            }
-        }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Same contraction on the 16x16x32 MFMA shape.  Identical block tile, staging, LDS image, swizzle,
-// accumulator count (8 x 4 tiles x 4 regs = 128) and LDS bytes per flop; per 32-k tile a wave
-// issues 24 ds_read_b128 and 32*NPROD MFMAs of 16 cycles.  The chip holds a higher clock on this
-// shape under load (MI355X_MICROARCH.md, DVFS give-back item 7), which is the only reason to
-// prefer it.  Lane l holds A[row l&15][k = 8(l>>4)+j] / B likewise; D: col = l&15, row = 4(l>>4)+e.
-// ---------------------------------------------------------------------------------------------
+// T = __bf16 (8-bit significand halves) or _Float16 (11-bit halves: hi + lo carry 22 bits, so the
+// three-product sum is float32-grade; |z| <= sqrt(K) << 65504 and fp16 subnormals are kept).
+// Lane l holds A[row l&15][k = 8(l>>4)+j] / B likewise; D: col = l&15, row = 4(l>>4)+e.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4v mfma16x16(vec8<__bf16> a, vec8<__bf16> b, f32x4v c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
@@ -231,15 +68,17 @@ __device__ __forceinline__ f32x4v mfma16x16(vec8<_Float16> a, vec8<_Float16> b, 
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-template <typename T, int NPROD, bool SYM>
+template <typename T, int NPROD, int MODE>
 __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
     const T* __restrict__ A, const T* __restrict__ B, float* __restrict__ C, float* __restrict__ Ct,
-    int64_t M, int64_t N, int64_t kt, int64_t ldc, float kdiv, int64_t tiles_m, int64_t tiles_n, int64_t super_n) {
+    int64_t M, int64_t N, int64_t kt, int64_t ldc, int64_t ldct, float kdiv, int64_t tiles_m, int64_t tiles_n,
+    int64_t super_n) {
     constexpr int WN = 4, MT = 8, NT = 4, PP = 4;  // 8 waves as 2 x 4, wave tile 128 x 64
+    constexpr bool SYM = MODE == SELF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int64_t tm, tn;
     if (!tile_of_block(blockIdx.x, super_n, tiles_m, tiles_n, &tm, &tn)) return;
-    if (SYM && tn < tm) return;
+    if (SYM && tn < tm) return;  // the mirror block writes this tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -320,7 +159,7 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
         cur ^= 1;
     }
 
-    const bool mirror = SYM && tm != tn;
+    const bool mirror = MODE == CROSS || (SYM && tm != tn);
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
@@ -331,17 +170,19 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
 #pragma unroll
             for (int e = 0; e < 4; e++) v[e] = acc[mt][nt][e] / kdiv;
             if (SYM && tm == tn) {
+                // diagonal tile: hi*lo and lo*hi enter the accumulator in a different order for
+                // (i,j) and (j,i); keep the upper element and mirror it so r is exactly symmetric
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const int64_t m = m0 + e;
                     if (n < N && m < M && n >= m) {
                         C[(size_t)m * ldc + n] = v[e];
-                        if (n > m) Ct[(size_t)n * ldc + m] = v[e];
+                        if (n > m) Ct[(size_t)n * ldct + m] = v[e];
                     }
                 }
             } else {
                 if (mirror && n < N) {  // r[n, m0..m0+3]: the lane's 4 rows are contiguous in the mirror
-                    float* dst = Ct + (size_t)n * ldc + m0;
+                    float* dst = Ct + (size_t)n * ldct + m0;
                     if (m0 + 3 < M && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
                         *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                     } else {
@@ -381,73 +222,57 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
         }
 }
 
-template <typename T, int NPROD, bool SYM>
-int launch16(skr_ctx* ctx, const T* A, const T* B, float* C, int64_t M, int64_t N, int64_t kt, int64_t ldc, int64_t K,
+struct SplitOut {
+    float* C;
+    int64_t ldc;
+    float* Ct;   // SELF: == C; CROSS: the matrix receiving the transposed block; PLAIN: unused
+    int64_t ldct;
+};
+
+template <typename T, int NPROD, int MODE>
+int launch16(skr_ctx* ctx, const T* A, const T* B, const SplitOut& o, int64_t M, int64_t N, int64_t kt, int64_t K,
              const char* name) {
     const int64_t tiles_m = (M + TM - 1) / TM, tiles_n = (N + TN - 1) / TN;
     const int64_t super_m = (tiles_m + 15) / 16, super_n = (tiles_n + 15) / 16;
     const int64_t grid = super_m * super_n * 256;
-    auto kern = pearson_gemm_split16_kernel<T, NPROD, SYM>;
+    auto kern = pearson_gemm_split16_kernel<T, NPROD, MODE>;
     SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 2 * kStageBytes));
     SkrProfScope prof(ctx, name);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), 2 * kStageBytes, ctx->stream, A, B, C, C, M, N, kt, ldc,
-                       (float)K, tiles_m, tiles_n, super_n);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), 2 * kStageBytes, ctx->stream, A, B, o.C, o.Ct, M, N, kt,
+                       o.ldc, o.ldct, (float)K, tiles_m, tiles_n, super_n);
     SKR_HIP(hipGetLastError());
     return SKR_OK;
 }
 
-template <typename T, int NPROD, bool SYM, int WM, int WN>
-int launch(skr_ctx* ctx, const T* A, const T* B, float* C, int64_t M, int64_t N, int64_t kt, int64_t ldc,
-           int64_t K, const char* name) {
-    const int64_t tiles_m = (M + TM - 1) / TM, tiles_n = (N + TN - 1) / TN;
-    const int64_t super_m = (tiles_m + 15) / 16, super_n = (tiles_n + 15) / 16;
-    const int64_t grid = super_m * super_n * 256;
-    auto kern = pearson_gemm_bf16s_kernel<T, NPROD, SYM, WM, WN>;
-    SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                2 * kStageBytes));
-    SkrProfScope prof(ctx, name);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WM * WN * 64), 2 * kStageBytes, ctx->stream, A, B, C, C, M, N,
-                       kt, ldc, (float)K, tiles_m, tiles_n, super_n);
-    SKR_HIP(hipGetLastError());
-    return SKR_OK;
-}
-
-template <typename T>
-int gemm_split(skr_ctx* ctx, const T* As, const T* Bs, float* C, int64_t M, int64_t N, int64_t kt, int64_t ldc, int64_t K,
-               int nprod, bool sym, const char* name) {
-    const char* shape_env = getenv("SEEKR_MFMA_SHAPE");  // "32" selects the 32x32x16 kernel (A/B knob)
-    if (!(shape_env && atoi(shape_env) == 32)) {
-        if (nprod == 3) {
-            if (sym) return launch16<T, 3, true>(ctx, As, Bs, C, M, N, kt, ldc, K, name);
-            return launch16<T, 3, false>(ctx, As, Bs, C, M, N, kt, ldc, K, name);
-        }
-        if (sym) return launch16<T, 4, true>(ctx, As, Bs, C, M, N, kt, ldc, K, name);
-        return launch16<T, 4, false>(ctx, As, Bs, C, M, N, kt, ldc, K, name);
+template <typename T, int NPROD>
+int gemm_split(skr_ctx* ctx, const T* As, const T* Bs, const SplitOut& o, int64_t M, int64_t N, int64_t kt, int64_t K,
+               int mode, const char* name) {
+    switch (mode) {
+        case SELF: return launch16<T, NPROD, SELF>(ctx, As, Bs, o, M, N, kt, K, name);
+        case CROSS: return launch16<T, NPROD, CROSS>(ctx, As, Bs, o, M, N, kt, K, name);
+        default: return launch16<T, NPROD, PLAIN>(ctx, As, Bs, o, M, N, kt, K, name);
     }
-    if (nprod == 3) {
-        if (sym) return launch<T, 3, true, 2, 4>(ctx, As, Bs, C, M, N, kt, ldc, K, name);
-        return launch<T, 3, false, 2, 4>(ctx, As, Bs, C, M, N, kt, ldc, K, name);
-    }
-    if (sym) return launch<T, 4, true, 2, 4>(ctx, As, Bs, C, M, N, kt, ldc, K, name);
-    return launch<T, 4, false, 2, 4>(ctx, As, Bs, C, M, N, kt, ldc, K, name);
 }
 
 }  // namespace
 
-// A, B: split-interleaved operands ([rows, kt, {hi,lo}, 32] 16-bit halves) produced by operand.hip
+// A, B: split-interleaved operands ([rows, kt, {hi,lo}, 32] 16-bit halves) produced by operand.hip.
+// mode 0: C = A B^T / K; 1: A == B, one triangle computed and mirrored inside C; 2: C as mode 0 and
+// Ct[j * ldct + i] = C[i * ldc + j] as well.
 int skr_launch_gemm_split(skr_ctx* ctx, int precision, const void* As, const void* Bs, float* C, int64_t M, int64_t N,
-                          int64_t kt, int64_t ldc, int64_t K, int sym) {
+                          int64_t kt, int64_t ldc, int64_t K, int mode, float* Ct, int64_t ldct) {
+    SplitOut o{C, ldc, mode == SELF ? C : Ct, mode == SELF ? ldc : ldct};
     switch (precision) {
         case SKR_PREC_BF16X3:
-            return gemm_split<__bf16>(ctx, (const __bf16*)As, (const __bf16*)Bs, C, M, N, kt, ldc, K, 3, sym != 0,
-                                      "pearson_gemm_bf16x3");
+            return gemm_split<__bf16, 3>(ctx, (const __bf16*)As, (const __bf16*)Bs, o, M, N, kt, K, mode,
+                                         "pearson_gemm_bf16x3");
         case SKR_PREC_BF16X4:
-            return gemm_split<__bf16>(ctx, (const __bf16*)As, (const __bf16*)Bs, C, M, N, kt, ldc, K, 4, sym != 0,
-                                      "pearson_gemm_bf16x4");
+            return gemm_split<__bf16, 4>(ctx, (const __bf16*)As, (const __bf16*)Bs, o, M, N, kt, K, mode,
+                                         "pearson_gemm_bf16x4");
         case SKR_PREC_F16X3:
-            return gemm_split<_Float16>(ctx, (const _Float16*)As, (const _Float16*)Bs, C, M, N, kt, ldc, K, 3, sym != 0,
-                                        "pearson_gemm_f16x3");
+            return gemm_split<_Float16, 3>(ctx, (const _Float16*)As, (const _Float16*)Bs, o, M, N, kt, K, mode,
+                                           "pearson_gemm_f16x3");
         default: return skr_set_error(SKR_ERR_INVALID, "not a split precision: %d", precision);
     }
 }

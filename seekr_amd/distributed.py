@@ -7,15 +7,24 @@ Counting and the elementwise steps are embarrassingly parallel.  Three steps exc
     the running sums are *passed along the ranks* (rank g continues where g-1 stopped) and the
     finished vector is sent back to everyone — bit-identical to the single-GPU result;
   * the global minimum of Log2.post (kmer_counts.py:208): NaN-propagating all-reduce(min);
-  * Pearson (pearson.py:41): every rank needs every other rank's standardised rows.  They are
-    exchanged as *prepared operands* (already split into 16-bit halves) in P-1 pairwise shifts
-    (xGMI is point-to-point: each shift uses one link per direction); the GEMM on the shard
-    received in shift s overlaps shift s+1.
+  * Pearson (pearson.py:41): standardised rows are exchanged as *prepared operands* (already
+    split into 16-bit halves) in pairwise shifts (xGMI is point-to-point: each shift uses one
+    link per direction); the GEMM on the shard received in shift s overlaps shift s+1.
+    Two layouts of the result:
+      - sharded_pearson_symmetric (default): r(h,g) = r(g,h)^T, so every unordered pair of
+        shards is multiplied ONCE, by one of its two ranks, which stores the block and its
+        transpose.  floor(P/2) shifts; each rank multiplies P/2 shard-blocks (1/2 for its own
+        triangle) and ends up holding n_g*N of the N^2 ordered pairs, each pair on exactly one
+        rank: its diagonal block, the blocks (g,h) of its forward half-ring and their mirrors
+        (h,g).  Work per delivered pair is the same as on one GPU.
+      - sharded_pearson_rowblock: rank g holds rows bounds[g]:bounds[g+1] of r, all columns —
+        the layout np.save expects — at the price of multiplying every off-diagonal block
+        twice across the node (P-1 shifts, P-1/2 shard-blocks per rank).
 
 The orchestration is written against two small interfaces so the same code runs on the HIP
 engine with RCCL (production) and on numpy with gloo (CPU tests of the sharding logic):
 
-  engine: colsum / finish / min_nan / apply / prepare / view / gemm
+  engine: colsum / finish / min_nan / apply / prepare / view / gemm / gemm_mirror
   comm  : rank, size, send_vec, recv_vec, allreduce(values, op), shift(...) -> ticket, wait
 """
 import numpy as np
@@ -36,7 +45,7 @@ def shard_bounds(n_rows, size):
 class HipEngine:
     """The production engine: every op is a kernel launch through libseekr_hip."""
 
-    def __init__(self, ctx, precision=_lib.PREC_BF16X3, use_symmetry=True):
+    def __init__(self, ctx, precision=_lib.PREC_F16X3, use_symmetry=True):
         self.ctx = ctx
         self.precision = precision
         self.use_symmetry = use_symmetry  # self-blocks compute one triangle and mirror it
@@ -77,6 +86,10 @@ class HipEngine:
 
     def gemm(self, a, b, r, col0, symmetric=False):
         _lib.pearson_gemm_op(self.ctx, a, b, r, symmetric and self.use_symmetry, 0, col0)
+
+    def gemm_mirror(self, a, b, r, row0, col0, rt, trow0, tcol0):
+        """r[row0+i, col0+j] = <a_i, b_j>/K and rt[trow0+j, tcol0+i] = the same value."""
+        _lib.pearson_gemm_op_mirror(self.ctx, a, b, r, row0, col0, rt, trow0, tcol0)
 
 
 class RcclComm:
@@ -214,3 +227,73 @@ def sharded_pearson_rowblock(engine, comm, z, bounds, r, recv_bufs):
                                         bounds[nsrc + 1] - bounds[nsrc], nsrc)
         engine.gemm(z, engine.view(recv_bufs[s % 2], 0, bounds[src + 1] - bounds[src]), r, bounds[src])
     return r
+
+
+# ------------------------------------------------------------------------------ half ring ---
+def half_ring_plan(size, rank, bounds):
+    """The cross blocks `rank` multiplies in the symmetric layout, in shift order:
+    [(s, peer, a_row0, a_rows, b_row0, b_rows)] — rows a_row0.. of this rank's shard against
+    rows b_row0.. of shard `peer` = rank+s.  Every unordered pair of shards {g, h} appears in
+    exactly one rank's plan; for even P the pair at distance P/2 is met by both of its ranks
+    and is split between them: the lower rank takes its rows against the first half of the
+    other's, the higher rank the second half of its rows against all of the lower's."""
+    def n(g):
+        return bounds[g + 1] - bounds[g]
+
+    plan = []
+    for s in range(1, size // 2 + 1):
+        peer = (rank + s) % size
+        if 2 * s == size:
+            half = n(max(rank, peer)) // 2
+            if rank < peer:
+                plan.append((s, peer, 0, n(rank), 0, half))
+            else:
+                plan.append((s, peer, half, n(rank) - half, 0, n(peer)))
+        else:
+            plan.append((s, peer, 0, n(rank), 0, n(peer)))
+    return plan
+
+
+def owned_blocks(size, rank, bounds):
+    """Where the symmetric layout keeps which ordered pairs on `rank`:
+    [(buffer, buf_row0, buf_col0, nrows, ncols, global_row0, global_col0)], buffer "row" =
+    r_row [n_g, N] (global columns), "col" = r_col [N, n_g] (global rows).  Over all ranks the
+    blocks tile the N x N matrix exactly once."""
+    g0, n_g = bounds[rank], bounds[rank + 1] - bounds[rank]
+    out = [("row", 0, g0, n_g, n_g, g0, g0)]
+    for _, peer, a0, an, b0, bn in half_ring_plan(size, rank, bounds):
+        if an and bn:
+            p0 = bounds[peer] + b0
+            out.append(("row", a0, p0, an, bn, g0 + a0, p0))
+            out.append(("col", p0, a0, bn, an, p0, g0 + a0))
+    return out
+
+
+def sharded_pearson_symmetric(engine, comm, z, bounds, r_row, r_col, recv_bufs):
+    """Self-comparison with every unordered pair of shards multiplied once (module docstring).
+
+    `z`: this rank's prepared operand; `r_row` [n_g, N] and `r_col` [N, n_g]: float32 result
+    buffers (r_col may be None on one GPU); `recv_bufs`: two operand buffers of at least
+    max-shard rows.  Shift s sends our shard to rank-s and receives rank+s's; its GEMM overlaps
+    shift s+1.  Returns owned_blocks(size, rank, bounds)."""
+    size, rank = comm.size, comm.rank
+    plan = half_ring_plan(size, rank, bounds)
+    tickets = {}
+
+    def post(i):
+        s, peer = plan[i][0], plan[i][1]
+        tickets[i] = comm.shift(z, (rank - s) % size, recv_bufs[i % 2], bounds[peer + 1] - bounds[peer], peer)
+
+    if plan:
+        post(0)
+    engine.gemm(z, z, r_row, bounds[rank], symmetric=True)
+    for i, (_, peer, a0, an, b0, bn) in enumerate(plan):
+        comm.wait(tickets.pop(i))
+        if i + 1 < len(plan):
+            post(i + 1)
+        if an and bn:
+            a = z if an == engine.rows(z) else engine.view(z, a0, an)
+            b = engine.view(recv_bufs[i % 2], b0, bn)
+            p0 = bounds[peer] + b0
+            engine.gemm_mirror(a, b, r_row, a0, p0, r_col, p0, a0)
+    return owned_blocks(size, rank, bounds)

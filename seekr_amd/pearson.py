@@ -2,13 +2,18 @@
 (pearson.py:32-44): same signature, same dtype promotion, same NaN behaviour.
 
 float32 inputs run on the matrix cores in the arithmetic named by `SEEKR_PRECISION`:
-  bf16x3 (default)  split-bf16, 3 products/k   |dr| <= ~4e-6 on r ~ 1, 2e-7 rms elsewhere
-  f16x3             split-fp16, 3 products/k   ~5 % slower, 1e-8 rms off the diagonal
-  bf16x4            split-bf16 with lo*lo      ~20 % slower
-  fp32              f32-input MFMA, blocked accumulation: 5e-7 everywhere, ~5x slower
-all of which sit inside the parity bar |dr| <= 2e-6 + 1e-5 |r| against the reference (below
-1024 columns every choice uses the fp32 kernel).  Anything else (float64, integers, DataFrames
-read from CSV) is promoted to float64 like numpy does and runs on the f64 MFMA.
+  f16x3 (default)   split-fp16, 3 products/k: two 11-bit halves carry 22 significand bits, so
+                    the operands are float32-grade; error vs float64 ~2e-7 off the diagonal
+                    (below numpy's own float32 noise), ~3e-6 on r ~ 1.  Row-standardised rows
+                    only (|z| <= sqrt(K) fits fp16); without row standardisation -> fp32.
+  bf16x3            split-bf16, 3 products/k: ~5 % faster, but two 8-bit halves carry 16 bits
+                    and the residual adds up on rows with few distinct values (raw counts of
+                    short sequences): up to ~2e-6 off the diagonal, 1e-5 on it
+  bf16x4            bf16x3 + lo*lo, ~25 % slower than bf16x3, same 16-bit residual
+  fp32              f32-input MFMA, blocked accumulation: 5e-7 on smooth data, ~6x slower
+(tools/adversarial.py prints the errors of all four on worst-case inputs; below 1024 columns
+every choice uses the fp32 kernel).  Anything else (float64, integers, DataFrames read from
+CSV) is promoted to float64 like numpy does and runs on the f64 MFMA.
 """
 import os
 
@@ -25,12 +30,14 @@ def _as_matrix(counts):
     return arr
 
 
-def _precision_for(dtype):
+def _precision_for(dtype, row_standardize=True):
     if dtype == np.float64:
         return _lib.PREC_F64
-    name = os.environ.get("SEEKR_PRECISION", "bf16x3").lower()
+    name = os.environ.get("SEEKR_PRECISION", "f16x3").lower()
     if name not in ("fp32", "bf16x3", "bf16x4", "f16x3"):
         raise ValueError("SEEKR_PRECISION must be fp32, bf16x3, bf16x4 or f16x3, got {!r}".format(name))
+    if name == "f16x3" and not row_standardize:
+        name = "fp32"  # arbitrary magnitudes: outside fp16's range / inside its subnormals
     return _lib.PRECISIONS[name]
 
 
@@ -54,7 +61,7 @@ def pearson(counts1, counts2, row_standardize=True, outfile=None):
     d1 = ctx.from_numpy(c1.astype(w1, copy=False))
     d2 = d1 if same else ctx.from_numpy(c2.astype(w2, copy=False))
     if w1 == w2:
-        r = _lib.pearson(ctx, d1, d2, row_standardize=row_standardize, precision=_precision_for(np.dtype(w1)))
+        r = _lib.pearson(ctx, d1, d2, row_standardize=row_standardize, precision=_precision_for(np.dtype(w1), row_standardize))
     else:
         # mixed float32 / float64: the reference standardises each operand in its own dtype and
         # only the inner product promotes (pearson.py:35-41)

@@ -88,6 +88,11 @@ class NumpyEngine:
     def gemm(self, a, b, r, col0, symmetric=False):
         r[:, col0:col0 + b.shape[0]] = np.inner(a, b) / a.shape[1]
 
+    def gemm_mirror(self, a, b, r, row0, col0, rt, trow0, tcol0):
+        blk = (np.inner(a, b) / a.shape[1]).astype(np.float32)
+        r[row0:row0 + a.shape[0], col0:col0 + b.shape[0]] = blk
+        rt[trow0:trow0 + b.shape[0], tcol0:tcol0 + a.shape[0]] = blk.T
+
 
 class GlooComm:
     def __init__(self, dist, torch):
@@ -128,7 +133,8 @@ def run(rank, size, port, n_rows, n_cols, log2, out_dir, with_nan):
     os.environ["MASTER_PORT"] = str(port)
     import torch
     import torch.distributed as dist
-    from seekr_amd.distributed import shard_bounds, sharded_normalize, sharded_normalize_prepare, sharded_pearson_rowblock
+    from seekr_amd.distributed import (shard_bounds, sharded_normalize, sharded_normalize_prepare,
+                                       sharded_pearson_rowblock, sharded_pearson_symmetric)
 
     dist.init_process_group("gloo", rank=rank, world_size=size)
     try:
@@ -150,7 +156,13 @@ def run(rank, size, port, n_rows, n_cols, log2, out_dir, with_nan):
         recv = [np.zeros((max_shard, n_cols), np.float32), np.zeros((max_shard, n_cols), np.float32)]
         with np.errstate(all="ignore"):
             sharded_pearson_rowblock(engine, comm, z, bounds, r, recv)
-        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), x=x, mean=mean, std=std, r=r,
+        # the symmetric layout: NaN-filled buffers so that unowned cells are recognisable
+        r_row = np.full((hi - lo, n_rows), np.float32(-7.0))
+        r_col = np.full((n_rows, hi - lo), np.float32(-7.0))
+        with np.errstate(all="ignore"):
+            blocks = sharded_pearson_symmetric(engine, comm, z, bounds, r_row, r_col, recv)
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), x=x, mean=mean, std=std, r=r, r_row=r_row, r_col=r_col,
+                 blocks=np.array([(0 if b[0] == "row" else 1,) + tuple(b[1:]) for b in blocks], dtype=np.int64),
                  has_nan=np.array(has_nan), lo=np.array(lo), hi=np.array(hi))
         comm.barrier()
     finally:

@@ -46,7 +46,21 @@ def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
-@pytest.mark.parametrize("size,n_rows,log2", [(2, 301, "Log2.post"), (3, 500, "Log2.none"), (2, 64, "Log2.post")])
+def assemble_symmetric(parts, n_rows):
+    """Put every rank's owned blocks of the symmetric layout into one N x N matrix; `hits`
+    counts how many ranks claimed each cell."""
+    full = np.zeros((n_rows, n_rows), np.float32)
+    hits = np.zeros((n_rows, n_rows), np.int32)
+    for p in parts:
+        for which, br, bc, nr, nc, gr, gc in p["blocks"]:
+            buf = p["r_row"] if which == 0 else p["r_col"]
+            full[gr:gr + nr, gc:gc + nc] = buf[br:br + nr, bc:bc + nc]
+            hits[gr:gr + nr, gc:gc + nc] += 1
+    return full, hits
+
+
+@pytest.mark.parametrize("size,n_rows,log2", [(2, 301, "Log2.post"), (3, 500, "Log2.none"), (2, 64, "Log2.post"),
+                                              (4, 203, "Log2.none")])
 def test_sharded_pipeline_matches_single_process(size, n_rows, log2, tmp_path):
     n_cols = 64
     parts = launch(size, n_rows, n_cols, log2, tmp_path)
@@ -61,6 +75,13 @@ def test_sharded_pipeline_matches_single_process(size, n_rows, log2, tmp_path):
         assert np.allclose(p["r"], r[lo:hi], rtol=1e-5, atol=2e-6)
     full_r = np.concatenate([p["r"] for p in parts], axis=0)
     assert full_r.shape == (n_rows, n_rows)
+    # symmetric (half-ring) layout: every ordered pair lives on exactly one rank, same values
+    sym, hits = assemble_symmetric(parts, n_rows)
+    assert (hits == 1).all()
+    assert np.array_equal(bits(sym), bits(full_r))       # numpy engine: same arithmetic either way
+    assert np.array_equal(bits(sym), bits(sym.T.copy()))
+    owned = sum(int(nr) * int(nc) for p in parts for _, _, _, nr, nc, _, _ in p["blocks"])
+    assert owned == n_rows * n_rows
 
 
 def test_sharded_nan_propagation(tmp_path):
@@ -68,6 +89,27 @@ def test_sharded_nan_propagation(tmp_path):
     for p in parts:
         assert bool(p["has_nan"])  # every rank learns about the NaN even if its own shard...
         assert np.isnan(p["x"]).all()  # ...and np.min's NaN propagates to the whole matrix (:208)
+
+
+@pytest.mark.parametrize("size", list(range(1, 10)))
+def test_half_ring_plan_tiles_the_matrix_once(size):
+    from seekr_amd.distributed import half_ring_plan, owned_blocks, shard_bounds
+    for n_rows in (size, 7 * size + 3, 101):
+        bounds = shard_bounds(n_rows, size)
+        hits = np.zeros((n_rows, n_rows), np.int32)
+        work = []
+        for rank in range(size):
+            for _, br, bc, nr, nc, gr, gc in owned_blocks(size, rank, bounds):
+                hits[gr:gr + nr, gc:gc + nc] += 1
+            n_g = bounds[rank + 1] - bounds[rank]
+            work.append(n_g * n_g / 2 + sum(an * bn for _, _, _, an, _, bn in half_ring_plan(size, rank, bounds)))
+            # shift s pairs rank with rank+s: the peer's plan must name the matching send
+            for s, peer, *_ in half_ring_plan(size, rank, bounds):
+                assert peer == (rank + s) % size
+        assert (hits == 1).all(), (size, n_rows)
+        if n_rows >= 7 * size:  # multiplications are balanced to within the raggedness of the shards
+            assert max(work) <= 1.35 * min(work), (size, n_rows, work)
+        assert len({len(half_ring_plan(size, r, bounds)) for r in range(size)}) == 1  # same number of shifts
 
 
 def test_shard_bounds():
