@@ -62,7 +62,7 @@ def cpu_baseline(k, length, x_norm_head):
     """The oracle (a port with the reference's structure: per-window dict increments in pure
     Python, numpy row standardisation + np.inner) timed on a bounded prefix of the workload."""
     from oracle import seekr_oracle as orc
-    n_count = 3000
+    n_count = 30000  # ~10 s of counting + ~5 s of Pearson on the GPU box's host
     seqs = orc.codes_to_seqs(synthetic_codes(SEED, n_count, length))
     t0 = time.perf_counter()
     orc.raw_counts_py(seqs, k)
@@ -202,7 +202,7 @@ def main():
         "kernels_ms_per_step": {n: round(v["ms_total"] / steps, 4) for n, v in sorted(kern.items())},
     }
     if size == 1 and not args.no_cpu_baseline:
-        head = x.to_numpy(0, min(8000, n_loc))
+        head = x.to_numpy(0, min(20000, n_loc))
         cb = cpu_baseline(k, length, head)
         t_cpu = n_total * length / cb["rate_bases"] + pairs_per_step / cb["rate_pairs"]
         out["cpu_baseline"] = {

@@ -10,8 +10,11 @@ import os
 import tempfile
 import time
 
-from seekr_amd import _lib
-from seekr_amd.distributed import RcclComm, SingleComm
+# the host driver only supports dmabuf IPC; RCCL's peer-to-peer setup fails without this
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+from seekr_amd import _lib  # noqa: E402
+from seekr_amd.distributed import RcclComm, SingleComm  # noqa: E402
 
 
 def world():
