@@ -85,24 +85,28 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
     const int64_t row_base = tm * TM, col_base = tn * TN;
     const int64_t pitch = kt * 64;
 
-    const T* a_src[PP];
-    const T* b_src[PP];
+    // staging: wave w moves pieces PP*w .. PP*w+PP-1 (8 rows x one 128-byte line each) of the A tile
+    // and of the B tile.  Uniform tile base (SGPRs) + 32-bit per-lane byte offset (one VGPR per piece).
+    const char* a_tile = reinterpret_cast<const char*>(A + (size_t)row_base * pitch);
+    const char* b_tile = reinterpret_cast<const char*>(B + (size_t)col_base * pitch);
+    uint32_t a_voff[PP], b_voff[PP];
 #pragma unroll
     for (int p = 0; p < PP; p++) {
         const int row = (wave * PP + p) * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        const int64_t ra = std::min<int64_t>(row_base + row, M - 1);
-        const int64_t rb = std::min<int64_t>(col_base + row, N - 1);
-        a_src[p] = A + (size_t)ra * pitch + chunk * 8;
-        b_src[p] = B + (size_t)rb * pitch + chunk * 8;
+        const int64_t ra = std::min<int64_t>(row, M - 1 - row_base);  // rows past the end re-read the last one
+        const int64_t rb = std::min<int64_t>(row, N - 1 - col_base);
+        a_voff[p] = (uint32_t)(ra * pitch * 2 + chunk * 16);
+        b_voff[p] = (uint32_t)(rb * pitch * 2 + chunk * 16);
     }
     auto stage = [&](int buf, int64_t tile) {
         char* abase = smem + buf * kStageBytes;
         char* bbase = abase + TM * kRowBytes;
+        const uint32_t toff = (uint32_t)tile * kRowBytes;  // folded into the 32-bit lane offset: saddr + voffset form
 #pragma unroll
         for (int p = 0; p < PP; p++) {
-            lds_dma16(a_src[p] + tile * 64, abase + (wave * PP + p) * 1024);
-            lds_dma16(b_src[p] + tile * 64, bbase + (wave * PP + p) * 1024);
+            lds_dma16(a_tile + (a_voff[p] + toff), abase + (wave * PP + p) * 1024);
+            lds_dma16(b_tile + (b_voff[p] + toff), bbase + (wave * PP + p) * 1024);
         }
     };
 
@@ -129,6 +133,12 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
 #pragma unroll
             for (int e = 0; e < 4; e++) acc[i][j][e] = 0.f;
 
+    // Two LDS stages: tile t+1 streams in by LDS-DMA while tile t is consumed; one barrier per k
+    // tile.  The loop runs at the clock the chip grants an MFMA-dense body (1.9-1.95 GHz effective,
+    // MI355X_MICROARCH.md "DVFS give-back"): a four-phase software pipeline that reads the next
+    // phase's fragments under the current phase's MFMAs and moves the barrier before the last
+    // phase (no MFMA ever waits on a fresh LDS read) ran in the same 25.1 vs 25.2 ms, so the
+    // simple form stays.
     int cur = 0;
     stage(0, 0);
     __syncthreads();
@@ -158,7 +168,6 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
         __syncthreads();
         cur ^= 1;
     }
-
     const bool mirror = MODE == CROSS || (SYM && tm != tn);
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
