@@ -37,7 +37,7 @@ enum {
     SKR_ERR_UNSUPPORTED = -4, /* valid request the device path does not implement                 */
     SKR_ERR_ZERODIV = -5,     /* a sequence has len == k-1 (kmer_counts.py:144 ZeroDivisionError) */
     SKR_ERR_COMM = -6,        /* RCCL failure / communicator not initialised                      */
-    SKR_ERR_IO = -7,          /* file could not be read                                           */
+    SKR_ERR_IO = -7,          /* file could not be read or written                                */
     SKR_ERR_FASTA_BLANK = -8, /* blank line in FASTA (fasta_reader.py:53 IndexError)              */
     SKR_ERR_FASTA_HEADER = -9 /* header without sequence (fasta_reader.py:58 AssertionError)      */
 };
@@ -51,11 +51,12 @@ enum { SKR_LOG2_NONE = 0, SKR_LOG2_PRE = 1, SKR_LOG2_POST = 2 };
 /* arithmetic of the Pearson contraction (pearson.py:41) */
 enum {
     SKR_PREC_FP32 = 0,   /* v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulate           */
-    SKR_PREC_BF16X3 = 1, /* split-bf16: hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16       */
+    SKR_PREC_BF16X3 = 1, /* split-bf16: hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16       */
     SKR_PREC_F64 = 2,    /* v_mfma_f64_16x16x4_f64 (float64 inputs: CSV / integer count files)   */
     SKR_PREC_BF16X4 = 3, /* split-bf16 with the lo*lo term as well                                */
-    SKR_PREC_F16X3 = 4   /* split-fp16 (11-bit halves), 3 products on v_mfma_f32_32x32x16_f16:   */
-                         /* float32-grade products at the bf16x3 cost                            */
+    SKR_PREC_F16X3 = 4   /* split-fp16 (11-bit halves: float32-grade operands), 3 products on    */
+                         /* v_mfma_f32_16x16x32_f16.  The host API's default for row-standardised */
+                         /* rows; values must fit fp16 (|z| <= sqrt(K) always does)              */
 };
 
 typedef struct skr_ctx skr_ctx;   /* one GPU + one stream + scratch + optional RCCL communicator */
@@ -210,6 +211,21 @@ int skr_gather_f32(skr_ctx* ctx, const skr_mat* src, const int64_t* idx_host, in
 /* p[i,j] = float32(count(bg > r[i,j]) / total_len) (find_pval.py:158-164); sorted_bg: the
  * background values ascending with NaNs removed, total_len: len(fitres) including NaNs.    */
 int skr_empirical_pvalues(skr_ctx* ctx, const skr_mat* r, const skr_mat* sorted_bg, int64_t total_len, skr_mat* p);
+
+/* ---------------------------------------------------------------- writers --------------- */
+/* The files the reference writes from the count matrix and from r, byte-identical to numpy's:
+ *   skr_*_save_npy                   np.save(path, a)              kmer_counts.py:234, pearson.py:43
+ *   skr_*_save_csv, fmt_mode 0       np.savetxt(path, a, delimiter=",", fmt="%1.6f")   kmer_counts.py:241
+ *                   fmt_mode 1       np.savetxt(path, a, delimiter=",")  ("%.18e")     find_dist.py:292
+ * (the caller appends ".npy" where np.save would).  one_dim != 0 writes shape (cols,) for a
+ * 1-row matrix (the mean / std vectors of seekr_norm_vectors).  Device matrices are streamed
+ * through pinned buffers; text is formatted by `threads` host threads (0 = pick).  The host
+ * variants take a C-contiguous array in host memory and need no device.                      */
+int skr_mat_save_npy(skr_ctx* ctx, const skr_mat* m, int one_dim, const char* path);
+int skr_mat_save_csv(skr_ctx* ctx, const skr_mat* m, int fmt_mode, int threads, const char* path);
+int skr_host_save_npy(const void* data, int dtype, int64_t rows, int64_t cols, int one_dim, const char* path);
+int skr_host_save_csv(const void* data, int dtype, int64_t rows, int64_t cols, int fmt_mode, int threads,
+                      const char* path);
 
 /* ---------------------------------------------------------------- multi-GPU (C1, C2) ---- */
 /* One process per GPU.  Rank 0 creates an id and distributes the 128 bytes out of band.    */

@@ -75,6 +75,10 @@ SIGNATURES = {
     "skr_triu_flatten": (_int, [_p, _p, _i64, _p]),
     "skr_gather_f32": (_int, [_p, _p, _p, _i64, _p]),
     "skr_empirical_pvalues": (_int, [_p, _p, _p, _i64, _p]),
+    "skr_mat_save_npy": (_int, [_p, _p, _int, C.c_char_p]),
+    "skr_mat_save_csv": (_int, [_p, _p, _int, _int, C.c_char_p]),
+    "skr_host_save_npy": (_int, [_p, _int, _i64, _i64, _int, C.c_char_p]),
+    "skr_host_save_csv": (_int, [_p, _int, _i64, _i64, _int, _int, C.c_char_p]),
     "skr_comm_unique_id": (_int, [C.c_char_p]),
     "skr_comm_init": (_int, [_p, _int, _int, C.c_char_p]),
     "skr_comm_destroy": (_int, [_p]),
@@ -490,6 +494,45 @@ def pearson(ctx, c1, c2, row_standardize=True, precision=PREC_FP32, r=None):
     r = ctx.empty(c1.rows, c2.rows, c1.dtype) if r is None else r
     check(lib().skr_pearson(ctx._h, c1._h, c2._h, 1 if row_standardize else 0, int(precision), r._h))
     return r
+
+
+# ----------------------------------------------------------------------------- writers -----
+FMT_FIXED6, FMT_SCI18 = 0, 1  # np.savetxt fmt "%1.6f" (kmer_counts.py:241) / numpy's default "%.18e"
+_NP_DTYPES = {np.dtype(np.float32): F32, np.dtype(np.float64): F64, np.dtype(np.uint32): U32}
+
+
+def npy_path(path):
+    """np.save appends '.npy' unless the name already ends with it (kmer_counts.py:234 relies on it)."""
+    path = os.fspath(path)
+    return path if path.endswith(".npy") else path + ".npy"
+
+
+def save_npy(path, a):
+    """np.save(path, a) for a device Matrix or a float32 / float64 / uint32 numpy array (1-D or 2-D)."""
+    path = npy_path(path).encode()
+    if isinstance(a, Matrix):
+        check(lib().skr_mat_save_npy(a.ctx._h, a._h, 0, path))
+        return
+    a = np.ascontiguousarray(a)
+    if a.dtype not in _NP_DTYPES or a.ndim not in (1, 2):
+        np.save(path.decode(), a)
+        return
+    rows, cols = (1, a.shape[0]) if a.ndim == 1 else a.shape
+    check(lib().skr_host_save_npy(a.ctypes.data_as(_p), _NP_DTYPES[a.dtype], rows, cols, 1 if a.ndim == 1 else 0, path))
+
+
+def save_csv(path, a, fmt=FMT_FIXED6, threads=0):
+    """np.savetxt(path, a, delimiter=',', fmt='%1.6f' | '%.18e') for a device Matrix or a 2-D float array."""
+    path = os.fspath(path).encode()
+    if isinstance(a, Matrix):
+        check(lib().skr_mat_save_csv(a.ctx._h, a._h, int(fmt), int(threads), path))
+        return
+    a = np.ascontiguousarray(a)
+    if a.dtype not in (np.float32, np.float64) or a.ndim != 2:
+        np.savetxt(path.decode(), a, delimiter=",", fmt="%1.6f" if fmt == FMT_FIXED6 else "%.18e")
+        return
+    check(lib().skr_host_save_csv(a.ctypes.data_as(_p), _NP_DTYPES[a.dtype], a.shape[0], a.shape[1], int(fmt),
+                                  int(threads), path))
 
 
 # ----------------------------------------------------------------------------- RCCL --------

@@ -248,14 +248,14 @@ class BasicCounter:
         assert not (self.binary and self.label), err_msg
         assert self.outfile is not None, "Please provide an outfile location."
         if self.binary:
-            np.save(self.outfile, self.counts)
+            _lib.save_npy(self.outfile, self.counts)  # np.save, streamed natively
         elif self.label:
             from pandas import DataFrame
             if names is None:
                 names = self._packed.headers() if self._packed is not None else Reader(self.infasta).get_headers()
             DataFrame(data=self.counts, index=names, columns=self.kmers).to_csv(self.outfile)
         else:
-            np.savetxt(self.outfile, self.counts, delimiter=",", fmt="%1.6f")
+            _lib.save_csv(self.outfile, self.counts)  # np.savetxt(..., delimiter=",", fmt="%1.6f"), threaded
 
     # ---- kmer_counts.py:243-262 -------------------------------------------------------------
     def make_count_file(self, names=None):

@@ -74,5 +74,5 @@ def pearson(counts1, counts2, row_standardize=True, outfile=None):
         r = _lib.pearson(ctx, d1, d2, row_standardize=False, precision=_lib.PREC_F64)
     dist = r.to_numpy()
     if outfile:
-        np.save(outfile, dist)
+        _lib.save_npy(outfile, dist)
     return dist

@@ -1,0 +1,97 @@
+"""The native writers against numpy's own files, byte for byte.  The host variants need no GPU,
+so the formatting logic (exact "%1.6f" rounding with integer arithmetic, .npy header padding,
+threaded row order) is pinned on CPU."""
+import filecmp
+import os
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def L():
+    from seekr_amd import _lib
+    return _lib
+
+
+def hard_values(rng, n, dtype):
+    """Values that stress '%1.6f': exact ties at the 7th decimal, tiny negatives, big and small
+    magnitudes, subnormals, per-kb count values, NaN and infinities."""
+    parts = [
+        rng.standard_normal(n) * 3,
+        rng.integers(0, 40, n) * (1000.0 / rng.integers(1, 2000, n)),          # per-kb counts
+        (rng.integers(-2_000_000, 2_000_000, n) + 0.5) / 1e6,                   # decimal ties (inexact in binary)
+        rng.integers(-2 ** 20, 2 ** 20, n) / 2.0 ** 7,                          # binary fractions: exact ties for %f
+        np.ldexp(rng.integers(1, 2 ** 23, n).astype(np.float64), rng.integers(-160, 40, n)),
+        np.array([0.0, -0.0, 1e-7, -1e-7, 4.9999995e-7, 5e-7, -5e-7, 0.9999995, 0.99999949, 123456.7890125,
+                  1e15, -1e15, 3.4e38, -3.4e38, 1e-45, np.nan, -np.nan, np.inf, -np.inf, 2.5e-7, 0.0000005, 1.0000005]),
+    ]
+    v = np.concatenate(parts)
+    with np.errstate(over="ignore"):
+        return v.astype(dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("fmt", ["%1.6f", "%.18e"])
+def test_csv_bytes_equal_numpy_savetxt(dtype, fmt, L, tmp_path):
+    rng = np.random.default_rng(7)
+    v = hard_values(rng, 3000, dtype)
+    cols = 37
+    a = np.resize(v, (len(v) // cols, cols)).astype(dtype)
+    want, got = str(tmp_path / "want.csv"), str(tmp_path / "got.csv")
+    np.savetxt(want, a, delimiter=",", fmt=fmt)
+    for threads in (1, 5):
+        L.save_csv(got, a, L.FMT_FIXED6 if fmt == "%1.6f" else L.FMT_SCI18, threads=threads)
+        assert filecmp.cmp(want, got, shallow=False), (dtype, fmt, threads)
+
+
+def test_csv_large_random_float32(L, tmp_path):
+    rng = np.random.default_rng(1)
+    a = (rng.binomial(30, 0.1, size=(700, 1024)) * np.float32(1000 / 1995)).astype(np.float32)
+    a = np.log2(a + 1).astype(np.float32) - np.float32(0.731)
+    want, got = str(tmp_path / "want.csv"), str(tmp_path / "got.csv")
+    np.savetxt(want, a, delimiter=",", fmt="%1.6f")
+    L.save_csv(got, a)
+    assert filecmp.cmp(want, got, shallow=False)
+
+
+@pytest.mark.parametrize("shape,dtype", [((5, 16), np.float32), ((1, 4096), np.float32), ((4096,), np.float32),
+                                         ((3, 3), np.float64), ((7, 1), np.uint32), ((0, 16), np.float32),
+                                         ((123, 4567), np.float32), ((12345678,), np.float32)])
+def test_npy_bytes_equal_numpy_save(shape, dtype, L, tmp_path):
+    rng = np.random.default_rng(3)
+    a = (rng.standard_normal(shape) * 100).astype(dtype)
+    want, got = str(tmp_path / "want.npy"), str(tmp_path / "got")  # np.save appends .npy
+    np.save(want, a)
+    L.save_npy(got, a)
+    assert os.path.exists(got + ".npy") and not os.path.exists(got)
+    assert filecmp.cmp(want, got + ".npy", shallow=False)
+    back = np.load(got + ".npy")
+    assert back.dtype == a.dtype and back.shape == a.shape
+
+
+def test_writer_errors(L, tmp_path):
+    with pytest.raises(OSError):
+        L.save_csv(str(tmp_path / "no" / "such" / "dir.csv"), np.zeros((2, 2), np.float32))
+
+
+@pytest.mark.gpu
+def test_device_matrices_stream_to_identical_files(L, tmp_path):
+    """skr_mat_save_npy / skr_mat_save_csv stream a device matrix through pinned double buffers;
+    sizes chosen to cross several chunk boundaries."""
+    ctx = L.default_context()
+    rng = np.random.default_rng(11)
+    a = (rng.standard_normal((9001, 4096)) * 3).astype(np.float32)
+    dev = ctx.from_numpy(a)
+    want, got = str(tmp_path / "want.npy"), str(tmp_path / "got.npy")
+    np.save(want, a)
+    L.save_npy(got, dev)
+    assert filecmp.cmp(want, got, shallow=False)
+    small = a[:2500]
+    np.savetxt(str(tmp_path / "want.csv"), small, delimiter=",", fmt="%1.6f")
+    L.save_csv(str(tmp_path / "got.csv"), dev.view(0, 2500))
+    assert filecmp.cmp(str(tmp_path / "want.csv"), str(tmp_path / "got.csv"), shallow=False)
+    d64 = ctx.from_numpy(a[:50].astype(np.float64))
+    np.savetxt(str(tmp_path / "want64.csv"), a[:50].astype(np.float64), delimiter=",")
+    L.save_csv(str(tmp_path / "got64.csv"), d64, L.FMT_SCI18)
+    assert filecmp.cmp(str(tmp_path / "want64.csv"), str(tmp_path / "got64.csv"), shallow=False)
