@@ -212,6 +212,19 @@ int skr_gather_f32(skr_ctx* ctx, const skr_mat* src, const int64_t* idx_host, in
  * background values ascending with NaNs removed, total_len: len(fitres) including NaNs.    */
 int skr_empirical_pvalues(skr_ctx* ctx, const skr_mat* r, const skr_mat* sorted_bg, int64_t total_len, skr_mat* p);
 
+/* The non-zero cells that kmer_leiden.py:94-96 leaves in a block of r, as an edge list and
+ * without writing the zeros: cells of r[0:nrows, col_begin:col_end] with !(v < cutoff) (NaN
+ * stays, like numpy's mask), v != 0 and global row != global column, where global row =
+ * row_global0 + i and global column = col_global0 + j (j = r's own column index);
+ * upper_only != 0 keeps global column > global row only.  *count receives the number of edges.
+ * With out_rows / out_cols (SKR_U32) and out_vals (SKR_F32) non-NULL (each at least *count
+ * cells) the triplets are written in row-major order — the order of np.nonzero on the
+ * thresholded matrix; with all three NULL only the count is made.  Blocks of r produced one
+ * row stripe at a time never need the N x N matrix.                      */
+int skr_edges(skr_ctx* ctx, const skr_mat* r, int64_t nrows, int64_t col_begin, int64_t col_end,
+              int64_t row_global0, int64_t col_global0, float cutoff, int upper_only, skr_mat* out_rows,
+              skr_mat* out_cols, skr_mat* out_vals, int64_t* count);
+
 /* ---------------------------------------------------------------- writers --------------- */
 /* The files the reference writes from the count matrix and from r, byte-identical to numpy's:
  *   skr_*_save_npy                   np.save(path, a)              kmer_counts.py:234, pearson.py:43

@@ -5,6 +5,8 @@ it: keeping these reductions on the GPU avoids shipping an N x N m
     triu_values           find_dist.py:163       sim[np.triu_indices(N, k=1)]
     subsample             find_dist.py:169       np.random.choice(values, size, replace=False)
     empirical_pvalues     find_pval.py:158-164   p[i,j] = np.sum(fitres > sim[i,j]) / len(fitres)
+    edges / pearson_edges kmer_leiden.py:91-96   the thresholded matrix as an edge list, r produced and consumed
+                                                 one row stripe at a time (N x N never exists)
 
 Every function takes and returns device matrices (`seekr_amd._lib.Matrix`); `*_host` helpers
 wrap host arrays for drop-in use.
@@ -61,3 +63,50 @@ def empirical_pvalues_host(sim, fitres):
     sim = np.ascontiguousarray(sim, dtype=np.float32)
     ctx = _lib.default_context()
     return empirical_pvalues(ctx.from_numpy(sim), fitres).to_numpy()
+
+
+def edges(r, cutoff, nrows=None, col_begin=0, col_end=None, row_global0=0, col_global0=0, upper_only=False):
+    """(rows, cols, vals) numpy arrays (uint32, uint32, float32): the cells of the device block
+    r[0:nrows, col_begin:col_end] that kmer_leiden.py:94-96 leaves non-zero, in np.nonzero order."""
+    ctx = r.ctx
+    nrows = r.rows if nrows is None else nrows
+    col_end = r.cols if col_end is None else col_end
+    count = C.c_int64(0)
+    args = (ctx._h, r._h, int(nrows), int(col_begin), int(col_end), int(row_global0), int(col_global0),
+            C.c_float(cutoff), 1 if upper_only else 0)
+    _lib.check(_lib.lib().skr_edges(*args, None, None, None, C.byref(count)))
+    n = count.value
+    if n == 0:
+        return np.empty(0, np.uint32), np.empty(0, np.uint32), np.empty(0, np.float32)
+    out_r, out_c, out_v = ctx.empty(1, n, np.uint32), ctx.empty(1, n, np.uint32), ctx.empty(1, n, np.float32)
+    _lib.check(_lib.lib().skr_edges(*args, out_r._h, out_c._h, out_v._h, C.byref(count)))
+    res = out_r.to_numpy().reshape(-1), out_c.to_numpy().reshape(-1), out_v.to_numpy().reshape(-1)
+    for m in (out_r, out_c, out_v):
+        m.free()
+    return res
+
+
+def pearson_edges(z, cutoff, stripe_rows=8192, upper_only=True, engine_gemm=None):
+    """Edge list of the self-comparison of the prepared operand `z` (seekr_amd._lib.Operand):
+    r is produced one stripe of `stripe_rows` rows at a time into one reusable buffer (columns at or
+    right of the stripe when `upper_only`) and reduced to edges before the next stripe overwrites
+    it, so memory is stripe_rows x N floats instead of N x N (config 5: 32 GB instead of 4 TB).
+    Returns (rows, cols, vals) in row-major order: what np.nonzero / indexing of the thresholded,
+    zero-diagonal matrix (kmer_leiden.py:94-96) gives — its upper triangle when `upper_only`."""
+    ctx = z.ctx
+    n = z.rows
+    stripe_rows = max(1, min(int(stripe_rows), n))
+    buf = ctx.empty(stripe_rows, n)
+    out = ([], [], [])
+    for s0 in range(0, n, stripe_rows):
+        rows = min(stripe_rows, n - s0)
+        c0 = s0 if upper_only else 0
+        a = z.view(s0, rows)
+        b = z.view(c0, n - c0) if c0 else z
+        _lib.pearson_gemm_op(ctx, a, b, buf, symmetric=False, row0=0, col0=c0)
+        part = edges(buf, cutoff, nrows=rows, col_begin=c0, col_end=n, row_global0=s0, col_global0=0,
+                     upper_only=upper_only)
+        for acc, p in zip(out, part):
+            acc.append(p)
+    buf.free()
+    return tuple(np.concatenate(p) if p else np.empty(0) for p in out)

@@ -63,6 +63,99 @@ __global__ __launch_bounds__(256) void empirical_p_kernel(const float* __restric
     }
 }
 
+// ---- threshold -> edge list (kmer_leiden.py:94-96 without ever writing the zeros) -------------
+// A cell survives `ld_sim[ld_sim < cutoff] = 0; np.fill_diagonal(ld_sim, 0)` as a non-zero iff
+// !(v < cutoff) (NaN stays), v != 0 and it is off the diagonal.  upper: keep column > row only.
+struct EdgeArgs {
+    const float* r;
+    int64_t ld, rows, col_begin, col_end, row_global0, col_global0;
+    float cutoff;
+    int upper;
+};
+
+__device__ __forceinline__ bool edge_kept(const EdgeArgs& a, int64_t grow, int64_t gcol, float v) {
+    if (v < a.cutoff || v == 0.f) return false;
+    return a.upper ? gcol > grow : gcol != grow;
+}
+
+__global__ __launch_bounds__(256) void edges_count_kernel(EdgeArgs a, unsigned long long* __restrict__ counts) {
+    __shared__ unsigned red[4];
+    for (int64_t i = blockIdx.x; i < a.rows; i += gridDim.x) {
+        const float* row = a.r + (size_t)i * a.ld;
+        const int64_t grow = a.row_global0 + i;
+        unsigned n = 0;
+        for (int64_t c = a.col_begin + threadIdx.x; c < a.col_end; c += 256) n += edge_kept(a, grow, a.col_global0 + c, row[c]);
+        for (int off = 32; off; off >>= 1) n += __shfl_down(n, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = n;
+        __syncthreads();
+        if (threadIdx.x == 0) counts[i] = (unsigned long long)red[0] + red[1] + red[2] + red[3];
+        __syncthreads();
+    }
+}
+
+// exclusive prefix sum of the per-row counts, in place; one workgroup (rows <= a few 10^5 per call)
+__global__ __launch_bounds__(1024) void edges_scan_kernel(unsigned long long* __restrict__ counts, int64_t n,
+                                                          unsigned long long* __restrict__ total) {
+    __shared__ unsigned long long part[1024];
+    const int64_t per = (n + 1023) / 1024, lo = std::min<int64_t>(n, threadIdx.x * per), hi = std::min<int64_t>(n, lo + per);
+    unsigned long long s = 0;
+    for (int64_t i = lo; i < hi; i++) s += counts[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (int t = 0; t < 1024; t++) {
+            const unsigned long long v = part[t];
+            part[t] = run;
+            run += v;
+        }
+        *total = run;
+    }
+    __syncthreads();
+    unsigned long long run = part[threadIdx.x];
+    for (int64_t i = lo; i < hi; i++) {
+        const unsigned long long v = counts[i];
+        counts[i] = run;
+        run += v;
+    }
+}
+
+// row-major order (== np.nonzero of the thresholded matrix): a workgroup walks its row 256 columns at
+// a time; position inside the chunk from wave ballots + a 4-entry scan
+__global__ __launch_bounds__(256) void edges_fill_kernel(EdgeArgs a, const unsigned long long* __restrict__ offsets,
+                                                         uint32_t* __restrict__ out_row, uint32_t* __restrict__ out_col,
+                                                         float* __restrict__ out_val) {
+    __shared__ unsigned wave_n[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t i = blockIdx.x; i < a.rows; i += gridDim.x) {
+        const float* row = a.r + (size_t)i * a.ld;
+        const int64_t grow = a.row_global0 + i;
+        unsigned long long base = offsets[i];
+        for (int64_t c0 = a.col_begin; c0 < a.col_end; c0 += 256) {
+            const int64_t c = c0 + threadIdx.x;
+            const float v = c < a.col_end ? row[c] : 0.f;
+            const bool keep = c < a.col_end && edge_kept(a, grow, a.col_global0 + c, v);
+            const unsigned long long mask = __ballot(keep);
+            if (lane == 0) wave_n[wave] = (unsigned)__popcll(mask);
+            __syncthreads();
+            unsigned before = 0, all = 0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                if (w < wave) before += wave_n[w];
+                all += wave_n[w];
+            }
+            if (keep) {
+                const unsigned long long pos = base + before + __popcll(mask & ((1ull << lane) - 1));
+                out_row[pos] = (uint32_t)grow;
+                out_col[pos] = (uint32_t)(a.col_global0 + c);
+                out_val[pos] = v;
+            }
+            base += all;
+            __syncthreads();
+        }
+    }
+}
+
 unsigned grid_for(const skr_ctx* ctx, int64_t items) {
     return (unsigned)std::max<int64_t>(1, std::min<int64_t>((items + 255) / 256, (int64_t)ctx->num_cu * 8));
 }
@@ -131,6 +224,52 @@ extern "C" int skr_empirical_pvalues(skr_ctx* ctx, const skr_mat* r, const skr_m
     hipLaunchKernelGGL(empirical_p_kernel, dim3(grid_for(ctx, cells)), dim3(256), 0, ctx->stream, (const float*)r->data,
                        cells, (const float*)sorted_bg->data, sorted_bg->rows * sorted_bg->cols, (double)total_len,
                        (float*)p->data);
+    SKR_HIP(hipGetLastError());
+    return SKR_OK;
+}
+
+extern "C" int skr_edges(skr_ctx* ctx, const skr_mat* r, int64_t nrows, int64_t col_begin, int64_t col_end,
+                         int64_t row_global0, int64_t col_global0, float cutoff, int upper_only, skr_mat* out_rows,
+                         skr_mat* out_cols, skr_mat* out_vals, int64_t* count) {
+    SKR_REQUIRE(ctx && r && count && r->ctx == ctx && r->dtype == SKR_F32, "need a float32 matrix of this ctx and a count");
+    SKR_REQUIRE(nrows >= 0 && nrows <= r->rows, "nrows out of range");
+    SKR_REQUIRE(col_begin >= 0 && col_begin <= col_end && col_end <= r->cols, "column range out of the matrix");
+    SKR_REQUIRE(row_global0 >= 0 && col_global0 >= 0 && row_global0 + nrows <= 0xffffffffLL &&
+                    col_global0 + col_end <= 0xffffffffLL, "global indices must fit 32 bits");
+    const bool fill = out_rows || out_cols || out_vals;
+    if (fill) {
+        SKR_REQUIRE(out_rows && out_cols && out_vals, "pass all three outputs or none");
+        SKR_REQUIRE(out_rows->ctx == ctx && out_cols->ctx == ctx && out_vals->ctx == ctx, "foreign ctx");
+        SKR_REQUIRE(out_rows->dtype == SKR_U32 && out_cols->dtype == SKR_U32 && out_vals->dtype == SKR_F32,
+                    "outputs are U32, U32, F32");
+    }
+    SKR_TRY(skr_activate(ctx));
+    *count = 0;
+    if (nrows == 0 || col_begin == col_end) return SKR_OK;
+    void* ws = nullptr;
+    SKR_TRY(skr_ctx_workspace(ctx, (size_t)(nrows + 2) * 8, &ws));
+    unsigned long long* counts = (unsigned long long*)ws;
+    unsigned long long* total = counts + nrows;
+    EdgeArgs a{(const float*)r->data, r->cols, nrows, col_begin, col_end, row_global0, col_global0, cutoff, upper_only != 0};
+    const unsigned grid = (unsigned)std::min<int64_t>(nrows, (int64_t)ctx->num_cu * 16);
+    {
+        SkrProfScope prof(ctx, "edges_count");
+        hipLaunchKernelGGL(edges_count_kernel, dim3(grid), dim3(256), 0, ctx->stream, a, counts);
+        SKR_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(edges_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, counts, nrows, total);
+    SKR_HIP(hipGetLastError());
+    unsigned long long h_total = 0;
+    SKR_HIP(hipMemcpyAsync(&h_total, total, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SKR_HIP(hipStreamSynchronize(ctx->stream));
+    *count = (int64_t)h_total;
+    if (!fill || h_total == 0) return SKR_OK;
+    const int64_t cap = std::min(out_rows->rows * out_rows->cols, std::min(out_cols->rows * out_cols->cols,
+                                                                           out_vals->rows * out_vals->cols));
+    SKR_REQUIRE((int64_t)h_total <= cap, "%lld edges do not fit outputs of %lld cells", (long long)h_total, (long long)cap);
+    SkrProfScope prof(ctx, "edges_fill");
+    hipLaunchKernelGGL(edges_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream, a, counts, (uint32_t*)out_rows->data,
+                       (uint32_t*)out_cols->data, (float*)out_vals->data);
     SKR_HIP(hipGetLastError());
     return SKR_OK;
 }

@@ -70,3 +70,56 @@ def test_empirical_pvalues(ctx):
     got = consumers.empirical_pvalues_host(sim, fitres)
     assert got.dtype == np.float32 and np.array_equal(got, want)
     assert np.array_equal(consumers.empirical_pvalues_host(sim, np.array([np.nan, np.nan])), np.zeros_like(sim))
+
+
+def nonzero_edges(r, cutoff, upper):
+    """kmer_leiden.py:94-96 on a host copy, then the non-zero cells in np.nonzero order."""
+    want = r.copy()
+    with np.errstate(invalid="ignore"):
+        want[want < cutoff] = 0
+    np.fill_diagonal(want, 0)
+    if upper:
+        want = np.triu(want, 1)
+    i, j = np.nonzero(want)  # NaN counts as non-zero
+    return i.astype(np.uint32), j.astype(np.uint32), want[i, j]
+
+
+@pytest.mark.parametrize("n,m,cutoff", [(301, 301, 0.1), (64, 1000, 0.25), (513, 513, -5.0), (100, 100, 2.0), (257, 255, 0.0)])
+def test_edges_of_a_block_match_numpy(n, m, cutoff, ctx):
+    from seekr_amd import consumers
+    r = rand_r(n, m, seed=n)
+    r[3, 5] = np.nan
+    r[7, 9] = 0.0
+    d = ctx.from_numpy(r)
+    for upper in (False, True):
+        i, j, v = consumers.edges(d, cutoff, upper_only=upper)
+        wi, wj, wv = nonzero_edges(r, cutoff, upper)
+        assert np.array_equal(i, wi) and np.array_equal(j, wj)
+        assert np.array_equal(np.isnan(v), np.isnan(wv)) and np.array_equal(np.nan_to_num(v), np.nan_to_num(wv))
+    # a sub-block with global offsets: rows 10.. of the matrix, columns 20..m, diagonal where global ids meet
+    sub = ctx.from_numpy(r[10:50])
+    i, j, v = consumers.edges(sub, cutoff, col_begin=20, row_global0=10)
+    full = np.full_like(r, 0)
+    full[10:50, 20:] = r[10:50, 20:]
+    wi, wj, wv = nonzero_edges(full, cutoff, False)
+    assert np.array_equal(i, wi) and np.array_equal(j, wj) and np.array_equal(np.nan_to_num(v), np.nan_to_num(wv))
+
+
+def test_pearson_edges_striped_equals_full_matrix(ctx):
+    """r produced and thresholded one row stripe at a time (never N x N) gives the edge list of the
+    full matrix: same cells, same order, same float32 values."""
+    from seekr_amd import _lib as L, consumers
+    rng = np.random.default_rng(5)
+    n, k = 3001, 4096
+    base = rng.binomial(40, 0.05, size=(60, k)).astype(np.float32)
+    x = (base[rng.integers(0, 60, n)] + rng.binomial(6, 0.3, size=(n, k))).astype(np.float32)  # clustered rows
+    z, _ = L.operand_fill(ctx, ctx.from_numpy(x))
+    full = ctx.empty(n, n)
+    L.pearson_gemm_op(ctx, z, z, full, symmetric=False)
+    r = full.to_numpy()
+    cutoff = float(np.quantile(r, 0.97))
+    for upper, stripe in ((True, 700), (False, 1024), (True, 5000)):
+        i, j, v = consumers.pearson_edges(z, cutoff, stripe_rows=stripe, upper_only=upper)
+        wi, wj, wv = nonzero_edges(r, cutoff, upper)
+        assert len(wi) > 1000
+        assert np.array_equal(i, wi) and np.array_equal(j, wj) and np.array_equal(v, wv)
