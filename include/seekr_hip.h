@@ -239,6 +239,16 @@ int skr_mat_save_csv(skr_ctx* ctx, const skr_mat* m, int fmt_mode, int threads, 
 int skr_host_save_npy(const void* data, int dtype, int64_t rows, int64_t cols, int one_dim, const char* path);
 int skr_host_save_csv(const void* data, int dtype, int64_t rows, int64_t cols, int fmt_mode, int threads,
                       const char* path);
+/* fmt_mode 2 of the two functions above writes numpy's str() of each value: the shortest digits
+ * that read back as the same float32 / float64 (positional for 1e-4 <= |x| < 1e16), NaN as an
+ * empty field — the cell format of DataFrame.to_csv.  The labelled variants write the file of
+ *   DataFrame(a, index=row_labels, columns=col_labels).to_csv(path)      kmer_counts.py:236-240
+ * (the reference CLI's default output): header line ",c0,c1,…", then label,values per row, labels
+ * quoted as csv.QUOTE_MINIMAL does.  row_labels / col_labels: '\n'-joined, exactly rows / cols of them. */
+int skr_mat_save_csv_labelled(skr_ctx* ctx, const skr_mat* m, const char* row_labels, const char* col_labels,
+                              int threads, const char* path);
+int skr_host_save_csv_labelled(const void* data, int dtype, int64_t rows, int64_t cols, const char* row_labels,
+                               const char* col_labels, int threads, const char* path);
 
 /* ---------------------------------------------------------------- multi-GPU (C1, C2) ---- */
 /* One process per GPU.  Rank 0 creates an id and distributes the 128 bytes out of band.    */

@@ -80,6 +80,8 @@ SIGNATURES = {
     "skr_mat_save_csv": (_int, [_p, _p, _int, _int, C.c_char_p]),
     "skr_host_save_npy": (_int, [_p, _int, _i64, _i64, _int, C.c_char_p]),
     "skr_host_save_csv": (_int, [_p, _int, _i64, _i64, _int, _int, C.c_char_p]),
+    "skr_mat_save_csv_labelled": (_int, [_p, _p, C.c_char_p, C.c_char_p, _int, C.c_char_p]),
+    "skr_host_save_csv_labelled": (_int, [_p, _int, _i64, _i64, C.c_char_p, C.c_char_p, _int, C.c_char_p]),
     "skr_comm_unique_id": (_int, [C.c_char_p]),
     "skr_comm_init": (_int, [_p, _int, _int, C.c_char_p]),
     "skr_comm_destroy": (_int, [_p]),
@@ -498,7 +500,7 @@ def pearson(ctx, c1, c2, row_standardize=True, precision=PREC_FP32, r=None):
 
 
 # ----------------------------------------------------------------------------- writers -----
-FMT_FIXED6, FMT_SCI18 = 0, 1  # np.savetxt fmt "%1.6f" (kmer_counts.py:241) / numpy's default "%.18e"
+FMT_FIXED6, FMT_SCI18, FMT_REPR = 0, 1, 2  # "%1.6f" (kmer_counts.py:241) / numpy's default "%.18e" / str(value)
 _NP_DTYPES = {np.dtype(np.float32): F32, np.dtype(np.float64): F64, np.dtype(np.uint32): U32}
 
 
@@ -534,6 +536,34 @@ def save_csv(path, a, fmt=FMT_FIXED6, threads=0):
         return
     check(lib().skr_host_save_csv(a.ctypes.data_as(_p), _NP_DTYPES[a.dtype], a.shape[0], a.shape[1], int(fmt),
                                   int(threads), path))
+
+
+def _joined_labels(labels, n):
+    """'\\n'-joined utf-8 labels, or None when they cannot be passed that way (then pandas writes)."""
+    labels = [str(x) for x in labels]
+    if len(labels) != n or any("\n" in x or "\r" in x or "\x00" in x for x in labels):
+        return None
+    return "\n".join(labels).encode("utf-8")
+
+
+def save_csv_labelled(path, a, index, columns, threads=0):
+    """DataFrame(a, index=index, columns=columns).to_csv(path) (kmer_counts.py:236-240) for a device
+    Matrix or a 2-D float32 / float64 array; anything the native writer does not cover goes to pandas."""
+    rows, cols = (a.rows, a.cols) if isinstance(a, Matrix) else np.shape(a)
+    rl, cl = _joined_labels(index, rows), _joined_labels(columns, cols)
+    native = rl is not None and cl is not None and rows > 0 and cols > 0
+    if native and isinstance(a, Matrix) and a.dtype != np.uint32:
+        check(lib().skr_mat_save_csv_labelled(a.ctx._h, a._h, rl, cl, int(threads), os.fspath(path).encode()))
+        return
+    if isinstance(a, Matrix):
+        a = a.to_numpy()
+    arr = np.ascontiguousarray(a)
+    if native and arr.ndim == 2 and arr.dtype in (np.float32, np.float64):
+        check(lib().skr_host_save_csv_labelled(arr.ctypes.data_as(_p), _NP_DTYPES[arr.dtype], rows, cols, rl, cl,
+                                               int(threads), os.fspath(path).encode()))
+        return
+    from pandas import DataFrame
+    DataFrame(data=a, index=index, columns=columns).to_csv(path)
 
 
 # ----------------------------------------------------------------------------- RCCL --------

@@ -101,9 +101,10 @@ def _run_pearson(counts1, counts2, outfile, binary_input, binary_output):
     if binary_output:
         pearson_mod.pearson(counts1, counts2, outfile=outfile)
     else:
-        import pandas as pd
         dist = pearson_mod.pearson(counts1, counts2)
-        pd.DataFrame(dist, names1, names2).to_csv(outfile)
+        # pd.DataFrame(dist, names1, names2).to_csv(outfile); names None -> RangeIndex labels 0..n-1
+        _lib.save_csv_labelled(outfile, dist, range(dist.shape[0]) if names1 is None else names1,
+                               range(dist.shape[1]) if names2 is None else names2)
 
 
 def console_pearson():

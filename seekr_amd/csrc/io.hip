@@ -8,7 +8,9 @@
 #include <algorithm>
 #include <cerrno>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <string>
 #include <thread>
 
 #include "common.hpp"
@@ -157,14 +159,130 @@ inline char* fmt_fixed6(char* p, float x) {
     return p + 6;
 }
 
+// ---- numpy's str() of a float scalar, which is what DataFrame.to_csv writes for a float column
+// (kmer_counts.py:238-240): the shortest digit string that reads back as the same float32 / float64,
+// positional for 1e-4 <= |x| < 1e16 (".0" appended to integers), else d.ddde+XX; NaN is the empty
+// field (na_rep), infinities "inf" / "-inf".  The shortest length is found by bisection over
+// "%.{p}e" (correctly rounded by glibc) + strtof/strtod round trip: if p digits identify the value,
+// so do p+1.
+inline bool reads_back(const char* s, float x) { return strtof(s, nullptr) == x; }
+inline bool reads_back(const char* s, double x) { return strtod(s, nullptr) == x; }
+
 template <typename T>
-size_t format_rows(const T* data, int64_t rows, int64_t cols, int fmt_mode, char* out) {
+inline char* fmt_repr(char* p, T x) {
+    constexpr int kMaxP = sizeof(T) == 4 ? 8 : 16;  // 9 / 17 significant digits always round-trip
+    if (std::isnan(x)) return p;
+    if (std::signbit(x)) *p++ = '-';
+    if (std::isinf(x)) {
+        memcpy(p, "inf", 3);
+        return p + 3;
+    }
+    const T a = std::fabs(x);
+    if (a == 0) {
+        memcpy(p, "0.0", 3);
+        return p + 3;
+    }
+    // A power of two sits at the bottom of its binade: the gap above it is twice the gap below, so a
+    // decimal one unit above the nearest p-digit one can still read back as x when the nearest (below)
+    // does not — numpy's Dragon4 finds it, so the bisection predicate tries it too.
+    int exp2;
+    const bool pow2 = std::frexp(a, &exp2) == (T)0.5;
+    char buf[48], digits[24];
+    int nd = 0, e10 = 0;
+    auto attempt = [&](int p) -> bool {  // leaves the accepted digits / exponent in digits, nd, e10
+        snprintf(buf, sizeof buf, "%.*e", p, (double)a);
+        const char* q = buf;
+        nd = 0;
+        for (; *q != 'e'; q++)
+            if (*q != '.') digits[nd++] = *q;
+        e10 = atoi(q + 1);
+        if (reads_back(buf, a)) return true;
+        if (!pow2) return false;
+        int i = nd - 1;  // digits + 1 unit in the last place
+        while (i >= 0 && digits[i] == '9') digits[i--] = '0';
+        if (i >= 0) {
+            digits[i]++;
+        } else {  // 99..9 -> 100..0
+            digits[0] = '1';
+            e10++;
+        }
+        char up[48];
+        int n = 0;
+        up[n++] = digits[0];
+        if (nd > 1) {
+            up[n++] = '.';
+            memcpy(up + n, digits + 1, nd - 1);
+            n += nd - 1;
+        }
+        snprintf(up + n, sizeof up - n, "e%d", e10);
+        return reads_back(up, a);
+    };
+    int lo = 0, hi = kMaxP;  // smallest p in [lo, hi] with a (p+1)-digit decimal that reads back as x
+    while (lo < hi) {
+        const int mid = (lo + hi) / 2;
+        if (attempt(mid)) hi = mid; else lo = mid + 1;
+    }
+    attempt(lo);
+    while (nd > 1 && digits[nd - 1] == '0') nd--;  // "%.{p}e" of the shortest p has no trailing zero, belt and braces
+    if ((double)a >= 1e16 || (double)a < 1e-4) {
+        *p++ = digits[0];
+        if (nd > 1) {
+            *p++ = '.';
+            memcpy(p, digits + 1, nd - 1);
+            p += nd - 1;
+        }
+        *p++ = 'e';
+        *p++ = e10 < 0 ? '-' : '+';
+        const int ae = e10 < 0 ? -e10 : e10;
+        if (ae < 10) *p++ = '0';
+        return put_u64(p, (uint64_t)ae);
+    }
+    if (e10 >= 0) {
+        for (int i = 0; i <= e10; i++) *p++ = i < nd ? digits[i] : '0';
+        *p++ = '.';
+        if (nd > e10 + 1) {
+            memcpy(p, digits + e10 + 1, nd - e10 - 1);
+            p += nd - e10 - 1;
+        } else {
+            *p++ = '0';
+        }
+    } else {
+        *p++ = '0';
+        *p++ = '.';
+        for (int i = 0; i < -e10 - 1; i++) *p++ = '0';
+        memcpy(p, digits, nd);
+        p += nd;
+    }
+    return p;
+}
+
+// pandas' csv.QUOTE_MINIMAL: quote a label that holds the delimiter, a quote or a line break
+inline char* put_label(char* p, const std::string& s) {
+    if (s.find_first_of(",\"\r\n") == std::string::npos) {
+        memcpy(p, s.data(), s.size());
+        return p + s.size();
+    }
+    *p++ = '"';
+    for (char c : s) {
+        if (c == '"') *p++ = '"';
+        *p++ = c;
+    }
+    *p++ = '"';
+    return p;
+}
+
+template <typename T>
+size_t format_rows(const T* data, int64_t rows, int64_t cols, int fmt_mode, const std::string* labels, char* out) {
     char* p = out;
     for (int64_t i = 0; i < rows; i++) {
         const T* row = data + (size_t)i * cols;
+        if (labels) {
+            p = put_label(p, labels[i]);
+            *p++ = ',';
+        }
         for (int64_t j = 0; j < cols; j++) {
             if (j) *p++ = ',';
-            p = fmt_mode == 0 ? fmt_fixed6(p, row[j]) : fmt_sci18(p, (double)row[j]);
+            p = fmt_mode == 0 ? fmt_fixed6(p, row[j]) : (fmt_mode == 1 ? fmt_sci18(p, (double)row[j]) : fmt_repr(p, row[j]));
         }
         *p++ = '\n';
     }
@@ -172,7 +290,10 @@ size_t format_rows(const T* data, int64_t rows, int64_t cols, int fmt_mode, char
 }
 
 // widest field: "%1.6f" of -FLT_MAX is 1 + 39 + 7 = 47 chars, of a double up to 1 + 309 + 7; "%.18e" is 26
-size_t field_width(int dtype, int fmt_mode) { return fmt_mode == 1 ? 28 : (dtype == SKR_F64 ? 320 : 48); }
+size_t field_width(int dtype, int fmt_mode) {
+    if (fmt_mode == 0) return dtype == SKR_F64 ? 320 : 48;
+    return 28;  // "%.18e" is 26; the shortest repr at most 1 + 17 + 16 zeros... positional tops out at 1e16: 20
+}
 
 // rows per formatting round: the text buffers are sized for the widest possible field, keep them ~128 MB
 int64_t chunk_rows_for(int dtype, int fmt_mode, int64_t cols) {
@@ -186,8 +307,10 @@ struct CsvFormatter {
     std::vector<std::vector<char>> bufs;
     std::vector<size_t> used;
     CsvFormatter(int dt, int fm, int th, int64_t c) : dtype(dt), fmt_mode(fm), threads(th), cols(c), bufs(th), used(th) {}
-    // format `rows` rows starting at `data` and append them to the file, in order
-    int run(const void* data, int64_t rows, FILE* fh, const char* path) {
+    const std::vector<std::string>* labels = nullptr;  // row labels (labelled CSV), indexed by global row
+    size_t max_label = 0;
+    // format `rows` rows starting at `data` (global row `row0`) and append them to the file, in order
+    int run(const void* data, int64_t rows, FILE* fh, const char* path, int64_t row0 = 0) {
         const int64_t per = (rows + threads - 1) / threads;
         const size_t w = field_width(dtype, fmt_mode) + 1;
         std::vector<std::thread> pool;
@@ -195,12 +318,13 @@ struct CsvFormatter {
             const int64_t r0 = std::min<int64_t>(rows, t * per), r1 = std::min<int64_t>(rows, r0 + per);
             used[t] = 0;
             if (r1 <= r0) continue;
-            bufs[t].resize((size_t)(r1 - r0) * ((size_t)cols * w + 1));
-            pool.emplace_back([this, data, r0, r1, t] {
+            bufs[t].resize((size_t)(r1 - r0) * ((size_t)cols * w + 2 + 2 * max_label + 3));
+            pool.emplace_back([this, data, r0, r1, t, row0] {
+                const std::string* lab = labels ? labels->data() + row0 + r0 : nullptr;
                 if (dtype == SKR_F64)
-                    used[t] = format_rows((const double*)data + (size_t)r0 * cols, r1 - r0, cols, fmt_mode, bufs[t].data());
+                    used[t] = format_rows((const double*)data + (size_t)r0 * cols, r1 - r0, cols, fmt_mode, lab, bufs[t].data());
                 else
-                    used[t] = format_rows((const float*)data + (size_t)r0 * cols, r1 - r0, cols, fmt_mode, bufs[t].data());
+                    used[t] = format_rows((const float*)data + (size_t)r0 * cols, r1 - r0, cols, fmt_mode, lab, bufs[t].data());
             });
         }
         for (auto& th : pool) th.join();
@@ -212,7 +336,7 @@ struct CsvFormatter {
 int pick_threads(int threads) {
     if (threads > 0) return std::min(threads, 256);
     const unsigned hc = std::thread::hardware_concurrency();
-    return (int)std::max(1u, std::min(hc ? hc : 8u, 32u));
+    return (int)std::max(1u, std::min(hc ? hc : 8u, 64u));
 }
 
 int check_host(const void* data, int dtype, int64_t rows, int64_t cols, const char* path) {
@@ -283,7 +407,7 @@ extern "C" int skr_host_save_csv(const void* data, int dtype, int64_t rows, int6
                                  const char* path) {
     SKR_TRY(check_host(data, dtype, rows, cols, path));
     SKR_REQUIRE(dtype != SKR_U32, "CSV output is for float matrices");
-    SKR_REQUIRE(fmt_mode == 0 || fmt_mode == 1, "fmt_mode must be 0 (%%1.6f) or 1 (%%.18e)");
+    SKR_REQUIRE(fmt_mode >= 0 && fmt_mode <= 2, "fmt_mode must be 0 (%%1.6f), 1 (%%.18e) or 2 (shortest repr)");
     File f;
     SKR_TRY(open_out(path, &f));
     CsvFormatter fmt(dtype, fmt_mode, pick_threads(threads), cols);
@@ -293,6 +417,77 @@ extern "C" int skr_host_save_csv(const void* data, int dtype, int64_t rows, int6
         SKR_TRY(fmt.run((const char*)data + (size_t)r0 * cols * (dtype == SKR_F64 ? 8 : 4), n, f.fh, path));
     }
     return SKR_OK;
+}
+
+namespace {
+std::vector<std::string> split_lines(const char* joined, int64_t expect, bool* ok) {
+    std::vector<std::string> out;
+    const char* s = joined ? joined : "";
+    if (expect > 0) {
+        for (const char* q = s;; q++) {
+            if (*q == '\n' || *q == 0) {
+                out.emplace_back(s, q - s);
+                s = q + 1;
+                if (*q == 0) break;
+            }
+        }
+    }
+    *ok = (int64_t)out.size() == expect;
+    return out;
+}
+
+int write_header_line(FILE* fh, const std::vector<std::string>& cols, const char* path) {
+    std::string line;
+    for (const auto& c : cols) {
+        line.push_back(',');
+        const size_t at = line.size();
+        line.resize(at + 2 * c.size() + 2);
+        char* end = put_label(&line[at], c);
+        line.resize(end - line.data());
+    }
+    line.push_back('\n');
+    return write_all(fh, line.data(), line.size(), path);
+}
+}  // namespace
+
+// DataFrame(data, index=row_labels, columns=col_labels).to_csv(path) (kmer_counts.py:236-240): labels are
+// '\n'-joined (labels themselves cannot hold a line break); a header line ",c0,c1,..." then one line per row.
+extern "C" int skr_host_save_csv_labelled(const void* data, int dtype, int64_t rows, int64_t cols, const char* row_labels,
+                                          const char* col_labels, int threads, const char* path) {
+    SKR_TRY(check_host(data, dtype, rows, cols, path));
+    SKR_REQUIRE(dtype != SKR_U32, "CSV output is for float matrices");
+    bool ok_r = false, ok_c = false;
+    const std::vector<std::string> rl = split_lines(row_labels, rows, &ok_r), cl = split_lines(col_labels, cols, &ok_c);
+    SKR_REQUIRE(ok_r && ok_c, "need %lld row labels and %lld column labels", (long long)rows, (long long)cols);
+    File f;
+    SKR_TRY(open_out(path, &f));
+    SKR_TRY(write_header_line(f.fh, cl, path));
+    CsvFormatter fmt(dtype, 2, pick_threads(threads), cols);
+    fmt.labels = &rl;
+    for (const auto& l : rl) fmt.max_label = std::max(fmt.max_label, l.size());
+    const int64_t chunk = chunk_rows_for(dtype, 2, cols);
+    for (int64_t r0 = 0; r0 < rows; r0 += chunk) {
+        const int64_t n = std::min(chunk, rows - r0);
+        SKR_TRY(fmt.run((const char*)data + (size_t)r0 * cols * (dtype == SKR_F64 ? 8 : 4), n, f.fh, path, r0));
+    }
+    return SKR_OK;
+}
+
+extern "C" int skr_mat_save_csv_labelled(skr_ctx* ctx, const skr_mat* m, const char* row_labels, const char* col_labels,
+                                         int threads, const char* path) {
+    SKR_REQUIRE(ctx && m && m->ctx == ctx && path, "NULL or foreign argument");
+    SKR_REQUIRE(m->dtype != SKR_U32, "CSV output is for float matrices");
+    bool ok_r = false, ok_c = false;
+    const std::vector<std::string> rl = split_lines(row_labels, m->rows, &ok_r), cl = split_lines(col_labels, m->cols, &ok_c);
+    SKR_REQUIRE(ok_r && ok_c, "need %lld row labels and %lld column labels", (long long)m->rows, (long long)m->cols);
+    File f;
+    SKR_TRY(open_out(path, &f));
+    SKR_TRY(write_header_line(f.fh, cl, path));
+    CsvFormatter fmt(m->dtype, 2, pick_threads(threads), m->cols);
+    fmt.labels = &rl;
+    for (const auto& l : rl) fmt.max_label = std::max(fmt.max_label, l.size());
+    return stream_rows(ctx, m, chunk_rows_for(m->dtype, 2, m->cols),
+                       [&](const void* host, int64_t row0, int64_t n) { return fmt.run(host, n, f.fh, path, row0); });
 }
 
 extern "C" int skr_mat_save_npy(skr_ctx* ctx, const skr_mat* m, int one_dim, const char* path) {
@@ -311,7 +506,7 @@ extern "C" int skr_mat_save_npy(skr_ctx* ctx, const skr_mat* m, int one_dim, con
 extern "C" int skr_mat_save_csv(skr_ctx* ctx, const skr_mat* m, int fmt_mode, int threads, const char* path) {
     SKR_REQUIRE(ctx && m && m->ctx == ctx && path, "NULL or foreign argument");
     SKR_REQUIRE(m->dtype != SKR_U32, "CSV output is for float matrices");
-    SKR_REQUIRE(fmt_mode == 0 || fmt_mode == 1, "fmt_mode must be 0 (%%1.6f) or 1 (%%.18e)");
+    SKR_REQUIRE(fmt_mode >= 0 && fmt_mode <= 2, "fmt_mode must be 0 (%%1.6f), 1 (%%.18e) or 2 (shortest repr)");
     File f;
     SKR_TRY(open_out(path, &f));
     CsvFormatter fmt(m->dtype, fmt_mode, pick_threads(threads), m->cols);

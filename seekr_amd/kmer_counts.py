@@ -250,10 +250,10 @@ class BasicCounter:
         if self.binary:
             _lib.save_npy(self.outfile, self.counts)  # np.save, streamed natively
         elif self.label:
-            from pandas import DataFrame
             if names is None:
                 names = self._packed.headers() if self._packed is not None else Reader(self.infasta).get_headers()
-            DataFrame(data=self.counts, index=names, columns=self.kmers).to_csv(self.outfile)
+            # DataFrame(data=self.counts, index=names, columns=self.kmers).to_csv(self.outfile), natively
+            _lib.save_csv_labelled(self.outfile, self.counts, names, self.kmers)
         else:
             _lib.save_csv(self.outfile, self.counts)  # np.savetxt(..., delimiter=",", fmt="%1.6f"), threaded
 

@@ -95,3 +95,60 @@ def test_device_matrices_stream_to_identical_files(L, tmp_path):
     np.savetxt(str(tmp_path / "want64.csv"), a[:50].astype(np.float64), delimiter=",")
     L.save_csv(str(tmp_path / "got64.csv"), d64, L.FMT_SCI18)
     assert filecmp.cmp(str(tmp_path / "want64.csv"), str(tmp_path / "got64.csv"), shallow=False)
+
+
+def repr_values(rng, n, dtype):
+    """Every regime of numpy's float str(): powers of two (asymmetric rounding interval), powers of
+    ten, the 1e-4 / 1e16 switch points, subnormals, short and long digit strings."""
+    info = np.finfo(dtype)
+    parts = [
+        hard_values(rng, n, dtype).astype(np.float64),
+        np.ldexp(1.0, np.arange(info.minexp - info.nmant, info.maxexp)),                    # all powers of two
+        np.ldexp(1.0, np.arange(info.minexp - info.nmant, info.maxexp)) * (1 + info.eps),   # and their successors
+        10.0 ** np.arange(-45 if dtype == np.float32 else -320, 39 if dtype == np.float32 else 308),
+        np.array([1e-4, 9.9999e-5, 1.00001e-4, 1e16, 9.999999e15, 1.0000001e16, 0.1, 0.3, 2.5, 1 / 3, 1e15, 123456789.0]),
+        rng.integers(1, 10 ** 6, n) / 10.0 ** rng.integers(0, 8, n),                        # short decimals
+        np.exp(rng.uniform(-100, 80, n)),
+    ]
+    with np.errstate(over="ignore", under="ignore"):
+        v = np.concatenate(parts).astype(dtype)
+    return np.concatenate([v, -v])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_repr_cells_equal_numpy_str(dtype, L, tmp_path):
+    """fmt_mode 2 == str(numpy scalar) for every value, NaN -> empty (pandas na_rep)."""
+    rng = np.random.default_rng(17)
+    v = repr_values(rng, 20000, dtype)
+    if dtype == np.float32:  # plus raw bit patterns
+        raw = rng.integers(0, 2 ** 32, 200000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+        v = np.concatenate([v, raw])
+    a = np.ascontiguousarray(v.reshape(1, -1))
+    got = str(tmp_path / "got.csv")
+    L.save_csv(got, a, L.FMT_REPR, threads=3)
+    cells = open(got).read().rstrip("\n").split(",")
+    want = ["" if np.isnan(x) else str(x) for x in v]
+    assert len(cells) == len(want)
+    bad = [(i, c, w) for i, (c, w) in enumerate(zip(cells, want)) if c != w]
+    assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_labelled_csv_bytes_equal_pandas(dtype, L, tmp_path):
+    import pandas as pd
+    rng = np.random.default_rng(5)
+    a = (rng.binomial(30, 0.1, size=(57, 64)) * np.float32(1000 / 1995)).astype(np.float32)
+    a = (np.log2(a + 1) - np.float32(0.731)).astype(dtype)
+    a[3, 4] = np.nan
+    a[5, 6] = np.inf
+    a[7, 8] = 1e-7
+    index = [">ENST%05d|gene,%d|\"q\" x" % (i, i) if i % 7 == 0 else ">ENST%05d.1|GENE%d" % (i, i) for i in range(57)]
+    columns = ["".join(p) for p in __import__("itertools").product("AGTC", repeat=3)]
+    want, got = str(tmp_path / "want.csv"), str(tmp_path / "got.csv")
+    pd.DataFrame(data=a, index=index, columns=columns).to_csv(want)
+    L.save_csv_labelled(got, a, index, columns, threads=4)
+    assert filecmp.cmp(want, got, shallow=False)
+    # RangeIndex-like labels (seekr_pearson with binary input writes names None -> 0..n-1)
+    pd.DataFrame(a[:, :57], None, None).to_csv(want)
+    L.save_csv_labelled(got, np.ascontiguousarray(a[:, :57]), range(57), range(57))
+    assert filecmp.cmp(want, got, shallow=False)
