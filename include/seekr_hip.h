@@ -262,6 +262,12 @@ int skr_comm_barrier(skr_ctx* ctx);
  * waited on by the compute stream with skr_comm_wait.                                       */
 int skr_comm_sendrecv(skr_ctx* ctx, const skr_mat* src, int64_t srow0, int64_t snrows, int dst_rank,
                       skr_mat* dst, int64_t drow0, int64_t dnrows, int src_rank, int64_t* ticket);
+/* all-gather of row shards of unequal size: rank g contributes `shard` (bounds[g+1]-bounds[g]
+ * rows) and every rank ends with all rows of `full` in global order.  One grouped RCCL
+ * operation: the sends to and receives from all P-1 peers are in flight together (one xGMI
+ * link per peer).  bounds: nranks+1 row offsets, bounds[0] == 0.                              */
+int skr_comm_allgather_rows(skr_ctx* ctx, const skr_mat* shard, skr_mat* full, const int64_t* bounds,
+                            int64_t* ticket);
 int skr_comm_wait(skr_ctx* ctx, int64_t ticket);
 /* all-reduce of a few host doubles (op: 0 = sum, 1 = max, 2 = min)                          */
 int skr_comm_allreduce_f64(skr_ctx* ctx, double* values, int n, int op);

@@ -87,6 +87,7 @@ SIGNATURES = {
     "skr_comm_destroy": (_int, [_p]),
     "skr_comm_barrier": (_int, [_p]),
     "skr_comm_sendrecv": (_int, [_p, _p, _i64, _i64, _int, _p, _i64, _i64, _int, C.POINTER(_i64)]),
+    "skr_comm_allgather_rows": (_int, [_p, _p, _p, C.POINTER(_i64), C.POINTER(_i64)]),
     "skr_comm_wait": (_int, [_p, _i64]),
     "skr_comm_allreduce_f64": (_int, [_p, C.POINTER(C.c_double), _int, _int]),
 }
@@ -581,6 +582,13 @@ def comm_sendrecv(ctx, src, srow0, snrows, dst_rank, dst, drow0, dnrows, src_ran
     ticket = _i64(-1)
     check(lib().skr_comm_sendrecv(ctx._h, _h(src), int(srow0), int(snrows), int(dst_rank), _h(dst), int(drow0),
                                   int(dnrows), int(src_rank), C.byref(ticket)))
+    return ticket.value
+
+
+def comm_allgather_rows(ctx, shard, full, bounds):
+    arr = (C.c_int64 * len(bounds))(*[int(b) for b in bounds])
+    ticket = _i64(-1)
+    check(lib().skr_comm_allgather_rows(ctx._h, shard._h, full._h, arr, C.byref(ticket)))
     return ticket.value
 
 

@@ -146,6 +146,48 @@ extern "C" int skr_comm_sendrecv(skr_ctx* ctx, const skr_mat* src, int64_t srow0
     return SKR_OK;
 }
 
+// All-gather of row shards of unequal size: rank g owns rows [bounds[g], bounds[g+1]) of `full`.
+// One ncclGroup holds the sends to and the receives from every peer, so all xGMI links of the GPU
+// carry traffic at once (the links are point-to-point: P-1 peers = P-1 links); the own shard is a
+// device copy on the same stream.
+extern "C" int skr_comm_allgather_rows(skr_ctx* ctx, const skr_mat* shard, skr_mat* full, const int64_t* bounds,
+                                       int64_t* ticket) {
+    SKR_TRY(need_comm(ctx));
+    SKR_REQUIRE(shard && full && bounds && shard->ctx == ctx && full->ctx == ctx, "NULL or foreign argument");
+    SKR_REQUIRE(shard->cols == full->cols && shard->elem() == full->elem(), "shard and full matrix differ in row layout");
+    const int P = ctx->nranks, me = ctx->rank;
+    for (int g = 0; g < P; g++) SKR_REQUIRE(bounds[g] <= bounds[g + 1], "bounds must not decrease");
+    SKR_REQUIRE(bounds[0] == 0 && bounds[P] <= full->rows, "bounds exceed the full matrix");
+    SKR_REQUIRE(shard->rows == bounds[me + 1] - bounds[me], "shard has %lld rows, bounds say %lld", (long long)shard->rows,
+                (long long)(bounds[me + 1] - bounds[me]));
+    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    const size_t rb = (size_t)full->cols * full->elem();
+    hipEvent_t ready;
+    SKR_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    SKR_HIP(hipEventRecord(ready, ctx->stream));
+    SKR_HIP(hipStreamWaitEvent(ctx->comm_stream, ready, 0));
+    SKR_HIP(hipEventDestroy(ready));
+    if (shard->rows && shard->data != (char*)full->data + (size_t)bounds[me] * rb)
+        SKR_HIP(hipMemcpyAsync((char*)full->data + (size_t)bounds[me] * rb, shard->data, (size_t)shard->rows * rb,
+                               hipMemcpyDeviceToDevice, ctx->comm_stream));
+    SKR_NCCL(g_api.GroupStart());
+    for (int s = 1; s < P; s++) {
+        const int dst = (me - s + P) % P, src = (me + s) % P;
+        if (shard->rows) SKR_NCCL(g_api.Send(shard->data, (size_t)shard->rows * rb, ncclUint8, dst, comm, ctx->comm_stream));
+        const int64_t n = bounds[src + 1] - bounds[src];
+        if (n)
+            SKR_NCCL(g_api.Recv((char*)full->data + (size_t)bounds[src] * rb, (size_t)n * rb, ncclUint8, src, comm,
+                                ctx->comm_stream));
+    }
+    SKR_NCCL(g_api.GroupEnd());
+    hipEvent_t done;
+    SKR_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    SKR_HIP(hipEventRecord(done, ctx->comm_stream));
+    ctx->tickets.push_back(done);
+    if (ticket) *ticket = (int64_t)ctx->tickets.size() - 1;
+    return SKR_OK;
+}
+
 extern "C" int skr_comm_wait(skr_ctx* ctx, int64_t ticket) {
     SKR_TRY(need_comm(ctx));
     SKR_REQUIRE(ticket >= 0 && ticket < (int64_t)ctx->tickets.size() && ctx->tickets[ticket], "unknown ticket");

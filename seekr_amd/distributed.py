@@ -91,6 +91,14 @@ class HipEngine:
         """r[row0+i, col0+j] = <a_i, b_j>/K and rt[trow0+j, tcol0+i] = the same value."""
         _lib.pearson_gemm_op_mirror(self.ctx, a, b, r, row0, col0, rt, trow0, tcol0)
 
+    def empty_block(self, rows, cols):
+        return self.ctx.empty(rows, cols)
+
+    def edges(self, r, cutoff, nrows, col_begin, col_end, row_global0, upper_only):
+        from seekr_amd import consumers
+        return consumers.edges(r, cutoff, nrows=nrows, col_begin=col_begin, col_end=col_end, row_global0=row_global0,
+                               upper_only=upper_only)
+
 
 class RcclComm:
     def __init__(self, ctx, rank, size):
@@ -110,6 +118,10 @@ class RcclComm:
         """send: an Operand (all rows go to dst); recv: an Operand buffer (rows [0, recv_rows) filled from src)."""
         return _lib.comm_sendrecv(self.ctx, send.as_matrix(), 0, send.rows, dst, recv.as_matrix(), 0, recv_rows, src)
 
+    def allgather_rows(self, shard, full, bounds):
+        """shard: this rank's Operand; full: an Operand of bounds[-1] rows; returns a ticket."""
+        return _lib.comm_allgather_rows(self.ctx, shard.as_matrix(), full.as_matrix(), bounds)
+
     def wait(self, ticket):
         _lib.comm_wait(self.ctx, ticket)
 
@@ -125,6 +137,9 @@ class SingleComm:
         return list(values)
 
     def barrier(self):
+        pass
+
+    def wait(self, ticket):
         pass
 
 
@@ -297,3 +312,52 @@ def sharded_pearson_symmetric(engine, comm, z, bounds, r_row, r_col, recv_bufs):
             p0 = bounds[peer] + b0
             engine.gemm_mirror(a, b, r_row, a0, p0, r_col, p0, a0)
     return owned_blocks(size, rank, bounds)
+
+
+# ------------------------------------------------------------------------------ edge lists ---
+def allgather_operand(engine, comm, z, bounds, full=None):
+    """Every rank ends with the prepared rows of all ranks, in global row order: one grouped RCCL
+    exchange with all P-1 peers at once (16 KiB per row at k = 6; config 5 is 65 GB in total, which
+    each 288 GB GPU can hold).  Returns the full operand (`z` itself on one GPU)."""
+    if comm.size == 1:
+        return z
+    full = engine.empty_operand(bounds[-1], engine.cols(z)) if full is None else full
+    comm.wait(comm.allgather_rows(z, full, bounds))
+    return full
+
+
+def stripes_of_rank(n_total, stripe_rows, size, rank):
+    """Row stripes [s0, s1) this rank reduces.  Stripes are dealt in zig-zag order (0..P-1, P-1..0,
+    ...): with upper_only the work of a stripe shrinks linearly with its index, and the zig-zag
+    keeps the ranks' totals within one stripe of each other."""
+    out = []
+    for t, s0 in enumerate(range(0, n_total, stripe_rows)):
+        lap, pos = divmod(t, size)
+        owner = pos if lap % 2 == 0 else size - 1 - pos
+        if owner == rank:
+            out.append((s0, min(n_total, s0 + stripe_rows)))
+    return out
+
+
+def sharded_pearson_edges(engine, comm, z, bounds, cutoff, stripe_rows=8192, upper_only=True, full=None):
+    """The edge list kmer_leiden builds from r (kmer_leiden.py:91-96: r < cutoff -> 0, zero diagonal,
+    non-zero cells are edges) for a row-sharded set, without ever holding an N x N matrix: the
+    operands are all-gathered once, then every rank produces and reduces its own row stripes of r
+    (stripe x columns at or right of the stripe when `upper_only`), no further communication.
+    Returns this rank's (rows, cols, vals) in row-major order of its stripes; the union over the
+    ranks is the edge list of the whole matrix."""
+    n_total = bounds[-1]
+    full = allgather_operand(engine, comm, z, bounds, full)
+    stripe_rows = max(1, min(int(stripe_rows), n_total))
+    buf = engine.empty_block(stripe_rows, n_total)
+    out = ([], [], [])
+    for s0, s1 in stripes_of_rank(n_total, stripe_rows, comm.size, comm.rank):
+        c0 = s0 if upper_only else 0
+        a = engine.view(full, s0, s1 - s0)
+        b = engine.view(full, c0, n_total - c0) if c0 else full
+        engine.gemm(a, b, buf, c0)
+        part = engine.edges(buf, cutoff, s1 - s0, c0, n_total, s0, upper_only)
+        for acc, p in zip(out, part):
+            acc.append(p)
+    return tuple(np.concatenate(p) if p else np.empty(0, dtype=d)
+                 for p, d in zip(out, (np.uint32, np.uint32, np.float32)))

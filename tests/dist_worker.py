@@ -86,7 +86,19 @@ class NumpyEngine:
         return self.row_standardize(y, op), has_nan
 
     def gemm(self, a, b, r, col0, symmetric=False):
-        r[:, col0:col0 + b.shape[0]] = np.inner(a, b) / a.shape[1]
+        r[:a.shape[0], col0:col0 + b.shape[0]] = np.inner(a, b) / a.shape[1]
+
+    def empty_block(self, rows, cols):
+        return np.zeros((rows, cols), dtype=np.float32)
+
+    def edges(self, r, cutoff, nrows, col_begin, col_end, row_global0, upper_only):
+        blk = r[:nrows, col_begin:col_end]
+        gi = row_global0 + np.arange(nrows)[:, None]
+        gj = col_begin + np.arange(col_end - col_begin)[None, :]
+        with np.errstate(invalid="ignore"):
+            keep = ~(blk < cutoff) & (blk != 0) & ((gj > gi) if upper_only else (gj != gi))
+        i, j = np.nonzero(keep)
+        return (row_global0 + i).astype(np.uint32), (col_begin + j).astype(np.uint32), blk[i, j]
 
     def gemm_mirror(self, a, b, r, row0, col0, rt, trow0, tcol0):
         blk = (np.inner(a, b) / a.shape[1]).astype(np.float32)
@@ -120,6 +132,19 @@ class GlooComm:
         self._pending[self._next] = works
         return self._next
 
+    def allgather_rows(self, shard, full, bounds):
+        full[bounds[self.rank]:bounds[self.rank + 1]] = shard
+        works = []
+        for s in range(1, self.size):
+            dst, src = (self.rank - s) % self.size, (self.rank + s) % self.size
+            if shard.shape[0]:
+                works.append(self.dist.isend(self.torch.from_numpy(np.ascontiguousarray(shard)), dst))
+            if bounds[src + 1] > bounds[src]:
+                works.append(self.dist.irecv(self.torch.from_numpy(full[bounds[src]:bounds[src + 1]]), src))
+        self._next += 1
+        self._pending[self._next] = works
+        return self._next
+
     def wait(self, ticket):
         for w in self._pending.pop(ticket):
             w.wait()
@@ -134,7 +159,7 @@ def run(rank, size, port, n_rows, n_cols, log2, out_dir, with_nan):
     import torch
     import torch.distributed as dist
     from seekr_amd.distributed import (shard_bounds, sharded_normalize, sharded_normalize_prepare,
-                                       sharded_pearson_rowblock, sharded_pearson_symmetric)
+                                       sharded_pearson_edges, sharded_pearson_rowblock, sharded_pearson_symmetric)
 
     dist.init_process_group("gloo", rank=rank, world_size=size)
     try:
@@ -161,7 +186,12 @@ def run(rank, size, port, n_rows, n_cols, log2, out_dir, with_nan):
         r_col = np.full((n_rows, hi - lo), np.float32(-7.0))
         with np.errstate(all="ignore"):
             blocks = sharded_pearson_symmetric(engine, comm, z, bounds, r_row, r_col, recv)
+        cutoff = 0.05
+        with np.errstate(all="ignore"):
+            e_up = sharded_pearson_edges(engine, comm, z, bounds, cutoff, stripe_rows=37, upper_only=True)
+            e_all = sharded_pearson_edges(engine, comm, z, bounds, cutoff, stripe_rows=50, upper_only=False)
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), x=x, mean=mean, std=std, r=r, r_row=r_row, r_col=r_col,
+                 e_up_i=e_up[0], e_up_j=e_up[1], e_up_v=e_up[2], e_all_i=e_all[0], e_all_j=e_all[1], e_all_v=e_all[2],
                  blocks=np.array([(0 if b[0] == "row" else 1,) + tuple(b[1:]) for b in blocks], dtype=np.int64),
                  has_nan=np.array(has_nan), lo=np.array(lo), hi=np.array(hi))
         comm.barrier()

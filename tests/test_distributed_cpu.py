@@ -82,6 +82,24 @@ def test_sharded_pipeline_matches_single_process(size, n_rows, log2, tmp_path):
     assert np.array_equal(bits(sym), bits(sym.T.copy()))
     owned = sum(int(nr) * int(nc) for p in parts for _, _, _, nr, nc, _, _ in p["blocks"])
     assert owned == n_rows * n_rows
+    # striped edge lists: the union over the ranks is the thresholded, zero-diagonal matrix's non-zeros
+    want = full_r.copy()
+    want[want < 0.05] = 0
+    np.fill_diagonal(want, 0)
+    for key, ref in (("e_all", want), ("e_up", np.triu(want, 1))):
+        got = np.zeros_like(want)
+        n_edges = 0
+        for p in parts:
+            i, j, v = p[key + "_i"], p[key + "_j"], p[key + "_v"]
+            assert not got[i, j].any()  # no cell reported twice
+            got[i, j] = v
+            n_edges += len(i)
+        assert n_edges > 0
+        # BLAS results differ in the last bit between a stripe and the full matrix: compare away from
+        # the cutoff (the GPU test compares bit for bit: its contraction does not depend on the tiling)
+        clear = np.abs(full_r - 0.05) > 1e-5
+        assert np.array_equal(got[clear] != 0, ref[clear] != 0)
+        assert np.allclose(got[clear], ref[clear], rtol=1e-5, atol=1e-6)
 
 
 def test_sharded_nan_propagation(tmp_path):
@@ -110,6 +128,20 @@ def test_half_ring_plan_tiles_the_matrix_once(size):
         if n_rows >= 7 * size:  # multiplications are balanced to within the raggedness of the shards
             assert max(work) <= 1.35 * min(work), (size, n_rows, work)
         assert len({len(half_ring_plan(size, r, bounds)) for r in range(size)}) == 1  # same number of shifts
+
+
+def test_stripes_are_dealt_once_and_balanced():
+    from seekr_amd.distributed import stripes_of_rank
+    for size in (1, 2, 3, 8):
+        for n, stripe in ((1000, 64), (8192 * 9 + 5, 8192), (10, 64)):
+            seen, work = [], []
+            for rank in range(size):
+                mine = stripes_of_rank(n, stripe, size, rank)
+                seen += mine
+                work.append(sum((s1 - s0) * (n - s0) for s0, s1 in mine))  # upper-only cells
+            assert sorted(seen) == [(s0, min(n, s0 + stripe)) for s0 in range(0, n, stripe)]
+            if n // stripe >= 4 * size:
+                assert max(work) - min(work) <= stripe * n
 
 
 def test_shard_bounds():

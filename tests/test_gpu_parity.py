@@ -580,6 +580,17 @@ def test_rccl_single_rank_plumbing(L):
             r2 = ctx.empty(300, 300)
             sharded_pearson_rowblock(eng, comm, z, shard_bounds(300, 1), r2, [None, None])
             assert np.allclose(r2.to_numpy(), r.to_numpy(), rtol=1e-6, atol=2e-7)
+            # grouped all-gather (1 rank: only the own-shard copy) and the striped edge list on top of it
+            full = eng.empty_operand(300, 1024)
+            comm.wait(comm.allgather_rows(z, full, [0, 300]))
+            r3 = ctx.empty(300, 300)
+            eng.gemm(full, full, r3, 0)
+            assert_bits(r3.to_numpy(), r.to_numpy(), "all-gathered operand")
+            from seekr_amd import consumers
+            from seekr_amd.distributed import sharded_pearson_edges
+            e1 = sharded_pearson_edges(eng, comm, z, [0, 300], 0.02, stripe_rows=64)
+            e2 = consumers.pearson_edges(z, 0.02, stripe_rows=128)
+            assert len(e1[0]) > 100 and all(np.array_equal(a, b) for a, b in zip(e1, e2))
     finally:
         ctx.close()
 
