@@ -83,6 +83,26 @@ def cpu_baseline(k, length, x_norm_head):
             "n_count": n_count, "n_pearson": n_p, "blas_threads": blas_threads}
 
 
+def pmc_traffic(kernel_key):
+    """HBM-side bytes per launch of a kernel from the committed rocprofv3 --pmc summary of this same
+    command (tools/profile.sh; counters cannot be collected inside the timed run): WRITE_SIZE as
+    reported, FETCH_SIZE doubled — gfx950 tallies the 128-byte requests of wide coalesced reads at
+    64 bytes (MI355X_MICROARCH.md, HBM).  None when no summary names the kernel."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.txt")), reverse=True):
+        vals, inside = {}, False
+        with open(path) as fh:
+            for line in fh:
+                if not line.startswith((" ", "#")):
+                    inside = kernel_key in line
+                elif inside and line.split()[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+                    vals[line.split()[0]] = float(line.split()[1]) * 1024.0  # KiB
+        if len(vals) == 2:
+            return {"bytes": 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"], "fetch_bytes_corrected": 2.0 * vals["FETCH_SIZE"],
+                    "write_bytes": vals["WRITE_SIZE"], "source": os.path.relpath(path, ROOT)}
+    return None
+
+
 def main():
     args = parse()
     rank, size, _ = launch.world()
@@ -160,18 +180,35 @@ def main():
         exec_pairs += float(n_loc) * (n_total - n_loc)
     gemm_ms_step = gemm["ms_total"] / steps
     gemm_avg_ms = gemm["ms_total"] / max(gemm["launches"], 1)
-    achieved_tf = 2.0 * n_cols * exec_pairs / (gemm_ms_step * 1e-3) / 1e12 if gemm_ms_step > 0 else 0.0
+    # 2*4^k flop per ORDERED pair delivered (what np.inner spends on it); the symmetric
+    # kernel multiplies only ~half of them, so the flops it really issues are reported next to it
+    delivered_pairs = float(n_loc) * n_total
+    achieved_tf = 2.0 * n_cols * delivered_pairs / (gemm_ms_step * 1e-3) / 1e12 if gemm_ms_step > 0 else 0.0
+    multiplied_tf = 2.0 * n_cols * exec_pairs / (gemm_ms_step * 1e-3) / 1e12 if gemm_ms_step > 0 else 0.0
     nprod = {"fp32": 1, "bf16x3": 3, "bf16x4": 4, "f16x3": 3}[args.precision]
     peak_tf = PEAK["fp32_mfma_tflops"] if args.precision == "fp32" else PEAK["bf16_mfma_tflops"]
+    # PMC traffic was collected on the default 1-GPU workload; it describes other shapes only by analogy
+    default_shape = size == 1 and not args.rows and length == 2000 and k == 6 and not args.no_symmetry
+    gemm_key = {"fp32": "pearson_gemm_f32_kernel", "bf16x3": "split16_kernelIDF16bLi3", "bf16x4": "split16_kernelIDF16bLi4",
+                "f16x3": "split16_kernelIDF16_Li3"}[args.precision]
+    gemm_traffic = pmc_traffic(gemm_key) if default_shape else None
+    count_traffic = pmc_traffic("count_kmers_kernel<0>") if default_shape else None
     roofline = {"kernel": gemm_name, "bound": "mfma", "achieved": round(achieved_tf, 2), "peak": peak_tf,
-                "unit": "TFLOP/s", "frac": round(achieved_tf / peak_tf, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved_tf / peak_tf, 4),
+                "traffic": round(gemm_traffic["bytes"] / 1e9, 2) if gemm_traffic else None,
+                "traffic_unit": "GB per launch (HBM-side: 2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)",
+                "traffic_detail": gemm_traffic,
+                "algorithmic_bytes_gb": round((2.0 * n_loc * n_cols * 4 + 4.0 * n_loc * n_total) / 1e9, 2),
                 "avg_launch_ms": round(gemm_avg_ms, 4), "launches_per_step": gemm["launches"] // max(steps, 1),
-                "mfma_executed_tflops": round(achieved_tf * nprod, 2),
-                "mfma_executed_frac": round(achieved_tf * nprod / peak_tf, 4),
-                "pairs_multiplied_per_step": exec_pairs, "pairs_delivered_per_step": float(n_loc) * n_total,
-                "note": "achieved = 2*4^k flop x pairs multiplied / kernel time (HIP events, summed over the "
-                        "step's launches); the split path issues {} 16-bit MFMA products per algorithmic product; "
-                        "symmetric self block: {}".format(nprod, sym)}
+                "multiplied_tflops": round(multiplied_tf, 2), "multiplied_frac": round(multiplied_tf / peak_tf, 4),
+                "mfma_executed_tflops": round(multiplied_tf * nprod, 2),
+                "mfma_executed_frac": round(multiplied_tf * nprod / peak_tf, 4),
+                "pairs_multiplied_per_step": exec_pairs, "pairs_delivered_per_step": delivered_pairs,
+                "note": "achieved = 2*4^k flop x ordered pairs delivered / kernel time (SURVEY 8d; HIP events, summed "
+                        "over the step's launches). r(j,i) = r(i,j): the kernel multiplies {:.3g} of the {:.3g} pairs it "
+                        "delivers (multiplied_*), and the split path issues {} 16-bit MFMA products per multiplication "
+                        "(mfma_executed_* = what the matrix cores really run, against the same dense peak)".format(
+                            exec_pairs, delivered_pairs, nprod)}
     # counting kernel: HBM bound, 0.25 B/base packed in + 4*4^k B per sequence out
     count_avg_ms = count["ms_total"] / max(count["launches"], 1)
     count_bytes = n_loc * (length * 0.25 + 8 + 4.0 * n_cols)
@@ -179,7 +216,9 @@ def main():
     mbases = n_loc * length / (count_avg_ms * 1e-3) / 1e6 if count_avg_ms > 0 else 0.0
     roofline_count = {"kernel": "count_kmers_f32", "bound": "hbm", "achieved": round(count_gbs, 1),
                       "peak": PEAK["hbm_gbs"], "unit": "GB/s", "frac": round(count_gbs / PEAK["hbm_gbs"], 4),
-                      "traffic": None, "avg_launch_ms": round(count_avg_ms, 4),
+                      "traffic": round(count_traffic["bytes"] / 1e9, 3) if count_traffic else None,
+                      "traffic_unit": "GB per launch", "traffic_detail": count_traffic,
+                      "algorithmic_bytes_gb": round(count_bytes / 1e9, 3), "avg_launch_ms": round(count_avg_ms, 4),
                       "bytes_per_base": round(count_bytes / (n_loc * length), 3)}
     out = {
         "metric": "Mbases/s k-mer counted + M seq-pairs/s Pearson, k=6, 1/2/4/8 GPU",

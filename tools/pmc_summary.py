@@ -11,8 +11,8 @@ acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
 for path in sorted(glob.glob(os.path.join(out_dir, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
     with open(path, newline="") as fh:
         for row in csv.DictReader(fh):
-            name = re.sub(r"^void ", "", row["Kernel_Name"])
-            name = re.sub(r"\(.*$", "", name)
+            name = re.sub(r"^void ", "", row["Kernel_Name"]).replace("(anonymous namespace)::", "")
+            name = re.sub(r"\(.*$", "", name)  # drop the argument list of demangled names
             cell = acc[name][row["Counter_Name"]]
             cell[0] += float(row["Counter_Value"])
             cell[1] += 1
