@@ -109,6 +109,8 @@ struct skr_operand {
     int precision = SKR_PREC_FP32;
     int kind = 0;  // 0 = float32 padded, 1 = bf16 halves, 2 = fp16 halves
     void* data = nullptr;
+    float* diag = nullptr;    // [rows] <z_i, z_i>/K, written by skr_operand_fill (not exchanged between GPUs)
+    bool diag_valid = false;  // false for buffers that only ever received rows from a peer
     bool owner = true;
     size_t row_bytes() const { return (size_t)kt * 128; }
 };

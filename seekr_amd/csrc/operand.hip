@@ -26,6 +26,7 @@ struct FillArgs {
     float shift;
     float* y;  // optional normalised-count output (may alias x)
     void* out;
+    float* diag;  // diag[r] = <z_r, z_r> / K from a float32 tree sum (see skr_pearson_gemm_op)
     uint32_t* flags;
 };
 
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(256) void operand_fill_kernel(FillArgs a) {
             sd = sqrtf(wave_sum(s) / kf);
         }
         // ---- pass 3: emit the operand row, 8 k per lane and step
+        float sq = 0.f;
         for (int64_t g = lane; g < a.kt * 4; g += 64) {
             const int64_t tile = g >> 2, sub = g & 3, k0 = tile * 32 + sub * 8;
             float z[8];
@@ -104,6 +106,7 @@ __global__ __launch_bounds__(256) void operand_fill_kernel(FillArgs a) {
                 float v = k < K ? row[k] : 0.f;
                 if (a.row_standardize && k < K) v = (v - mean) / sd;
                 z[j] = v;
+                sq += v * v;
             }
             if (sizeof(T) == 4) {
                 float* dst = reinterpret_cast<float*>(a.out) + (size_t)r * Kp + k0;
@@ -122,6 +125,8 @@ __global__ __launch_bounds__(256) void operand_fill_kernel(FillArgs a) {
                 *reinterpret_cast<vec8<T>*>(dst + 32) = lo;
             }
         }
+        sq = wave_sum(sq);
+        if (lane == 0) a.diag[r] = sq / (float)K;
     }
     if (any_nan) atomicOr(&a.flags[1], 1u);
 }
@@ -192,6 +197,11 @@ __global__ __launch_bounds__(256) void operand_fill_reg_kernel(FillArgs a) {
                 v[i].x /= sd; v[i].y /= sd; v[i].z /= sd; v[i].w /= sd;
             }
         }
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; i++) sq += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        sq = wave_sum(sq);
+        if (lane == 0) a.diag[r] = sq / (float)K;
 #pragma unroll
         for (int i = 0; i < VPL; i++) {
             const int64_t c = i * 256 + lane * 4;
@@ -213,6 +223,16 @@ __global__ __launch_bounds__(256) void operand_fill_reg_kernel(FillArgs a) {
         }
     }
     if (any_nan) atomicOr(&a.flags[1], 1u);
+}
+
+// r[i, i] of a self-comparison = <z_i, z_i> / K.  The contraction adds 4 096 squares into one float32
+// accumulator per cell in k order (as BLAS does in the reference, whose own diagonal is 4-6e-6 off
+// on rows with few distinct values); the tree sum taken while the operand was filled is accurate
+// to ~1e-7, so the diagonal is written from it after the contraction.
+__global__ __launch_bounds__(256) void patch_diag_kernel(float* __restrict__ C, int64_t ldc, const float* __restrict__ diag,
+                                                         int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) C[(size_t)i * ldc + i] = diag[i];
 }
 
 int vec_kind(const skr_mat* v, int64_t cols, const char* what, int* kind) {
@@ -259,13 +279,15 @@ extern "C" int skr_operand_create(skr_ctx* ctx, int64_t rows, int64_t cols, int 
     // (|dr| <= 2e-6 + 1e-5 |r|); below that the exact-product fp32 MFMA is used, where it is cheap.
     if (precision == SKR_PREC_FP32 || cols < 1024) op->kind = 0;
     else op->kind = precision == SKR_PREC_F16X3 ? 2 : 1;
-    size_t bytes = std::max<size_t>((size_t)rows * op->row_bytes(), 16);
+    const size_t body = ((size_t)rows * op->row_bytes() + 255) & ~(size_t)255;
+    const size_t bytes = body + std::max<size_t>((size_t)rows * sizeof(float), 16);  // rows, then diag[rows]
     hipError_t e = hipMalloc(&op->data, bytes);
     if (e != hipSuccess) {
         delete op;
         return skr_set_error(SKR_ERR_NOMEM, "hipMalloc(%zu bytes) for a %lld x %lld operand failed: %s", bytes,
                              (long long)rows, (long long)cols, hipGetErrorString(e));
     }
+    op->diag = reinterpret_cast<float*>((char*)op->data + body);
     *out = op;
     return SKR_OK;
 }
@@ -291,6 +313,7 @@ extern "C" int skr_operand_view(const skr_operand* parent, int64_t row0, int64_t
     v->rows = nrows;
     v->owner = false;
     v->data = (char*)parent->data + (size_t)row0 * parent->row_bytes();
+    v->diag = parent->diag ? parent->diag + row0 : nullptr;
     *out = v;
     return SKR_OK;
 }
@@ -330,6 +353,7 @@ extern "C" int skr_operand_fill(skr_ctx* ctx, const skr_mat* x, const skr_mat* c
     a.row_standardize = row_standardize != 0;
     a.y = y ? (float*)y->data : nullptr;
     a.out = op->data;
+    a.diag = op->diag;
     a.flags = ctx->d_flags;
     SKR_TRY(skr_activate(ctx));
     if (has_nan) *has_nan = 0;
@@ -382,6 +406,7 @@ extern "C" int skr_operand_fill(skr_ctx* ctx, const skr_mat* x, const skr_mat* c
 #undef LAUNCH
         SKR_HIP(hipGetLastError());
     }
+    op->diag_valid = true;
     if (has_nan) {
         SKR_HIP(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         SKR_HIP(hipStreamSynchronize(ctx->stream));
@@ -404,12 +429,20 @@ extern "C" int skr_pearson_gemm_op(skr_ctx* ctx, const skr_operand* a, const skr
     const int64_t M = a->rows, N = b->rows, K = a->cols;
     if (M == 0 || N == 0) return SKR_OK;
     float* C = (float*)r->data + (size_t)row0 * r->cols + col0;
+    const bool self = a->data == b->data && M == N;
     if (a->kind == 0) {
         const int64_t Kp = a->kt * 32;
-        return skr_launch_gemm_f32(ctx, (const float*)a->data, (const float*)b->data, C, M, N, Kp, Kp, Kp, r->cols, K);
+        SKR_TRY(skr_launch_gemm_f32(ctx, (const float*)a->data, (const float*)b->data, C, M, N, Kp, Kp, Kp, r->cols, K));
+    } else {
+        SKR_TRY(skr_launch_gemm_split(ctx, a->precision, a->data, b->data, C, M, N, a->kt, r->cols, K,
+                                      symmetric && self ? 1 : 0, nullptr, 0));
     }
-    const bool sym = symmetric && a->data == b->data && M == N;
-    return skr_launch_gemm_split(ctx, a->precision, a->data, b->data, C, M, N, a->kt, r->cols, K, sym ? 1 : 0, nullptr, 0);
+    if (self && a->diag_valid && a->diag) {
+        hipLaunchKernelGGL(patch_diag_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream, C, r->cols,
+                           a->diag, M);
+        SKR_HIP(hipGetLastError());
+    }
+    return SKR_OK;
 }
 
 extern "C" int skr_pearson_gemm_op_mirror(skr_ctx* ctx, const skr_operand* a, const skr_operand* b, skr_mat* r,

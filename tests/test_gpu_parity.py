@@ -579,7 +579,10 @@ def test_rccl_single_rank_plumbing(L):
             assert np.allclose(r.to_numpy(), orc.pearson(ref, ref), rtol=RTOL, atol=ATOL_R)
             r2 = ctx.empty(300, 300)
             sharded_pearson_rowblock(eng, comm, z, shard_bounds(300, 1), r2, [None, None])
-            assert np.allclose(r2.to_numpy(), r.to_numpy(), rtol=1e-6, atol=2e-7)
+            got2, got1 = r2.to_numpy(), r.to_numpy()   # r2: self block (diagonal from the z^2 tree sum), r: z x received copy
+            off_diag = ~np.eye(300, dtype=bool)
+            assert np.allclose(got2[off_diag], got1[off_diag], rtol=1e-6, atol=2e-7)
+            assert np.allclose(np.diag(got2), 1.0, rtol=0, atol=5e-7) and np.allclose(np.diag(got1), 1.0, rtol=0, atol=1e-5)
             # grouped all-gather (1 rank: only the own-shard copy) and the striped edge list on top of it
             full = eng.empty_operand(300, 1024)
             comm.wait(comm.allgather_rows(z, full, [0, 300]))
@@ -702,12 +705,12 @@ def test_default_precision_on_few_valued_rows(L, ctx):
                for p in ("f16x3", "bf16x3")}
         # off the diagonal: float32-grade, and far inside the absolute part of the bar
         assert err["f16x3"][off].max() < max(1.0e-6, 4 * ref_err[off].max()), (name, err["f16x3"][off].max())
-        # on it (r = 1): 4096 near-equal squares added into one float32 accumulator round the same
-        # way again and again — numpy's own result is 4-6e-6 from float64 here, the fp32 kernel
-        # 7e-6, the split kernels (384 sequential MFMA adds) up to 2e-5 on single rows while the
-        # mean stays < 1e-6.  Bounded, documented, not hidden.
-        assert err["f16x3"][~off].max() < 2.5e-5, (name, err["f16x3"][~off].max())
-        assert abs((np.diag(L.pearson(ctx, dev, dev, True, L.PREC_F16X3).to_numpy()).astype(np.float64) - 1.0).mean()) < 2e-6
+        # on it (r = 1): 4096 near-equal squares added into one float32 accumulator in k order round
+        # the same way again and again — numpy's own diagonal is 4-6e-6 from float64 here and a
+        # contraction's up to 2e-5 — so the diagonal of a self-comparison is written from the float32
+        # tree sum of z^2 taken while the operand is filled (operand.hip: patch_diag_kernel)
+        assert err["f16x3"][~off].max() < 1e-6, (name, err["f16x3"][~off].max())
+        assert err["bf16x3"][~off].max() < 1e-6, (name, err["bf16x3"][~off].max())
         assert err["f16x3"][off].max() <= err["bf16x3"][off].max(), name
 
 
