@@ -259,7 +259,7 @@ int skr_comm_barrier(skr_ctx* ctx);
 /* send rows [srow0, srow0+snrows) of `src` to `dst_rank` and receive rows into `dst` from
  * `src_rank` as one grouped RCCL operation on the ctx's communication stream; either side
  * may be skipped with rank < 0.  Completion is tracked per call: the returned ticket can be
- * waited on by the compute stream with skr_comm_wait.                                       */
+ * waited on (once) by the compute stream with skr_comm_wait.                                */
 int skr_comm_sendrecv(skr_ctx* ctx, const skr_mat* src, int64_t srow0, int64_t snrows, int dst_rank,
                       skr_mat* dst, int64_t drow0, int64_t dnrows, int src_rank, int64_t* ticket);
 /* all-gather of row shards of unequal size: rank g contributes `shard` (bounds[g+1]-bounds[g]

@@ -192,6 +192,9 @@ extern "C" int skr_comm_wait(skr_ctx* ctx, int64_t ticket) {
     SKR_TRY(need_comm(ctx));
     SKR_REQUIRE(ticket >= 0 && ticket < (int64_t)ctx->tickets.size() && ctx->tickets[ticket], "unknown ticket");
     SKR_HIP(hipStreamWaitEvent(ctx->stream, ctx->tickets[ticket], 0));
+    // a ticket is waited on once: the dependency is now in the compute stream, release the event
+    (void)hipEventDestroy(ctx->tickets[ticket]);
+    ctx->tickets[ticket] = nullptr;
     return SKR_OK;
 }
 
