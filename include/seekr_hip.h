@@ -250,6 +250,21 @@ int skr_mat_save_csv_labelled(skr_ctx* ctx, const skr_mat* m, const char* row_la
 int skr_host_save_csv_labelled(const void* data, int dtype, int64_t rows, int64_t cols, const char* row_labels,
                                const char* col_labels, int threads, const char* path);
 
+/* ---------------------------------------------------------------- CSV input ------------- */
+/* pd.read_csv(path, index_col=0) (console_scripts.py:626-631) for the labelled count files
+ * seekr_kmer_counts writes: float64 values [rows, cols] + row and column labels.  Only cells
+ * that pandas' own converter turns into the correctly rounded double are parsed (<= 15
+ * significant digits, <= 17 digit characters, decimal exponent within +-22, NA strings, inf);
+ * any other content returns SKR_ERR_UNSUPPORTED so that the caller can hand the file to pandas
+ * — a successful read is bit-identical to the reference's.  Labels come back '\n'-terminated:
+ * call skr_csv_labels with buf NULL to learn the size.  which: 0 = rows, 1 = columns.        */
+typedef struct skr_csv skr_csv;
+int skr_csv_read(const char* path, int threads, skr_csv** out);
+int skr_csv_shape(const skr_csv* csv, int64_t* rows, int64_t* cols);
+int skr_csv_values(const skr_csv* csv, double* out);
+int skr_csv_labels(const skr_csv* csv, int which, char* buf, int64_t cap, int64_t* needed);
+int skr_csv_free(skr_csv* csv);
+
 /* ---------------------------------------------------------------- multi-GPU (C1, C2) ---- */
 /* One process per GPU.  Rank 0 creates an id and distributes the 128 bytes out of band.    */
 int skr_comm_unique_id(char id[128]);

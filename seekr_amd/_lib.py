@@ -82,6 +82,11 @@ SIGNATURES = {
     "skr_host_save_csv": (_int, [_p, _int, _i64, _i64, _int, _int, C.c_char_p]),
     "skr_mat_save_csv_labelled": (_int, [_p, _p, C.c_char_p, C.c_char_p, _int, C.c_char_p]),
     "skr_host_save_csv_labelled": (_int, [_p, _int, _i64, _i64, C.c_char_p, C.c_char_p, _int, C.c_char_p]),
+    "skr_csv_read": (_int, [C.c_char_p, _int, C.POINTER(_p)]),
+    "skr_csv_shape": (_int, [_p, C.POINTER(_i64), C.POINTER(_i64)]),
+    "skr_csv_values": (_int, [_p, _p]),
+    "skr_csv_labels": (_int, [_p, _int, C.c_char_p, _i64, C.POINTER(_i64)]),
+    "skr_csv_free": (_int, [_p]),
     "skr_comm_unique_id": (_int, [C.c_char_p]),
     "skr_comm_init": (_int, [_p, _int, _int, C.c_char_p]),
     "skr_comm_destroy": (_int, [_p]),
@@ -565,6 +570,45 @@ def save_csv_labelled(path, a, index, columns, threads=0):
         return
     from pandas import DataFrame
     DataFrame(data=a, index=index, columns=columns).to_csv(path)
+
+
+def _looks_numeric(label):
+    try:
+        float(label)
+        return True
+    except ValueError:
+        return label.strip() == ""
+
+
+def load_csv_labelled(path, threads=0):
+    """pd.read_csv(path, index_col=0) (console_scripts.py:626-631) for the labelled count files this
+    package and the reference write: returns (values float64 [rows, cols], row_labels, col_labels),
+    or None when the file is outside the subset the native reader reproduces bit for bit (then the
+    caller uses pandas): see csv_read.hip."""
+    handle = _p()
+    rc = lib().skr_csv_read(os.fspath(path).encode(), int(threads), C.byref(handle))
+    if rc == -4:  # SKR_ERR_UNSUPPORTED
+        return None
+    check(rc)
+    try:
+        rows, cols = _i64(0), _i64(0)
+        check(lib().skr_csv_shape(handle, C.byref(rows), C.byref(cols)))
+        labels = []
+        for which in (0, 1):
+            need = _i64(0)
+            check(lib().skr_csv_labels(handle, which, None, 0, C.byref(need)))
+            buf = C.create_string_buffer(max(1, need.value))
+            check(lib().skr_csv_labels(handle, which, buf, need.value, C.byref(need)))
+            text = buf.raw[:need.value].decode("utf-8")
+            labels.append(text.split("\n")[:-1] if need.value else [])
+        # pandas would turn an all-numeric index into numbers and rename duplicate columns: not handled here
+        if (labels[0] and all(_looks_numeric(x) for x in labels[0])) or len(set(labels[1])) != len(labels[1]):
+            return None
+        values = np.empty((rows.value, cols.value), dtype=np.float64)
+        check(lib().skr_csv_values(handle, values.ctypes.data_as(_p)))
+        return values, labels[0], labels[1]
+    finally:
+        lib().skr_csv_free(handle)
 
 
 # ----------------------------------------------------------------------------- RCCL --------

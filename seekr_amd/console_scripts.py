@@ -87,17 +87,26 @@ def console_kmer_counts():
                      args.log2, args.remove_labels, args.mean_vector, args.std_vector, args.alphabet)
 
 
+def _read_labelled_csv(path):
+    """pd.read_csv(path, index_col=0) -> (float64 values, index labels): natively for the files the
+    count command writes, through pandas for anything the native reader declines (csv_read.hip)."""
+    native = _lib.load_csv_labelled(path)
+    if native is not None:
+        return native[0], np.array(native[1], dtype=object)
+    import pandas as pd
+    frame = pd.read_csv(path, index_col=0)
+    return frame, frame.index.values
+
+
 def _run_pearson(counts1, counts2, outfile, binary_input, binary_output):
     names1 = names2 = None
     if binary_input:
         counts1 = np.load(counts1)
         counts2 = np.load(counts2)
     else:  # labelled CSVs; float64 path (console_scripts.py:628-631)
-        import pandas as pd
-        counts1 = pd.read_csv(counts1, index_col=0)
-        counts2 = pd.read_csv(counts2, index_col=0)
-        names1 = counts1.index.values
-        names2 = counts2.index.values
+        same_file = counts1 == counts2
+        counts1, names1 = _read_labelled_csv(counts1)
+        counts2, names2 = (counts1, names1) if same_file else _read_labelled_csv(counts2)
     if binary_output:
         pearson_mod.pearson(counts1, counts2, outfile=outfile)
     else:

@@ -152,3 +152,82 @@ def test_labelled_csv_bytes_equal_pandas(dtype, L, tmp_path):
     pd.DataFrame(a[:, :57], None, None).to_csv(want)
     L.save_csv_labelled(got, np.ascontiguousarray(a[:, :57]), range(57), range(57))
     assert filecmp.cmp(want, got, shallow=False)
+
+
+def _frames_equal(native, df):
+    values, rows, cols = native
+    want = df.values.astype(np.float64)
+    assert values.shape == want.shape and values.dtype == np.float64
+    assert np.array_equal(values.view(np.uint64)[~np.isnan(want)], want.view(np.uint64)[~np.isnan(want)])  # bit for bit
+    assert np.array_equal(np.isnan(values), np.isnan(want))
+    assert rows == [str(x) for x in df.index] and cols == [str(x) for x in df.columns]
+
+
+def test_csv_reader_equals_pandas_on_count_files(L, tmp_path):
+    """pd.read_csv(path, index_col=0) on the files seekr_kmer_counts writes (labelled, float32 shortest
+    repr) and on %1.6f-style cells: values bit for bit, labels as text."""
+    import itertools
+    import pandas as pd
+    rng = np.random.default_rng(9)
+    a = (rng.binomial(30, 0.1, size=(211, 256)) * np.float32(1000 / 1995)).astype(np.float32)
+    a = (np.log2(a + 1) - np.float32(0.731)).astype(np.float32)
+    a[3, 4] = np.nan
+    a[5, 6] = np.inf
+    a[6, 6] = -np.inf
+    a[7, 8] = 1.5e-5
+    a[9, 9] = -0.0
+    index = [">ENST%05d|gene,%d|\"q\" x" % (i, i) if i % 7 == 0 else ">ENST%05d.1|GENE%d" % (i, i) for i in range(211)]
+    columns = ["".join(p) for p in itertools.product("AGTC", repeat=4)]
+    path = str(tmp_path / "counts.csv")
+    pd.DataFrame(a, index, columns).to_csv(path)
+    for threads in (1, 6):
+        native = L.load_csv_labelled(path, threads=threads)
+        assert native is not None
+        _frames_equal(native, pd.read_csv(path, index_col=0))
+    # CRLF line ends, no trailing newline, blank lines, integer-looking cells
+    text = open(path).read().replace("\n", "\r\n").rstrip("\r\n") + "\r\n\r\n"
+    text = text.replace(",0.0,", ",0,", 5)
+    crlf = str(tmp_path / "crlf.csv")
+    open(crlf, "w", newline="").write(text)
+    _frames_equal(L.load_csv_labelled(crlf), pd.read_csv(crlf, index_col=0))
+
+
+def test_csv_reader_declines_what_pandas_may_round_differently(L, tmp_path):
+    """Fields outside the exactly reproducible subset are not parsed natively (the caller falls back to
+    pandas), and inside it the reader equals pandas even where pandas is not correctly rounded elsewhere."""
+    import pandas as pd
+    head = ",c0,c1\n"
+    cases = {"17 digits": ">a,0.12345678901234567,1\n", "big exponent": ">a,1.5e-30,1\n", "text": ">a,hello,1\n",
+             "ragged": ">a,1\n", "18 digit chars": ">a,0.000000000000123456,1\n", "numeric index": "7,1.0,2.0\n"}
+    for name, row in cases.items():
+        p = str(tmp_path / "x.csv")
+        open(p, "w").write(head + row)
+        assert L.load_csv_labelled(p) is None, name
+    rng = np.random.default_rng(2)
+    cells = ["%.*e" % (int(rng.integers(0, 14)), x) for x in np.exp(rng.uniform(-60, 60, 20000))] + \
+            ["%.*f" % (int(rng.integers(0, 9)), x) for x in rng.standard_normal(20000) * 1000]
+    p = str(tmp_path / "mixed.csv")
+    with open(p, "w") as fh:
+        fh.write(",v\n")
+        for i, c in enumerate(cells):
+            fh.write(">r%d,%s\n" % (i, c))
+    native = L.load_csv_labelled(p)
+    if native is not None:  # every cell happened to be in the subset
+        _frames_equal(native, pd.read_csv(p, index_col=0))
+    ok = bad = 0
+    for c in cells[::40]:
+        q = _one(tmp_path, c)
+        nat = L.load_csv_labelled(q)
+        if nat is None:
+            bad += 1
+            continue
+        ok += 1
+        assert nat[0][0, 0].tobytes() == np.float64(pd.read_csv(q, index_col=0).values[0, 0]).tobytes(), c
+    assert ok > 300 and bad > 20
+
+
+def _one(tmp_path, cell):
+    q = str(tmp_path / "one.csv")
+    with open(q, "w") as fh:
+        fh.write(",v\n>r,%s\n" % cell)
+    return q
