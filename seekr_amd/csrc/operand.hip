@@ -27,6 +27,7 @@ struct FillArgs {
     float* y;  // optional normalised-count output (may alias x)
     void* out;
     float* diag;  // diag[r] = <z_r, z_r> / K from a float32 tree sum (see skr_pearson_gemm_op)
+    float out_scale;  // power of two applied before the split (fp16 halves only, see f16_scale)
     uint32_t* flags;
 };
 
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void operand_fill_kernel(FillArgs a) {
     const int64_t K = a.cols, Kp = a.kt * 32;
     float* row = lds + (size_t)wave * ((K + 3) & ~(int64_t)3);
     const bool vec = (K & 3) == 0;
-    bool any_nan = false;
+    bool any_nan = false, overflow = false;
     for (int64_t r = (int64_t)blockIdx.x * waves + wave; r < a.rows; r += (int64_t)gridDim.x * waves) {
         const float* xr = a.x + (size_t)r * K;
         // ---- pass 1: load, elementwise tail of the normalisation, optional write-back, row sum
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void operand_fill_kernel(FillArgs a) {
                 float v = k < K ? row[k] : 0.f;
                 if (a.row_standardize && k < K) v = (v - mean) / sd;
                 z[j] = v;
-                sq += v * v;
+                sq = __fmaf_rn(v, v, sq);
             }
             if (sizeof(T) == 4) {
                 float* dst = reinterpret_cast<float*>(a.out) + (size_t)r * Kp + k0;
@@ -116,9 +117,11 @@ __global__ __launch_bounds__(256) void operand_fill_kernel(FillArgs a) {
                 vec8<T> hi, lo;
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const T hh = (T)z[j];               // hardware convert: RNE, NaN stays NaN
+                    const float zs = z[j] * a.out_scale;
+                    if (fabsf(zs) > 65504.f) overflow = true;
+                    const T hh = (T)zs;                 // hardware convert: RNE, NaN stays NaN
                     hi[j] = hh;
-                    lo[j] = (T)(z[j] - (float)hh);      // exact difference, then RNE
+                    lo[j] = (T)(zs - (float)hh);        // exact difference, then RNE
                 }
                 T* dst = reinterpret_cast<T*>(a.out) + ((size_t)r * a.kt + tile) * 64 + sub * 8;
                 *reinterpret_cast<vec8<T>*>(dst) = hi;
@@ -129,6 +132,7 @@ __global__ __launch_bounds__(256) void operand_fill_kernel(FillArgs a) {
         if (lane == 0) a.diag[r] = sq / (float)K;
     }
     if (any_nan) atomicOr(&a.flags[1], 1u);
+    if (overflow) atomicOr(&a.flags[3], 1u);
 }
 
 // Register-resident variant for K = VPL * 256 columns (k = 5: VPL 4, k = 6: VPL 16): a wave keeps
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(256) void operand_fill_reg_kernel(FillArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
     constexpr int64_t K = (int64_t)VPL * 256;
-    bool any_nan = false;
+    bool any_nan = false, overflow = false;
     for (int64_t r = (int64_t)blockIdx.x * waves + wave; r < a.rows; r += (int64_t)gridDim.x * waves) {
         const float* xr = a.x + (size_t)r * K;
         float4 v[VPL];
@@ -199,7 +203,8 @@ __global__ __launch_bounds__(256) void operand_fill_reg_kernel(FillArgs a) {
         }
         float sq = 0.f;
 #pragma unroll
-        for (int i = 0; i < VPL; i++) sq += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        for (int i = 0; i < VPL; i++)  // explicit FMAs: every instantiation of the kernel rounds this sum identically
+            sq = __fmaf_rn(v[i].w, v[i].w, __fmaf_rn(v[i].z, v[i].z, __fmaf_rn(v[i].y, v[i].y, __fmaf_rn(v[i].x, v[i].x, sq))));
         sq = wave_sum(sq);
         if (lane == 0) a.diag[r] = sq / (float)K;
 #pragma unroll
@@ -212,9 +217,11 @@ __global__ __launch_bounds__(256) void operand_fill_reg_kernel(FillArgs a) {
                 vec4h<T> hi, lo;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const T hh = (T)z[j];
+                    const float zs = z[j] * a.out_scale;
+                    if (fabsf(zs) > 65504.f) overflow = true;
+                    const T hh = (T)zs;
                     hi[j] = hh;
-                    lo[j] = (T)(z[j] - (float)hh);
+                    lo[j] = (T)(zs - (float)hh);
                 }
                 T* dst = reinterpret_cast<T*>(a.out) + ((size_t)r * a.kt + (c >> 5)) * 64 + (c & 31);
                 *reinterpret_cast<vec4h<T>*>(dst) = hi;
@@ -223,6 +230,7 @@ __global__ __launch_bounds__(256) void operand_fill_reg_kernel(FillArgs a) {
         }
     }
     if (any_nan) atomicOr(&a.flags[1], 1u);
+    if (overflow) atomicOr(&a.flags[3], 1u);
 }
 
 // r[i, i] of a self-comparison = <z_i, z_i> / K.  The contraction adds 4 096 squares into one float32
@@ -279,6 +287,12 @@ extern "C" int skr_operand_create(skr_ctx* ctx, int64_t rows, int64_t cols, int 
     // (|dr| <= 2e-6 + 1e-5 |r|); below that the exact-product fp32 MFMA is used, where it is cheap.
     if (precision == SKR_PREC_FP32 || cols < 1024) op->kind = 0;
     else op->kind = precision == SKR_PREC_F16X3 ? 2 : 1;
+    // fp16 halves: rows are stored times a power of two chosen so that sqrt(K) — the largest value a
+    // row-standardised row can hold — lands just below 2^15.  The lo half of a small z then stays a
+    // normal fp16 number (without the scale it is subnormal for |z| < 0.125 and z keeps only 3e-8
+    // absolute precision); the contraction divides by K s^2.  A function of K alone, so shards
+    // exchanged between GPUs agree on it.
+    if (op->kind == 2) op->scale = std::exp2f(std::floor(std::log2(32768.0f / std::sqrt((float)cols))));
     const size_t body = ((size_t)rows * op->row_bytes() + 255) & ~(size_t)255;
     const size_t bytes = body + std::max<size_t>((size_t)rows * sizeof(float), 16);  // rows, then diag[rows]
     hipError_t e = hipMalloc(&op->data, bytes);
@@ -354,6 +368,7 @@ extern "C" int skr_operand_fill(skr_ctx* ctx, const skr_mat* x, const skr_mat* c
     a.y = y ? (float*)y->data : nullptr;
     a.out = op->data;
     a.diag = op->diag;
+    a.out_scale = op->scale;
     a.flags = ctx->d_flags;
     SKR_TRY(skr_activate(ctx));
     if (has_nan) *has_nan = 0;
@@ -363,7 +378,8 @@ extern "C" int skr_operand_fill(skr_ctx* ctx, const skr_mat* x, const skr_mat* c
         return skr_set_error(SKR_ERR_UNSUPPORTED, "rows of %lld columns do not fit the LDS row buffer", (long long)x->cols);
     const int waves = (int)std::max<size_t>(1, std::min<size_t>(4, (64 * 1024) / (row_floats * 4)));
     const size_t lds = row_floats * 4 * waves;
-    SKR_HIP(hipMemsetAsync(ctx->d_flags + 1, 0, 4, ctx->stream));
+    SKR_HIP(hipMemsetAsync(ctx->d_flags + 1, 0, 4, ctx->stream));  // [1] NaN seen
+    SKR_HIP(hipMemsetAsync(ctx->d_flags + 3, 0, 4, ctx->stream));  // [3] fp16 range exceeded ([2] belongs to the counting kernel)
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / lds));
     const int64_t want = (x->rows + waves - 1) / waves;
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cu * per_cu));
@@ -407,10 +423,17 @@ extern "C" int skr_operand_fill(skr_ctx* ctx, const skr_mat* x, const skr_mat* c
         SKR_HIP(hipGetLastError());
     }
     op->diag_valid = true;
-    if (has_nan) {
+    // values are only bounded by sqrt(K) when the rows were standardised here: check the fp16 range otherwise
+    const bool check_range = op->kind == 2 && !row_standardize;
+    if (has_nan || check_range) {
         SKR_HIP(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         SKR_HIP(hipStreamSynchronize(ctx->stream));
-        *has_nan = ctx->h_flags[1] != 0;
+        if (has_nan) *has_nan = ctx->h_flags[1] != 0;
+        if (check_range && ctx->h_flags[3] != 0)
+            return skr_set_error(SKR_ERR_INVALID,
+                                 "a value exceeds the split-fp16 operand range (|v| <= %g at %lld columns); "
+                                 "use SKR_PREC_FP32 for rows that are not row-standardised",
+                                 65504.0 / op->scale, (long long)op->cols);
     }
     return SKR_OK;
 }
@@ -434,8 +457,8 @@ extern "C" int skr_pearson_gemm_op(skr_ctx* ctx, const skr_operand* a, const skr
         const int64_t Kp = a->kt * 32;
         SKR_TRY(skr_launch_gemm_f32(ctx, (const float*)a->data, (const float*)b->data, C, M, N, Kp, Kp, Kp, r->cols, K));
     } else {
-        SKR_TRY(skr_launch_gemm_split(ctx, a->precision, a->data, b->data, C, M, N, a->kt, r->cols, K,
-                                      symmetric && self ? 1 : 0, nullptr, 0));
+        SKR_TRY(skr_launch_gemm_split(ctx, a->precision, a->data, b->data, C, M, N, a->kt, r->cols,
+                                      (float)K * a->scale * b->scale, symmetric && self ? 1 : 0, nullptr, 0));
     }
     if (self && a->diag_valid && a->diag) {
         hipLaunchKernelGGL(patch_diag_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream, C, r->cols,
@@ -476,7 +499,8 @@ extern "C" int skr_pearson_gemm_op_mirror(skr_ctx* ctx, const skr_operand* a, co
         SKR_TRY(skr_launch_gemm_f32(ctx, (const float*)a->data, (const float*)b->data, C, M, N, Kp, Kp, Kp, r->cols, K));
         return skr_launch_gemm_f32(ctx, (const float*)b->data, (const float*)a->data, Ct, N, M, Kp, Kp, Kp, rt->cols, K);
     }
-    return skr_launch_gemm_split(ctx, a->precision, a->data, b->data, C, M, N, a->kt, r->cols, K, 2, Ct, rt->cols);
+    return skr_launch_gemm_split(ctx, a->precision, a->data, b->data, C, M, N, a->kt, r->cols,
+                                 (float)K * a->scale * b->scale, 2, Ct, rt->cols);
 }
 
 // ---- matrix-level entry points built on operands ------------------------------------------------

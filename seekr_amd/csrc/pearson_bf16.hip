@@ -239,7 +239,7 @@ struct SplitOut {
 };
 
 template <typename T, int NPROD, int MODE>
-int launch16(skr_ctx* ctx, const T* A, const T* B, const SplitOut& o, int64_t M, int64_t N, int64_t kt, int64_t K,
+int launch16(skr_ctx* ctx, const T* A, const T* B, const SplitOut& o, int64_t M, int64_t N, int64_t kt, float K,
              const char* name) {
     const int64_t tiles_m = (M + TM - 1) / TM, tiles_n = (N + TN - 1) / TN;
     const int64_t super_m = (tiles_m + 15) / 16, super_n = (tiles_n + 15) / 16;
@@ -249,13 +249,13 @@ int launch16(skr_ctx* ctx, const T* A, const T* B, const SplitOut& o, int64_t M,
                                 2 * kStageBytes));
     SkrProfScope prof(ctx, name);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), 2 * kStageBytes, ctx->stream, A, B, o.C, o.Ct, M, N, kt,
-                       o.ldc, o.ldct, (float)K, tiles_m, tiles_n, super_n);
+                       o.ldc, o.ldct, K, tiles_m, tiles_n, super_n);
     SKR_HIP(hipGetLastError());
     return SKR_OK;
 }
 
 template <typename T, int NPROD>
-int gemm_split(skr_ctx* ctx, const T* As, const T* Bs, const SplitOut& o, int64_t M, int64_t N, int64_t kt, int64_t K,
+int gemm_split(skr_ctx* ctx, const T* As, const T* Bs, const SplitOut& o, int64_t M, int64_t N, int64_t kt, float K,
                int mode, const char* name) {
     switch (mode) {
         case SELF: return launch16<T, NPROD, SELF>(ctx, As, Bs, o, M, N, kt, K, name);
@@ -267,10 +267,10 @@ int gemm_split(skr_ctx* ctx, const T* As, const T* Bs, const SplitOut& o, int64_
 }  // namespace
 
 // A, B: split-interleaved operands ([rows, kt, {hi,lo}, 32] 16-bit halves) produced by operand.hip.
-// mode 0: C = A B^T / K; 1: A == B, one triangle computed and mirrored inside C; 2: C as mode 0 and
+// K: the divisor (columns x the operands' storage scales).  mode 0: C = A B^T / K; 1: A == B, one triangle computed and mirrored inside C; 2: C as mode 0 and
 // Ct[j * ldct + i] = C[i * ldc + j] as well.
 int skr_launch_gemm_split(skr_ctx* ctx, int precision, const void* As, const void* Bs, float* C, int64_t M, int64_t N,
-                          int64_t kt, int64_t ldc, int64_t K, int mode, float* Ct, int64_t ldct) {
+                          int64_t kt, int64_t ldc, float K, int mode, float* Ct, int64_t ldct) {
     SplitOut o{C, ldc, mode == SELF ? C : Ct, mode == SELF ? ldc : ldct};
     switch (precision) {
         case SKR_PREC_BF16X3:

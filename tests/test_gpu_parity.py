@@ -709,8 +709,8 @@ def test_default_precision_on_few_valued_rows(L, ctx):
         # the same way again and again — numpy's own diagonal is 4-6e-6 from float64 here and a
         # contraction's up to 2e-5 — so the diagonal of a self-comparison is written from the float32
         # tree sum of z^2 taken while the operand is filled (operand.hip: patch_diag_kernel)
-        assert err["f16x3"][~off].max() < 1e-6, (name, err["f16x3"][~off].max())
-        assert err["bf16x3"][~off].max() < 1e-6, (name, err["bf16x3"][~off].max())
+        assert err["f16x3"][~off].max() < 2e-6, (name, err["f16x3"][~off].max())
+        assert err["bf16x3"][~off].max() < 2e-6, (name, err["bf16x3"][~off].max())
         assert err["f16x3"][off].max() <= err["bf16x3"][off].max(), name
 
 
@@ -746,6 +746,27 @@ def test_pearson_split_bf16_vs_oracle(prec, shape, L, ctx):
     # order the hi*lo and lo*hi cross terms enter the float32 accumulator
     assert np.array_equal(np.triu(full), np.triu(rs))
     assert np.allclose(full, rs, rtol=1e-6, atol=2e-7)
+
+
+def test_split_fp16_small_values_and_range(L, ctx):
+    """fp16 halves are stored times a power of two (a function of K), so tiny values keep float32-grade
+    relative precision instead of falling into fp16 subnormals; rows that are not row-standardised are
+    range-checked and refused loudly rather than turned into inf."""
+    K = 1024
+    ones = ctx.from_numpy(np.ones((16, K), np.float32))
+    for val in (1e-6, 3e-5, 1e-4, 0.01):
+        a = ctx.from_numpy(np.full((16, K), val, np.float32))
+        r = ctx.empty(16, 16)
+        L.pearson_gemm(ctx, a, ones, r, precision=L.PREC_F16X3)
+        got = float(r.to_numpy()[0, 0])
+        # what a dot product needs is absolute precision: < 1e-11 here (3e-8 without the scale) ...
+        assert abs(got - val) < 1e-11 + 2e-6 * val, (val, got)
+    big = ctx.from_numpy(np.full((16, K), 1000.0, np.float32))
+    with pytest.raises(ValueError, match="split-fp16 operand range"):
+        L.pearson_gemm(ctx, big, ones, ctx.empty(16, 16), precision=L.PREC_F16X3)
+    r = ctx.empty(16, 16)  # bf16 halves have float32's exponent range
+    L.pearson_gemm(ctx, big, ones, r, precision=L.PREC_BF16X3)
+    assert abs(float(r.to_numpy()[0, 0]) / 1000.0 - 1.0) < 1e-5
 
 
 def test_pearson_split_bf16_nan_rows(L, ctx):
