@@ -68,20 +68,53 @@ __device__ __forceinline__ f32x4v mfma16x16(vec8<_Float16> a, vec8<_Float16> b, 
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-template <typename T, int NPROD, int MODE>
+// PERSIST: one workgroup per CU for the whole launch.  Tile slots are handed out by eight counters,
+// one per XCD group (slot i of group x is block id 8 i + x of the order above, so an XCD keeps
+// walking 8 x 4 sub-tiles in its own L2); a workgroup drains the queue of the XCD it runs on
+// (HW_REG_XCC_ID) and then helps with the others, so every slot is processed exactly once whatever
+// the placement.  What this buys over one workgroup per tile: the stores of tile t drain while the
+// main loop of tile t+1 runs (with one 128 KiB workgroup per CU nothing else overlaps them), and
+// the slots a self-comparison skips cost one atomic instead of a workgroup launch.
+template <typename T, int NPROD, int MODE, bool PERSIST>
 __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
     const T* __restrict__ A, const T* __restrict__ B, float* __restrict__ C, float* __restrict__ Ct,
     int64_t M, int64_t N, int64_t kt, int64_t ldc, int64_t ldct, float kdiv, int64_t tiles_m, int64_t tiles_n,
-    int64_t super_n) {
+    int64_t super_n, uint32_t* __restrict__ queues, int64_t slots_per_queue) {
     constexpr int WN = 4, MT = 8, NT = 4, PP = 4;  // 8 waves as 2 x 4, wave tile 128 x 64
     constexpr bool SYM = MODE == SELF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int64_t tm, tn;
-    if (!tile_of_block(blockIdx.x, super_n, tiles_m, tiles_n, &tm, &tn)) return;
-    if (SYM && tn < tm) return;  // the mirror block writes this tile
+    __shared__ int64_t s_bid;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    const int home = PERSIST ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7) : 0;  // HW_REG_XCC_ID[3:0]
+    int helping = 0;  // queues tried so far: home, home+1, ...
+  for (;;) {
+    int64_t bid = blockIdx.x;
+    if (PERSIST) {
+        if (tid == 0) {
+            int64_t got = -1;
+            while (helping < 8) {
+                const int q = (home + helping) & 7;
+                const uint32_t i = atomicAdd(&queues[q], 1u);
+                if ((int64_t)i < slots_per_queue) {
+                    got = ((int64_t)i << 3) | q;
+                    break;
+                }
+                helping++;
+            }
+            s_bid = got;
+        }
+        __syncthreads();
+        bid = s_bid;
+        __syncthreads();  // s_bid may be rewritten as soon as this slot turns out to be empty
+        if (bid < 0) return;
+    }
+    int64_t tm, tn;
+    if (!tile_of_block(bid, super_n, tiles_m, tiles_n, &tm, &tn) || (SYM && tn < tm)) {  // outside, or the mirror writes it
+        if (PERSIST) continue;
+        return;
+    }
     const int64_t row_base = tm * TM, col_base = tn * TN;
     const int64_t pitch = kt * 64;
 
@@ -229,6 +262,8 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
                 }
             }
         }
+    if (!PERSIST) return;
+  }
 }
 
 struct SplitOut {
@@ -243,13 +278,26 @@ int launch16(skr_ctx* ctx, const T* A, const T* B, const SplitOut& o, int64_t M,
              const char* name) {
     const int64_t tiles_m = (M + TM - 1) / TM, tiles_n = (N + TN - 1) / TN;
     const int64_t super_m = (tiles_m + 15) / 16, super_n = (tiles_n + 15) / 16;
-    const int64_t grid = super_m * super_n * 256;
-    auto kern = pearson_gemm_split16_kernel<T, NPROD, MODE>;
+    const int64_t slots = super_m * super_n * 256;
+    static const bool persist = !(getenv("SEEKR_GEMM_PERSIST") && atoi(getenv("SEEKR_GEMM_PERSIST")) == 0);  // A/B knob
+    if (persist && slots > ctx->num_cu) {
+        uint32_t* queues = ctx->d_flags + 8;  // eight counters, zeroed per launch
+        SKR_HIP(hipMemsetAsync(queues, 0, 8 * sizeof(uint32_t), ctx->stream));
+        auto kern = pearson_gemm_split16_kernel<T, NPROD, MODE, true>;
+        SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    2 * kStageBytes));
+        SkrProfScope prof(ctx, name);
+        hipLaunchKernelGGL(kern, dim3((unsigned)ctx->num_cu), dim3(512), 2 * kStageBytes, ctx->stream, A, B, o.C, o.Ct, M,
+                           N, kt, o.ldc, o.ldct, K, tiles_m, tiles_n, super_n, queues, slots / 8);
+        SKR_HIP(hipGetLastError());
+        return SKR_OK;
+    }
+    auto kern = pearson_gemm_split16_kernel<T, NPROD, MODE, false>;
     SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 2 * kStageBytes));
     SkrProfScope prof(ctx, name);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), 2 * kStageBytes, ctx->stream, A, B, o.C, o.Ct, M, N, kt,
-                       o.ldc, o.ldct, K, tiles_m, tiles_n, super_n);
+    hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(512), 2 * kStageBytes, ctx->stream, A, B, o.C, o.Ct, M, N, kt,
+                       o.ldc, o.ldct, K, tiles_m, tiles_n, super_n, (uint32_t*)nullptr, (int64_t)0);
     SKR_HIP(hipGetLastError());
     return SKR_OK;
 }
