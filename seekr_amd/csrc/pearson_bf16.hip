@@ -287,8 +287,14 @@ int launch16(skr_ctx* ctx, const T* A, const T* B, const SplitOut& o, int64_t M,
         SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     2 * kStageBytes));
         SkrProfScope prof(ctx, name);
-        hipLaunchKernelGGL(kern, dim3((unsigned)ctx->num_cu), dim3(512), 2 * kStageBytes, ctx->stream, A, B, o.C, o.Ct, M,
-                           N, kt, o.ldc, o.ldct, K, tiles_m, tiles_n, super_n, queues, slots / 8);
+        // A resident workgroup owns its CU outright (8 waves x ~248 VGPRs, 128 KiB LDS): with RCCL traffic
+        // in flight on the communication stream a few CUs are left free, or the send/recv kernels of
+        // shift s+1 could not start before this launch ends and the overlap of §5 would be lost.
+        static const int reserve_env = getenv("SEEKR_GEMM_RESERVE_CUS") ? atoi(getenv("SEEKR_GEMM_RESERVE_CUS")) : -1;
+        const int reserve = reserve_env >= 0 ? reserve_env : (ctx->nranks > 1 ? 8 : 0);
+        const unsigned grid = (unsigned)std::max(8, ctx->num_cu - reserve);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 2 * kStageBytes, ctx->stream, A, B, o.C, o.Ct, M, N, kt, o.ldc,
+                           o.ldct, K, tiles_m, tiles_n, super_n, queues, slots / 8);
         SKR_HIP(hipGetLastError());
         return SKR_OK;
     }
