@@ -12,6 +12,10 @@
 // 16-entry per-sequence table covers almost every bin), zeroes them for the next sequence, and
 // streams the dense row to HBM as 16-byte stores — the row write (4*4^k bytes per sequence) is
 // the algorithmic traffic that bounds this kernel.  Two barriers per sequence.
+//
+// k >= 8 (4^k bins no longer fit the LDS): the same kernel with GLOBAL = true counts straight into
+// the sequence's output row, used as a uint32 histogram in HBM (zeroed by a memset first, L2
+// atomics), and the flush converts the row in place.
 #include "common.hpp"
 
 namespace {
@@ -42,13 +46,14 @@ __device__ __forceinline__ double per_kb_value_f64(uint32_t n, double inc) {
 
 enum OutKind { OUT_F32 = 0, OUT_F32_LOG2 = 1, OUT_U32 = 2, OUT_F64 = 3 };
 
-template <int OUT>
+template <int OUT, bool GLOBAL>
 __global__ __launch_bounds__(kThreads) void count_kmers_kernel(
     const uint32_t* __restrict__ packed, const int64_t* __restrict__ word_off, const int64_t* __restrict__ len,
     const uint32_t* __restrict__ mask, const int64_t* __restrict__ mask_off, int64_t n_seqs, int k, void* __restrict__ out,
     uint32_t* __restrict__ flags) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_hist[];
     __shared__ float tab[kTabSize];  // 64 bytes: keeps the dynamic region 16-byte aligned
+    uint32_t* hist = lds_hist;       // GLOBAL: re-pointed at the output row of each sequence
     const int tid = threadIdx.x;
     const uint32_t nbins = 1u << (2 * k);
     const uint32_t idx_mask = nbins - 1u;
@@ -98,7 +103,8 @@ __global__ __launch_bounds__(kThreads) void count_kmers_kernel(
         n_m1 = mask[mb + 1];
     };
 
-    for (uint32_t b = tid * 4; b < nbins; b += kThreads * 4) *reinterpret_cast<uint4*>(&hist[b]) = make_uint4(0, 0, 0, 0);
+    if (!GLOBAL)
+        for (uint32_t b = tid * 4; b < nbins; b += kThreads * 4) *reinterpret_cast<uint4*>(&hist[b]) = make_uint4(0, 0, 0, 0);
     prefetch(blockIdx.x);
     __syncthreads();
 
@@ -107,6 +113,7 @@ __global__ __launch_bounds__(kThreads) void count_kmers_kernel(
         const uint32_t c_hi = n_hi, c_lo = n_lo, c_m0 = n_m0, c_m1 = n_m1;
         const int64_t W = L - k + 1;  // windows, counting every character (kmer_counts.py:143-144)
         if (W == 0 && tid == 0) atomicOr(&flags[2], 1u);  // ZeroDivisionError in the reference
+        if (GLOBAL) hist = reinterpret_cast<uint32_t*>(out) + (size_t)seq * nbins;  // 4-byte cells in every OUT handled here
         const int64_t n_win_words = W > 0 ? (W + 15) >> 4 : 0;
         // the sequence's output value for every small count (almost all bins): 16 threads do the
         // float64 work once, the flush just looks it up (visible after the barrier below)
@@ -147,7 +154,17 @@ __global__ __launch_bounds__(kThreads) void count_kmers_kernel(
             if (OUT == OUT_F32_LOG2) t = skr_log2_cr(t + 1.0f);
             return t;
         };
-        if (OUT == OUT_F64) {
+        if (GLOBAL) {
+            // the row holds this sequence's counts (written by L2 atomics: read them past the L1);
+            // uint32 output is already in place, float output is converted where it stands
+            if (OUT != OUT_U32) {
+                __threadfence();
+                for (uint32_t b = tid; b < nbins; b += kThreads) {
+                    const uint32_t c = __hip_atomic_load(&hist[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    reinterpret_cast<float*>(hist)[b] = value_of(c);
+                }
+            }
+        } else if (OUT == OUT_F64) {
             double* row = reinterpret_cast<double*>(out) + (size_t)seq * nbins;
             for (uint32_t b = tid; b < nbins; b += kThreads) {
                 row[b] = per_kb_value_f64(hist[b], inc);
@@ -175,8 +192,18 @@ __global__ __launch_bounds__(kThreads) void count_kmers_kernel(
 
 template <int OUT>
 int launch_count(skr_ctx* ctx, const skr_seqs* s, int k, void* out, const char* name) {
+    if (k > 7) {  // histogram in the output row itself
+        if (s->n < 1) return SKR_OK;
+        SKR_HIP(hipMemsetAsync(out, 0, (size_t)s->n * ((size_t)4 << (2 * k)), ctx->stream));
+        const int64_t grid = std::min<int64_t>(s->n, (int64_t)ctx->num_cu * 8);
+        SkrProfScope prof(ctx, name);
+        hipLaunchKernelGGL((count_kmers_kernel<OUT, true>), dim3((unsigned)grid), dim3(kThreads), 0, ctx->stream, s->d_packed,
+                           s->d_word_off, s->d_len, s->d_mask, s->d_mask_off, s->n, k, out, ctx->d_flags);
+        SKR_HIP(hipGetLastError());
+        return SKR_OK;
+    }
     const size_t lds = (size_t)4 << (2 * k);
-    SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(count_kmers_kernel<OUT>),
+    SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(count_kmers_kernel<OUT, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // as many resident workgroups as LDS allows, capped by the wave limit (8 x 256 threads / CU)
     int per_cu = (int)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1));
@@ -184,7 +211,7 @@ int launch_count(skr_ctx* ctx, const skr_seqs* s, int k, void* out, const char* 
     int64_t grid = std::min<int64_t>(s->n, (int64_t)ctx->num_cu * per_cu);
     if (grid < 1) return SKR_OK;
     SkrProfScope prof(ctx, name);
-    hipLaunchKernelGGL(count_kmers_kernel<OUT>, dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream, s->d_packed,
+    hipLaunchKernelGGL((count_kmers_kernel<OUT, false>), dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream, s->d_packed,
                        s->d_word_off, s->d_len, s->d_mask, s->d_mask_off, s->n, k, out, ctx->d_flags);
     SKR_HIP(hipGetLastError());
     return SKR_OK;
@@ -194,10 +221,7 @@ int check_count_args(skr_ctx* ctx, const skr_seqs* s, int k, const skr_mat* out)
     SKR_REQUIRE(ctx && s && out, "NULL argument");
     SKR_REQUIRE(s->ctx == ctx && out->ctx == ctx, "handles belong to a different ctx");
     SKR_REQUIRE(k >= 1, "k must be >= 1 (got %d)", k);
-    if (k > 7)
-        return skr_set_error(SKR_ERR_UNSUPPORTED,
-                             "k=%d needs a %d KiB histogram per sequence; the LDS path covers k <= 7", k,
-                             4 << (2 * k - 10));
+    if (k > 12) return skr_set_error(SKR_ERR_UNSUPPORTED, "k=%d: rows of 4^k columns are supported up to k = 12", k);
     SKR_REQUIRE(out->rows == s->n && out->cols == ((int64_t)1 << (2 * k)),
                 "output must be [%lld, %lld], got [%lld, %lld]", (long long)s->n, (long long)1 << (2 * k),
                 (long long)out->rows, (long long)out->cols);
@@ -222,7 +246,10 @@ extern "C" int skr_count_per_kb(skr_ctx* ctx, const skr_seqs* s, int k, int log2
     for (int64_t L : s->h_len)
         if (L == k - 1)
             return skr_set_error(SKR_ERR_ZERODIV, "division by zero (a sequence has length k-1 = %d)", k - 1);
-    if (out->dtype == SKR_F64) return launch_count<OUT_F64>(ctx, s, k, out->data, "count_kmers_f64");
+    if (out->dtype == SKR_F64) {
+        if (k > 7) return skr_set_error(SKR_ERR_UNSUPPORTED, "float64 count output is implemented for k <= 7");
+        return launch_count<OUT_F64>(ctx, s, k, out->data, "count_kmers_f64");
+    }
     if (log2_pre) return launch_count<OUT_F32_LOG2>(ctx, s, k, out->data, "count_kmers_f32_log2");
     return launch_count<OUT_F32>(ctx, s, k, out->data, "count_kmers_f32");
 }

@@ -135,6 +135,90 @@ __global__ __launch_bounds__(256) void operand_fill_kernel(FillArgs a) {
     if (overflow) atomicOr(&a.flags[3], 1u);
 }
 
+// Rows too wide for the LDS (k >= 8: 4^k floats = 256 KiB and up): one workgroup per row, four passes
+// over the row in global memory (it stays in the L2 between them).  A thread owns the same groups of
+// 8 consecutive columns in every pass, so the values it wrote to `y` in pass 1 are its own in the
+// later ones; without `y` the normalisation tail is simply recomputed from x.
+template <typename T>
+__global__ __launch_bounds__(256) void operand_fill_wide_kernel(FillArgs a) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t K = a.cols, Kp = a.kt * 32, groups = a.kt * 4;
+    bool any_nan = false, overflow = false;
+    auto block_sum = [&](float v) -> float {
+        v = wave_sum(v);
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        const float t = (red[0] + red[1]) + (red[2] + red[3]);
+        __syncthreads();
+        return t;
+    };
+    for (int64_t r = blockIdx.x; r < a.rows; r += gridDim.x) {
+        const float* xr = a.x + (size_t)r * K;
+        float* yr = a.y ? a.y + (size_t)r * K : nullptr;
+        bool scratch_nan = false;
+        auto val = [&](int64_t c) -> float { return yr ? yr[c] : fill_tail(a, xr[c], c, scratch_nan); };
+        float s = 0.f;
+        for (int64_t g = tid; g < groups; g += 256)
+            for (int64_t c = g * 8; c < std::min<int64_t>(K, g * 8 + 8); c++) {
+                const float v = fill_tail(a, xr[c], c, any_nan);
+                if (yr) yr[c] = v;
+                s += v;
+            }
+        float mean = 0.f, sd = 1.f;
+        if (a.row_standardize) {
+            const float kf = (float)K;
+            mean = block_sum(s) / kf;
+            s = 0.f;
+            for (int64_t g = tid; g < groups; g += 256)
+                for (int64_t c = g * 8; c < std::min<int64_t>(K, g * 8 + 8); c++) s += val(c) - mean;
+            const float m2 = block_sum(s) / kf;
+            s = 0.f;
+            for (int64_t g = tid; g < groups; g += 256)
+                for (int64_t c = g * 8; c < std::min<int64_t>(K, g * 8 + 8); c++) {
+                    const float d = (val(c) - mean) - m2;
+                    s += d * d;
+                }
+            sd = sqrtf(block_sum(s) / kf);
+        }
+        float sq = 0.f;
+        for (int64_t g = tid; g < groups; g += 256) {
+            const int64_t tile = g >> 2, sub = g & 3, k0 = g * 8;
+            float z[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int64_t k = k0 + j;
+                float v = k < K ? val(k) : 0.f;
+                if (a.row_standardize && k < K) v = (v - mean) / sd;
+                z[j] = v;
+                sq = __fmaf_rn(v, v, sq);
+            }
+            if (sizeof(T) == 4) {
+                float* dst = reinterpret_cast<float*>(a.out) + (size_t)r * Kp + k0;
+                *reinterpret_cast<float4*>(dst) = make_float4(z[0], z[1], z[2], z[3]);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(z[4], z[5], z[6], z[7]);
+            } else {
+                vec8<T> hi, lo;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float zs = z[j] * a.out_scale;
+                    if (fabsf(zs) > 65504.f) overflow = true;
+                    const T hh = (T)zs;
+                    hi[j] = hh;
+                    lo[j] = (T)(zs - (float)hh);
+                }
+                T* dst = reinterpret_cast<T*>(a.out) + ((size_t)r * a.kt + tile) * 64 + sub * 8;
+                *reinterpret_cast<vec8<T>*>(dst) = hi;
+                *reinterpret_cast<vec8<T>*>(dst + 32) = lo;
+            }
+        }
+        sq = block_sum(sq);
+        if (tid == 0) a.diag[r] = sq / (float)K;
+    }
+    if (any_nan) atomicOr(&a.flags[1], 1u);
+    if (overflow) atomicOr(&a.flags[3], 1u);
+}
+
 // Register-resident variant for K = VPL * 256 columns (k = 5: VPL 4, k = 6: VPL 16): a wave keeps
 // its whole row in VPL float4 registers per lane — all loads of a row are in flight together, no
 // LDS, no barrier, ~100 VGPRs so 20 waves per CU stay resident.  Lane l owns columns
@@ -285,7 +369,10 @@ extern "C" int skr_operand_create(skr_ctx* ctx, int64_t rows, int64_t cols, int 
     op->precision = precision;
     // The split error averages out like 1/sqrt(K): at K >= 1024 (k >= 5) it is inside the parity bar
     // (|dr| <= 2e-6 + 1e-5 |r|); below that the exact-product fp32 MFMA is used, where it is cheap.
-    if (precision == SKR_PREC_FP32 || cols < 1024) op->kind = 0;
+    // ... and above 16 384 columns (k >= 8) one float32 accumulator per cell over the whole of K drifts
+    // past the bar (1e-5 at K = 65 536 measured), so those shapes also take the fp32 kernel, whose
+    // accumulation is blocked.
+    if (precision == SKR_PREC_FP32 || cols < 1024 || cols > 16384) op->kind = 0;
     else op->kind = precision == SKR_PREC_F16X3 ? 2 : 1;
     // fp16 halves: rows are stored times a power of two chosen so that sqrt(K) — the largest value a
     // row-standardised row can hold — lands just below 2^15.  The lo half of a small z then stays a
@@ -374,8 +461,7 @@ extern "C" int skr_operand_fill(skr_ctx* ctx, const skr_mat* x, const skr_mat* c
     if (has_nan) *has_nan = 0;
     if (x->rows == 0) return SKR_OK;
     const size_t row_floats = (size_t)((x->cols + 3) & ~(int64_t)3);
-    if (row_floats * 4 > 150 * 1024)
-        return skr_set_error(SKR_ERR_UNSUPPORTED, "rows of %lld columns do not fit the LDS row buffer", (long long)x->cols);
+    const bool wide = row_floats * 4 > 150 * 1024;  // k >= 8: the row does not fit the LDS
     const int waves = (int)std::max<size_t>(1, std::min<size_t>(4, (64 * 1024) / (row_floats * 4)));
     const size_t lds = row_floats * 4 * waves;
     SKR_HIP(hipMemsetAsync(ctx->d_flags + 1, 0, 4, ctx->stream));  // [1] NaN seen
@@ -407,6 +493,13 @@ extern "C" int skr_operand_fill(skr_ctx* ctx, const skr_mat* x, const skr_mat* c
         else LAUNCH_REG(_Float16);
 #undef LAUNCH_REG
 #undef LAUNCH_REG2
+        SKR_HIP(hipGetLastError());
+    } else if (wide) {
+        SkrProfScope prof(ctx, "operand_fill");
+        const unsigned wgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(x->rows, (int64_t)ctx->num_cu * 8));
+        if (op->kind == 0) hipLaunchKernelGGL(operand_fill_wide_kernel<float>, dim3(wgrid), dim3(256), 0, ctx->stream, a);
+        else if (op->kind == 1) hipLaunchKernelGGL(operand_fill_wide_kernel<__bf16>, dim3(wgrid), dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(operand_fill_wide_kernel<_Float16>, dim3(wgrid), dim3(256), 0, ctx->stream, a);
         SKR_HIP(hipGetLastError());
     } else {
         SkrProfScope prof(ctx, "operand_fill");

@@ -537,9 +537,35 @@ def test_k7_pipeline_16384_columns(L, ctx):
         assert np.allclose(got, want, rtol=RTOL, atol=ATOL_R), (prec, np.abs(got - want).max())
     assert np.allclose(pearson(ref, ref[:100]), want[:, :100], rtol=RTOL, atol=ATOL_R)
     with pytest.raises(NotImplementedError):
-        run(seqs[:3], k=8, mean=False, std=False, log2="Log2.none")
+        run(seqs[:3], k=13, mean=False, std=False, log2="Log2.none")
     with pytest.raises(NotImplementedError):
         run(seqs[:3], k=3, mean=False, std=False, log2="Log2.none", alphabet="ACGTN")
+
+
+@pytest.mark.parametrize("k", [8, 9])
+def test_k8_and_up_global_histogram(k, L, ctx):
+    """k >= 8: 4^k bins no longer fit the LDS, the histogram lives in the output row (L2 atomics) and is
+    converted in place; rows of 65 536+ columns take the wide operand fill.  Same bars as every other k."""
+    from seekr_amd.pearson import pearson
+    seqs = orc.codes_to_seqs(orc.synthetic_codes(k, 60, 3000)) + ["ACGTN" * 700, "G" * 2500, "ACGT" * 3, "AC"]
+    n = L.count_u32(ctx, ctx.pack(seqs), k).to_numpy()
+    assert np.array_equal(n, orc.count_kmers_u32(seqs, k))
+    raw = orc.raw_counts(seqs, k)
+    assert_bits(run(seqs, k=k, mean=False, std=False, log2="Log2.none").counts, raw, "k=%d raw" % k)
+    c = run(seqs, k=k, log2="Log2.post", mean=True, std=True)
+    with np.errstate(all="ignore"):
+        ref, mean, std = orc.normalize(raw, log2="Log2.post")
+    assert_bits(c.mean, mean, "mean")
+    assert_bits(c.std, std, "std")
+    assert np.allclose(c.counts, ref, rtol=RTOL, atol=2e-6, equal_nan=True)
+    # Pearson on a NaN-free version (Log2.none, centred only): wide rows through every contraction
+    ref2, _, _ = orc.normalize(raw, mean=True, std=False, log2="Log2.none")
+    want = orc.pearson(ref2, ref2)
+    for prec in ("fp32", "f16x3", "bf16x3"):
+        d = ctx.from_numpy(ref2)
+        got = L.pearson(ctx, d, d, precision=L.PRECISIONS[prec]).to_numpy()
+        assert np.allclose(got, want, rtol=RTOL, atol=ATOL_R, equal_nan=True), (prec, np.nanmax(np.abs(got - want)))
+    assert np.allclose(pearson(ref2, ref2[:20]), want[:, :20], rtol=RTOL, atol=ATOL_R, equal_nan=True)
 
 
 # ------------------------------------------------------------------ RCCL plumbing on one rank
