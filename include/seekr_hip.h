@@ -225,6 +225,14 @@ int skr_edges(skr_ctx* ctx, const skr_mat* r, int64_t nrows, int64_t col_begin, 
               int64_t row_global0, int64_t col_global0, float cutoff, int upper_only, skr_mat* out_rows,
               skr_mat* out_cols, skr_mat* out_vals, int64_t* count);
 
+/* Per-row top-k of the block r[0:nrows, col_begin:col_end]: out_idx[i, t] / out_val[i, t] = global
+ * column and value of the t-th largest cell of row i (descending, ties to the smaller column,
+ * NaN last: np.argsort(-row, kind="stable")[:k]), the row's own diagonal cell (global column ==
+ * global row, as in skr_edges) excluded.  Rows with fewer than k candidates are padded with
+ * index 0xFFFFFFFF / NaN.  out_idx: SKR_U32, out_val: SKR_F32, each at least nrows * k cells.  */
+int skr_topk_rows(skr_ctx* ctx, const skr_mat* r, int64_t nrows, int64_t col_begin, int64_t col_end,
+                  int64_t row_global0, int64_t col_global0, int k, skr_mat* out_idx, skr_mat* out_val);
+
 /* ---------------------------------------------------------------- writers --------------- */
 /* The files the reference writes from the count matrix and from r, byte-identical to numpy's:
  *   skr_*_save_npy                   np.save(path, a)              kmer_counts.py:234, pearson.py:43

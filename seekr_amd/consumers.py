@@ -86,6 +86,21 @@ def edges(r, cutoff, nrows=None, col_begin=0, col_end=None, row_global0=0, col_g
     return res
 
 
+def topk_rows(r, k, nrows=None, col_begin=0, col_end=None, row_global0=0, col_global0=0):
+    """(idx uint32 [nrows, k], val float32 [nrows, k]): the k largest cells of each row of the device
+    block, descending, diagonal cell excluded — np.argsort(-row, kind="stable")[:k] per row."""
+    ctx = r.ctx
+    nrows = r.rows if nrows is None else nrows
+    col_end = r.cols if col_end is None else col_end
+    idx, val = ctx.empty(nrows, k, np.uint32), ctx.empty(nrows, k, np.float32)
+    _lib.check(_lib.lib().skr_topk_rows(ctx._h, r._h, int(nrows), int(col_begin), int(col_end), int(row_global0),
+                                        int(col_global0), int(k), idx._h, val._h))
+    out = idx.to_numpy(), val.to_numpy()
+    idx.free()
+    val.free()
+    return out
+
+
 def pearson_edges(z, cutoff, stripe_rows=8192, upper_only=True, engine_gemm=None):
     """Edge list of the self-comparison of the prepared operand `z` (seekr_amd._lib.Operand):
     r is produced one stripe of `stripe_rows` rows at a time into one reusable buffer (columns at or

@@ -156,6 +156,74 @@ __global__ __launch_bounds__(256) void edges_fill_kernel(EdgeArgs a, const unsig
     }
 }
 
+// ---- per-row top-k: the k largest cells of each row, descending, ties to the
+// smaller column — np.argsort(-row, kind="stable")[:k] with NaN last and the row's own (global)
+// diagonal cell excluded.  One workgroup per row; k selection passes over the row (it stays in the
+// L2): pass t finds the largest key below the t-1-th winner.  Keys order (value desc, column asc).
+__device__ __forceinline__ unsigned long long topk_key(float v, uint32_t col) {
+    // monotone map of the float to uint32 (larger float -> larger key), NaN to the smallest key;
+    // the low word prefers the smaller column on equal values
+    uint32_t b = __float_as_uint(v == 0.f ? 0.f : v);  // -0 and +0 compare equal
+    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    if (v != v) b = 0u;
+    return ((unsigned long long)b << 32) | (0xFFFFFFFFu - col);
+}
+
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ r, int64_t ld, int64_t rows,
+                                                        int64_t col_begin, int64_t col_end, int64_t row_global0,
+                                                        int64_t col_global0, int k, uint32_t* __restrict__ out_idx,
+                                                        float* __restrict__ out_val) {
+    __shared__ unsigned long long red[4];
+    __shared__ unsigned long long s_best;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t i = blockIdx.x; i < rows; i += gridDim.x) {
+        const float* row = r + (size_t)i * ld;
+        const int64_t skip = row_global0 + i - col_global0;  // local column of the diagonal cell, if any
+        unsigned long long bound = ~0ull;                     // keys must be strictly below this
+        for (int t = 0; t < k; t++) {
+            unsigned long long best = 0ull;
+            for (int64_t c = col_begin + threadIdx.x; c < col_end; c += 256) {
+                if (c == skip) continue;
+                const unsigned long long key = topk_key(row[c], (uint32_t)(c - col_begin));
+                if (key < bound && key > best) best = key;
+            }
+            for (int off = 32; off; off >>= 1) {
+                const unsigned long long o = __shfl_down(best, off, 64);
+                if (o > best) best = o;
+            }
+            if (lane == 0) red[wave] = best;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                unsigned long long b = red[0];
+                for (int w = 1; w < 4; w++) b = red[w] > b ? red[w] : b;
+                s_best = b;
+            }
+            __syncthreads();
+            best = s_best;
+            if (threadIdx.x == 0) {
+                if (best == 0ull) {  // fewer than k candidates in the row
+                    out_idx[(size_t)i * k + t] = 0xFFFFFFFFu;
+                    out_val[(size_t)i * k + t] = __uint_as_float(0x7FC00000u);
+                } else {
+                    const uint32_t c = 0xFFFFFFFFu - (uint32_t)best;
+                    out_idx[(size_t)i * k + t] = (uint32_t)(col_global0 + col_begin + c);
+                    out_val[(size_t)i * k + t] = row[col_begin + c];
+                }
+            }
+            bound = best;
+            if (best == 0ull) {  // nothing left: fill the remaining slots the same way
+                for (int u = t + 1; u < k; u++)
+                    if (threadIdx.x == 0) {
+                        out_idx[(size_t)i * k + u] = 0xFFFFFFFFu;
+                        out_val[(size_t)i * k + u] = __uint_as_float(0x7FC00000u);
+                    }
+                break;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 unsigned grid_for(const skr_ctx* ctx, int64_t items) {
     return (unsigned)std::max<int64_t>(1, std::min<int64_t>((items + 255) / 256, (int64_t)ctx->num_cu * 8));
 }
@@ -270,6 +338,27 @@ extern "C" int skr_edges(skr_ctx* ctx, const skr_mat* r, int64_t nrows, int64_t 
     SkrProfScope prof(ctx, "edges_fill");
     hipLaunchKernelGGL(edges_fill_kernel, dim3(grid), dim3(256), 0, ctx->stream, a, counts, (uint32_t*)out_rows->data,
                        (uint32_t*)out_cols->data, (float*)out_vals->data);
+    SKR_HIP(hipGetLastError());
+    return SKR_OK;
+}
+
+extern "C" int skr_topk_rows(skr_ctx* ctx, const skr_mat* r, int64_t nrows, int64_t col_begin, int64_t col_end,
+                             int64_t row_global0, int64_t col_global0, int k, skr_mat* out_idx, skr_mat* out_val) {
+    SKR_REQUIRE(ctx && r && out_idx && out_val, "NULL argument");
+    SKR_REQUIRE(r->ctx == ctx && out_idx->ctx == ctx && out_val->ctx == ctx, "foreign ctx");
+    SKR_REQUIRE(r->dtype == SKR_F32 && out_idx->dtype == SKR_U32 && out_val->dtype == SKR_F32, "r F32, out_idx U32, out_val F32");
+    SKR_REQUIRE(nrows >= 0 && nrows <= r->rows, "nrows out of range");
+    SKR_REQUIRE(col_begin >= 0 && col_begin <= col_end && col_end <= r->cols, "column range out of the matrix");
+    SKR_REQUIRE(k >= 1 && k <= 4096, "k must be in 1..4096");
+    SKR_REQUIRE(row_global0 >= 0 && col_global0 >= 0 && col_global0 + col_end <= 0xffffffffLL, "global indices must fit 32 bits");
+    SKR_REQUIRE(out_idx->rows * out_idx->cols >= nrows * k && out_val->rows * out_val->cols >= nrows * k,
+                "outputs must hold %lld cells", (long long)(nrows * k));
+    SKR_TRY(skr_activate(ctx));
+    if (nrows == 0) return SKR_OK;
+    SkrProfScope prof(ctx, "topk_rows");
+    hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)std::min<int64_t>(nrows, (int64_t)ctx->num_cu * 16)), dim3(256), 0,
+                       ctx->stream, (const float*)r->data, r->cols, nrows, col_begin, col_end, row_global0, col_global0, k,
+                       (uint32_t*)out_idx->data, (float*)out_val->data);
     SKR_HIP(hipGetLastError());
     return SKR_OK;
 }

@@ -123,3 +123,29 @@ def test_pearson_edges_striped_equals_full_matrix(ctx):
         wi, wj, wv = nonzero_edges(r, cutoff, upper)
         assert len(wi) > 1000
         assert np.array_equal(i, wi) and np.array_equal(j, wj) and np.array_equal(v, wv)
+
+
+@pytest.mark.parametrize("n,m,k", [(50, 50, 5), (301, 1000, 17), (64, 64, 80), (20, 3000, 1)])
+def test_topk_rows_matches_stable_argsort(n, m, k, ctx):
+    from seekr_amd import consumers
+    r = rand_r(n, m, seed=n + k)
+    r[:, 5] = r[:, 7]          # ties: the smaller column wins
+    r[3, 11] = np.nan          # NaN sorts last
+    r[4, :] = 0.25             # a constant row
+    idx, val = consumers.topk_rows(ctx.from_numpy(r), k)
+    for i in range(n):
+        row = r[i].copy()
+        cand = np.array([c for c in range(m) if c != i])          # the diagonal cell is excluded
+        order = cand[np.argsort(-row[cand], kind="stable")][:k]
+        want_idx = np.full(k, 0xFFFFFFFF, np.uint32)
+        want_idx[:len(order)] = order
+        assert np.array_equal(idx[i], want_idx), (i, idx[i][:8], want_idx[:8])
+        got = val[i][:len(order)]
+        assert np.array_equal(np.isnan(got), np.isnan(row[order])) and np.array_equal(np.nan_to_num(got), np.nan_to_num(row[order]))
+        assert np.isnan(val[i][len(order):]).all()
+    # a row block with global offsets: rows 10.., the diagonal sits at local column 10 + i
+    blk = ctx.from_numpy(r[10:20])
+    idx2, _ = consumers.topk_rows(blk, 3, row_global0=10)
+    for i in range(10):
+        cand = np.array([c for c in range(m) if c != 10 + i])
+        assert np.array_equal(idx2[i], cand[np.argsort(-r[10 + i][cand], kind="stable")][:3])
