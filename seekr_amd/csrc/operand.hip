@@ -135,15 +135,19 @@ __global__ __launch_bounds__(256) void operand_fill_kernel(FillArgs a) {
     if (overflow) atomicOr(&a.flags[3], 1u);
 }
 
-// Rows too wide for the LDS (k >= 8: 4^k floats = 256 KiB and up): one workgroup per row, four passes
-// over the row in global memory (it stays in the L2 between them).  A thread owns the same groups of
-// 8 consecutive columns in every pass, so the values it wrote to `y` in pass 1 are its own in the
-// later ones; without `y` the normalisation tail is simply recomputed from x.
-template <typename T>
-__global__ __launch_bounds__(256) void operand_fill_wide_kernel(FillArgs a) {
+// One WORKGROUP per row, for rows of 32 KiB and more (k >= 7), where a wave-private LDS slice would
+// leave one or two waves per CU.  IN_LDS: the row is parked in LDS between the passes (k = 7: 64 KiB,
+// two workgroups per CU); otherwise (k >= 8: 256 KiB and up) the later passes re-read it from global
+// memory, where it stays in the L2.  A thread owns the same groups of 8 consecutive columns in every
+// pass, so what it parked (in LDS, or in `y`) in pass 1 is its own later on; without `y` and without
+// LDS the normalisation tail is simply recomputed from x.
+template <typename T, bool IN_LDS>
+__global__ __launch_bounds__(256) void operand_fill_block_kernel(FillArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float rowbuf[];
     __shared__ float red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t K = a.cols, Kp = a.kt * 32, groups = a.kt * 4;
+    const bool vec = (K & 7) == 0;
     bool any_nan = false, overflow = false;
     auto block_sum = [&](float v) -> float {
         v = wave_sum(v);
@@ -157,14 +161,41 @@ __global__ __launch_bounds__(256) void operand_fill_wide_kernel(FillArgs a) {
         const float* xr = a.x + (size_t)r * K;
         float* yr = a.y ? a.y + (size_t)r * K : nullptr;
         bool scratch_nan = false;
-        auto val = [&](int64_t c) -> float { return yr ? yr[c] : fill_tail(a, xr[c], c, scratch_nan); };
+        auto val = [&](int64_t c) -> float {
+            if (IN_LDS) return rowbuf[c];
+            return yr ? yr[c] : fill_tail(a, xr[c], c, scratch_nan);
+        };
         float s = 0.f;
-        for (int64_t g = tid; g < groups; g += 256)
-            for (int64_t c = g * 8; c < std::min<int64_t>(K, g * 8 + 8); c++) {
-                const float v = fill_tail(a, xr[c], c, any_nan);
-                if (yr) yr[c] = v;
-                s += v;
+        for (int64_t g = tid; g < groups; g += 256) {
+            const int64_t c0 = g * 8;
+            if (vec) {
+                float4 u = *reinterpret_cast<const float4*>(xr + c0), w = *reinterpret_cast<const float4*>(xr + c0 + 4);
+                u.x = fill_tail(a, u.x, c0, any_nan);
+                u.y = fill_tail(a, u.y, c0 + 1, any_nan);
+                u.z = fill_tail(a, u.z, c0 + 2, any_nan);
+                u.w = fill_tail(a, u.w, c0 + 3, any_nan);
+                w.x = fill_tail(a, w.x, c0 + 4, any_nan);
+                w.y = fill_tail(a, w.y, c0 + 5, any_nan);
+                w.z = fill_tail(a, w.z, c0 + 6, any_nan);
+                w.w = fill_tail(a, w.w, c0 + 7, any_nan);
+                if (yr) {
+                    *reinterpret_cast<float4*>(yr + c0) = u;
+                    *reinterpret_cast<float4*>(yr + c0 + 4) = w;
+                }
+                if (IN_LDS) {
+                    *reinterpret_cast<float4*>(rowbuf + c0) = u;
+                    *reinterpret_cast<float4*>(rowbuf + c0 + 4) = w;
+                }
+                s += ((u.x + u.y) + (u.z + u.w)) + ((w.x + w.y) + (w.z + w.w));
+            } else {
+                for (int64_t c = c0; c < std::min<int64_t>(K, c0 + 8); c++) {
+                    const float v = fill_tail(a, xr[c], c, any_nan);
+                    if (yr) yr[c] = v;
+                    if (IN_LDS) rowbuf[c] = v;
+                    s += v;
+                }
             }
+        }
         float mean = 0.f, sd = 1.f;
         if (a.row_standardize) {
             const float kf = (float)K;
@@ -212,7 +243,7 @@ __global__ __launch_bounds__(256) void operand_fill_wide_kernel(FillArgs a) {
                 *reinterpret_cast<vec8<T>*>(dst + 32) = lo;
             }
         }
-        sq = block_sum(sq);
+        sq = block_sum(sq);  // its barriers also fence the LDS row against the next row's pass 1
         if (tid == 0) a.diag[r] = sq / (float)K;
     }
     if (any_nan) atomicOr(&a.flags[1], 1u);
@@ -494,12 +525,25 @@ extern "C" int skr_operand_fill(skr_ctx* ctx, const skr_mat* x, const skr_mat* c
 #undef LAUNCH_REG
 #undef LAUNCH_REG2
         SKR_HIP(hipGetLastError());
-    } else if (wide) {
+    } else if (row_floats * 4 >= 32 * 1024) {  // k >= 7: one workgroup per row
         SkrProfScope prof(ctx, "operand_fill");
-        const unsigned wgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(x->rows, (int64_t)ctx->num_cu * 8));
-        if (op->kind == 0) hipLaunchKernelGGL(operand_fill_wide_kernel<float>, dim3(wgrid), dim3(256), 0, ctx->stream, a);
-        else if (op->kind == 1) hipLaunchKernelGGL(operand_fill_wide_kernel<__bf16>, dim3(wgrid), dim3(256), 0, ctx->stream, a);
-        else hipLaunchKernelGGL(operand_fill_wide_kernel<_Float16>, dim3(wgrid), dim3(256), 0, ctx->stream, a);
+        const size_t blds = wide ? 0 : row_floats * 4;
+        const int64_t bper_cu = wide ? 8 : std::max<int64_t>(1, (int64_t)((150 * 1024) / blds));
+        const unsigned wgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(x->rows, (int64_t)ctx->num_cu * bper_cu));
+#define LAUNCH_BLOCK(T)                                                                                           \
+    do {                                                                                                          \
+        if (wide) {                                                                                               \
+            hipLaunchKernelGGL((operand_fill_block_kernel<T, false>), dim3(wgrid), dim3(256), 0, ctx->stream, a);  \
+        } else {                                                                                                  \
+            SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(operand_fill_block_kernel<T, true>),        \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));                  \
+            hipLaunchKernelGGL((operand_fill_block_kernel<T, true>), dim3(wgrid), dim3(256), blds, ctx->stream, a); \
+        }                                                                                                         \
+    } while (0)
+        if (op->kind == 0) LAUNCH_BLOCK(float);
+        else if (op->kind == 1) LAUNCH_BLOCK(__bf16);
+        else LAUNCH_BLOCK(_Float16);
+#undef LAUNCH_BLOCK
         SKR_HIP(hipGetLastError());
     } else {
         SkrProfScope prof(ctx, "operand_fill");
