@@ -3,6 +3,7 @@
 // a "ticket" (HIP event) lets the compute stream wait for one specific exchange, which is how
 // the Pearson row-block schedule overlaps the arrival of shard s+1 with the GEMM on shard s.
 #include <dlfcn.h>
+#include <cstdlib>
 #include <cstring>
 #include <rccl/rccl.h>
 
@@ -27,11 +28,15 @@ RcclApi g_api;
 
 int load_rccl() {
     if (g_api.handle) return SKR_OK;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // SEEKR_RCCL_LIB: test hook — tests/mock_rccl stands in for RCCL so that several ranks can share the
+    // one GPU of a test box (RCCL refuses that); never set in production
+    const char* override_path = getenv("SEEKR_RCCL_LIB");
+    const char* names[] = {override_path ? override_path : "librccl.so.1", "librccl.so.1", "librccl.so",
+                           "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
     for (const char* n : names) {
         h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (h) break;
+        if (h || override_path) break;  // an override that does not load is an error, not a fallback
     }
     if (!h) return skr_set_error(SKR_ERR_COMM, "cannot load librccl: %s", dlerror());
 #define SYM(field, name)                                                          \

@@ -21,6 +21,8 @@ def world():
     rank = int(os.environ.get("RANK", "0"))
     size = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if "SEEKR_FORCE_DEVICE" in os.environ:  # test hook: several ranks on one GPU (with tests/mock_rccl)
+        local = int(os.environ["SEEKR_FORCE_DEVICE"])
     return rank, size, local
 
 

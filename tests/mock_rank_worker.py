@@ -1,0 +1,43 @@
+"""One rank of the multi-rank-on-one-GPU test: the production stack (launch.init -> RcclComm ->
+HipEngine -> seekr_amd.distributed) with tests/mock_rccl standing in for librccl."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out_dir, n_total, length, k = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    from seekr_amd import _lib, launch
+    from seekr_amd.distributed import (HipEngine, shard_bounds, sharded_normalize_prepare, sharded_pearson_edges,
+                                       sharded_pearson_rowblock, sharded_pearson_symmetric)
+    from seekr_amd.synthetic import synthetic_ascii
+    ctx, comm = launch.init()
+    rank, size = comm.rank, comm.size
+    bounds = shard_bounds(n_total, size)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    blob, offsets = synthetic_ascii(11, hi - lo, length, start=lo)
+    packed = _lib.PackedSeqs.from_buffer(ctx, blob, offsets, "AGTC")
+    x = _lib.count_per_kb(ctx, packed, k)
+    engine = HipEngine(ctx)
+    mean, std, has_nan, z = sharded_normalize_prepare(engine, comm, x, n_total, "Log2.post", True, True)
+    max_shard = max(bounds[g + 1] - bounds[g] for g in range(size))
+    recv = [engine.empty_operand(max_shard, x.cols) for _ in range(2)]
+    r_row, r_col = ctx.zeros(hi - lo, n_total), ctx.zeros(n_total, hi - lo)
+    blocks = sharded_pearson_symmetric(engine, comm, z, bounds, r_row, r_col, recv)
+    r = ctx.zeros(hi - lo, n_total)
+    sharded_pearson_rowblock(engine, comm, z, bounds, r, recv)
+    e = sharded_pearson_edges(engine, comm, z, bounds, 0.05, stripe_rows=128, upper_only=True)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), mean=mean.vector(), std=std.vector(), x=x.to_numpy(),
+             r_row=r_row.to_numpy(), r_col=r_col.to_numpy(), r=r.to_numpy(), has_nan=np.array(has_nan),
+             blocks=np.array([(0 if b[0] == "row" else 1,) + tuple(b[1:]) for b in blocks], dtype=np.int64),
+             e_i=e[0], e_j=e[1], e_v=e[2], lo=np.array(lo), hi=np.array(hi))
+    comm.barrier()
+    ctx.sync()
+
+
+if __name__ == "__main__":
+    main()

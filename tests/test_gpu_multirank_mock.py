@@ -1,0 +1,109 @@
+"""The N > 1 path for real on ONE GPU: 2, 3, 4 and 8 rank processes share device 0 through
+tests/mock_rccl (RCCL itself refuses two ranks on one GPU), running launch.init, the C-ABI comm
+layer with its streams and tickets, and the HIP engine under the sharded orchestration.  Results
+must equal the single-GPU pipeline: statistics and normalised counts bit for bit (the float32 sum
+chain crosses ranks in row order), r in both layouts, the striped edge list."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.fixture(scope="module")
+def mock_lib(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("mock") / "libmock_rccl.so")
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "-fPIC", "-shared", "-o", out,
+                    os.path.join(HERE, "mock_rccl", "mock_rccl.cpp")], check=True, capture_output=True)
+    return out
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.fixture(scope="module")
+def single():
+    """The same workload on one GPU through the same entry points."""
+    from seekr_amd import _lib
+    from seekr_amd.distributed import HipEngine, SingleComm, sharded_normalize_prepare
+    from seekr_amd.synthetic import synthetic_ascii
+    n_total, length, k = 1101, 600, 6
+    ctx = _lib.default_context()
+    blob, offsets = synthetic_ascii(11, n_total, length)
+    x = _lib.count_per_kb(ctx, _lib.PackedSeqs.from_buffer(ctx, blob, offsets, "AGTC"), k)
+    engine = HipEngine(ctx)
+    mean, std, has_nan, z = sharded_normalize_prepare(engine, SingleComm(), x, n_total, "Log2.post", True, True)
+    r = ctx.empty(n_total, n_total)
+    _lib.pearson_gemm_op(ctx, z, z, r, symmetric=True)
+    return dict(n_total=n_total, length=length, k=k, mean=mean.vector(), std=std.vector(), x=x.to_numpy(), r=r.to_numpy())
+
+
+@pytest.mark.parametrize("size", [2, 3, 4, 8])
+def test_ranks_on_one_gpu_equal_single_gpu(size, mock_lib, single, tmp_path):
+    env = dict(os.environ, WORLD_SIZE=str(size), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), LOCAL_RANK="0",
+               SEEKR_RCCL_LIB=mock_lib)
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mock_rank_worker.py"), str(tmp_path),
+                               str(single["n_total"]), str(single["length"]), str(single["k"])],
+                              env=dict(env, RANK=str(rank)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for rank in range(size)]
+    for rank, p in enumerate(procs):
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, "rank %d failed:\n%s" % (rank, out.decode()[-3000:])
+    parts = [np.load(str(tmp_path / ("rank%d.npz" % rank))) for rank in range(size)]
+    n = single["n_total"]
+    bits = lambda a: np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)  # noqa: E731
+    for p in parts:
+        lo, hi = int(p["lo"]), int(p["hi"])
+        assert np.array_equal(bits(p["mean"]), bits(single["mean"]))   # the chain crossed ranks in row order
+        assert np.array_equal(bits(p["std"]), bits(single["std"]))
+        assert np.array_equal(bits(p["x"]), bits(single["x"][lo:hi]))
+        assert not bool(p["has_nan"])
+        assert np.allclose(p["r"], single["r"][lo:hi], rtol=1e-6, atol=1e-6)
+    # symmetric layout: every cell on exactly one rank, exactly symmetric, same values as one GPU
+    full, hits = np.zeros((n, n), np.float32), np.zeros((n, n), np.int32)
+    for p in parts:
+        for which, br, bc, nr, nc, gr, gc in p["blocks"]:
+            buf = p["r_row"] if which == 0 else p["r_col"]
+            full[gr:gr + nr, gc:gc + nc] = buf[br:br + nr, bc:bc + nc]
+            hits[gr:gr + nr, gc:gc + nc] += 1
+    assert (hits == 1).all()
+    assert np.array_equal(bits(full), bits(full.T.copy()))
+    assert np.allclose(full, single["r"], rtol=1e-6, atol=1e-6)
+    # striped edge lists: the union over the ranks = upper triangle of the thresholded single-GPU matrix
+    want = np.triu(np.where(single["r"] < 0.05, 0, single["r"]), 1)
+    got = np.zeros_like(want)
+    for p in parts:
+        assert not got[p["e_i"], p["e_j"]].any()
+        got[p["e_i"], p["e_j"]] = p["e_v"]
+    clear = np.abs(single["r"] - 0.05) > 1e-5
+    assert np.array_equal(got[clear] != 0, want[clear] != 0) and np.allclose(got[clear], want[clear], rtol=1e-6, atol=1e-6)
+    assert np.count_nonzero(got) > 100
+
+
+def test_bench_under_torchrun_with_two_ranks(mock_lib):
+    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one process per
+    rank), both ranks on device 0 over the mock transport: one JSON line from rank 0, whole-job value."""
+    import json
+    env = dict(os.environ, SEEKR_RCCL_LIB=mock_lib, SEEKR_FORCE_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--rows", "6000", "--length", "500"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["rows_total"] == 6000 and out["config"]["rows_per_gpu"] == 3000
+    assert "symmetric" in out["config"]["layout"] and "cpu_baseline" not in out
+    # half the ordered pairs are multiplied: own triangle + half of the one cross block
+    assert abs(out["roofline"]["pairs_multiplied_per_step"] / out["roofline"]["pairs_delivered_per_step"] - 0.5) < 0.1
