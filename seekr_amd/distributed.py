@@ -105,7 +105,8 @@ class RcclComm:
         self.ctx, self.rank, self.size = ctx, rank, size
 
     def send_vec(self, v, dst):
-        _lib.comm_sendrecv(self.ctx, v, 0, 1, dst, None, 0, 0, -1)
+        """Returns a ticket: the compute stream must wait on it before it overwrites `v`."""
+        return _lib.comm_sendrecv(self.ctx, v, 0, 1, dst, None, 0, 0, -1)
 
     def recv_vec(self, v, src):
         t = _lib.comm_sendrecv(self.ctx, None, 0, 0, -1, v, 0, 1, src)
@@ -157,8 +158,14 @@ def _chain_colsum(engine, comm, x, n_cols, center=None, center2=None, square=Fal
             comm.send_vec(acc, comm.rank + 1)
             comm.recv_vec(acc, last)
         else:
+            ticket = None
             for g in range(last):
-                comm.send_vec(acc, g)
+                ticket = comm.send_vec(acc, g)
+            # the caller goes on to rescale `acc` in place (finish) on the compute stream, while these
+            # sends sit on the communication stream: without this wait the peers could read the
+            # rescaled vector (caught by the asynchronous mode of tests/mock_rccl)
+            if ticket is not None:
+                comm.wait(ticket)
     return acc
 
 

@@ -2,8 +2,11 @@
 // lets several ranks share ONE GPU, which RCCL itself refuses ("duplicate GPU"), so that the N > 1
 // path — launch rendezvous, the C-ABI comm layer with its streams and tickets, the HIP engine under
 // the sharded orchestration — can run for real on a 1-GPU box.  Transport: files in /dev/shm, one
-// per message; every call synchronises the stream it is given (stream ordering is therefore kept,
-// overlap is not — timing under this mock means nothing).
+// per message.  Two modes: by default every call synchronises the stream it is given (stream
+// ordering kept trivially); with MOCK_RCCL_ASYNC=1 the operations are ENQUEUED on the stream like
+// RCCL's kernels — a pinned staging copy plus a host function that publishes / awaits the file — so
+// that a missing event or ticket wait in the product shows up as wrong data.  Timing under this
+// mock means nothing.
 #include <hip/hip_runtime.h>
 #include <fcntl.h>
 #include <sys/stat.h>
@@ -62,7 +65,47 @@ std::vector<char> consume(const std::string& path, size_t n) {
     unlink(path.c_str());
     return v;
 }
+// ---- asynchronous mode: stream-ordered, the host thread does not wait
+struct AsyncMsg {
+    std::string path;
+    void* pinned;
+    size_t bytes;
+};
+void cb_publish(void* p) {
+    AsyncMsg* m = static_cast<AsyncMsg*>(p);
+    publish(m->path, m->pinned, m->bytes);
+}
+void cb_consume(void* p) {
+    AsyncMsg* m = static_cast<AsyncMsg*>(p);
+    const std::vector<char> v = consume(m->path, m->bytes);
+    if (m->bytes) memcpy(m->pinned, v.data(), m->bytes);
+}
+ncclResult_t run_async(const Op& op) {
+    MockComm* c = op.comm;
+    char name[512];
+    AsyncMsg* m = new AsyncMsg();  // lives until the process ends: tests move a few hundred MB at most
+    m->bytes = op.bytes;
+    if (hipHostMalloc(&m->pinned, op.bytes ? op.bytes : 16, hipHostMallocDefault) != hipSuccess) return ncclUnhandledCudaError;
+    if (op.send) {
+        snprintf(name, sizeof name, "%s_m_%d_%d_%llu", c->base.c_str(), c->rank, op.peer, (unsigned long long)c->sent[op.peer]++);
+        m->path = name;
+        if (op.bytes && hipMemcpyAsync(m->pinned, op.buf, op.bytes, hipMemcpyDeviceToHost, op.stream) != hipSuccess) return ncclUnhandledCudaError;
+        if (hipLaunchHostFunc(op.stream, cb_publish, m) != hipSuccess) return ncclUnhandledCudaError;
+    } else {
+        snprintf(name, sizeof name, "%s_m_%d_%d_%llu", c->base.c_str(), op.peer, c->rank, (unsigned long long)c->received[op.peer]++);
+        m->path = name;
+        if (hipLaunchHostFunc(op.stream, cb_consume, m) != hipSuccess) return ncclUnhandledCudaError;
+        if (op.bytes && hipMemcpyAsync(op.buf, m->pinned, op.bytes, hipMemcpyHostToDevice, op.stream) != hipSuccess) return ncclUnhandledCudaError;
+    }
+    return ncclSuccess;
+}
+bool async_mode() {
+    static const bool on = getenv("MOCK_RCCL_ASYNC") && atoi(getenv("MOCK_RCCL_ASYNC")) != 0;
+    return on;
+}
+
 ncclResult_t run(const Op& op) {
+    if (async_mode()) return run_async(op);
     MockComm* c = op.comm;
     if (hipStreamSynchronize(op.stream) != hipSuccess) return ncclUnhandledCudaError;
     char name[512];

@@ -47,10 +47,12 @@ def single():
     return dict(n_total=n_total, length=length, k=k, mean=mean.vector(), std=std.vector(), x=x.to_numpy(), r=r.to_numpy())
 
 
-@pytest.mark.parametrize("size", [2, 3, 4, 8])
-def test_ranks_on_one_gpu_equal_single_gpu(size, mock_lib, single, tmp_path):
+@pytest.mark.parametrize("size,asynchronous", [(2, 0), (3, 0), (4, 0), (8, 0), (2, 1), (3, 1), (4, 1)])
+def test_ranks_on_one_gpu_equal_single_gpu(size, asynchronous, mock_lib, single, tmp_path):
+    """asynchronous = 1: the mock enqueues its copies and waits on the communication stream like RCCL's
+    kernels, so the product's event / ticket waits between the two streams are what keeps the data right."""
     env = dict(os.environ, WORLD_SIZE=str(size), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), LOCAL_RANK="0",
-               SEEKR_RCCL_LIB=mock_lib)
+               SEEKR_RCCL_LIB=mock_lib, MOCK_RCCL_ASYNC=str(asynchronous))
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mock_rank_worker.py"), str(tmp_path),
                                str(single["n_total"]), str(single["length"]), str(single["k"])],
                               env=dict(env, RANK=str(rank)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
@@ -93,7 +95,7 @@ def test_bench_under_torchrun_with_two_ranks(mock_lib):
     """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one process per
     rank), both ranks on device 0 over the mock transport: one JSON line from rank 0, whole-job value."""
     import json
-    env = dict(os.environ, SEEKR_RCCL_LIB=mock_lib, SEEKR_FORCE_DEVICE="0")
+    env = dict(os.environ, SEEKR_RCCL_LIB=mock_lib, SEEKR_FORCE_DEVICE="0", MOCK_RCCL_ASYNC="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--rows", "6000", "--length", "500"]
