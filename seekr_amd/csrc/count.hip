@@ -182,7 +182,10 @@ __global__ __launch_bounds__(kThreads) void count_kmers_kernel(
                     v.y = value_of(c.y);
                     v.z = value_of(c.z);
                     v.w = value_of(c.w);
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)seq * nbins + b) = v;
+                    // the row is written once and not read again by this kernel: keep it out of the L2
+                    typedef float f4 __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(f4{v.x, v.y, v.z, v.w},
+                                                reinterpret_cast<f4*>(reinterpret_cast<float*>(out) + (size_t)seq * nbins + b));
                 }
             }
         }

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
                 if (mirror && n < N) {  // r[n, m0..m0+3]: the lane's 4 rows are contiguous in the mirror
                     float* dst = Ct + (size_t)n * ldct + m0;
                     if (m0 + 3 < M && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
-                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                        __builtin_nontemporal_store(f32x4v{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4v*>(dst));
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; e++)
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
                 float* dst = C + (size_t)mrow * ldc + ncol;
                 if (mrow < M) {
                     if (ncol + 3 < N && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
-                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                        __builtin_nontemporal_store(f32x4v{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4v*>(dst));
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; e++)
