@@ -132,11 +132,11 @@ def main():
     def step():
         _lib.count_per_kb(ctx, packed, k, out=x)
         # column statistics (rank-chained), then ONE pass: normalised counts -> x, standardised rows -> z
-        sharded_normalize_prepare(engine, comm, x, n_total, "Log2.post", True, True, keep_counts=True, op=z)
+        zz = sharded_normalize_prepare(engine, comm, x, n_total, "Log2.post", True, True, keep_counts=True, op=z)[3]
         if symmetric_layout:
-            sharded_pearson_symmetric(engine, comm, z, bounds, r, r_col, recv)
+            sharded_pearson_symmetric(engine, comm, zz, bounds, r, r_col, recv)
         else:
-            sharded_pearson_rowblock(engine, comm, z, bounds, r, recv)
+            sharded_pearson_rowblock(engine, comm, zz, bounds, r, recv)
 
     for _ in range(args.warmup):
         step()

@@ -185,6 +185,15 @@ int skr_operand_as_mat(skr_operand* op, skr_mat** view);
  * has_nan (optional) as in skr_apply.                                                        */
 int skr_operand_fill(skr_ctx* ctx, const skr_mat* x, const skr_mat* center, const skr_mat* scale, int post,
                      float shift, skr_mat* y, int row_standardize, skr_operand* op, int* has_nan);
+/* Storage kind an operand ended up with: 0 = zero-padded float32 (fp32 kernel), 1 = bf16 halves,
+ * 2 = fp16 halves.  skr_operand_fill falls back from a split kind to 0 when a row is dominated by
+ * so few columns that one float32 accumulator per cell would drop the others (e.g. the raw counts
+ * of a homopolymer: one non-zero k-mer): the MFMA adds each product aligned to the accumulator, so
+ * products below ~2^-24 of a huge one vanish; the fp32 kernel accumulates in blocks.  Both operands
+ * of a contraction must have the same kind; skr_operand_adopt_layout re-tags a buffer of the same
+ * width (a receive buffer) with the kind and scale of `like`.                                    */
+int skr_operand_kind(const skr_operand* op, int* kind);
+int skr_operand_adopt_layout(skr_operand* op, const skr_operand* like);
 /* r[row0 + i, col0 + j] = <a_i, b_j> / K on prepared operands (same meaning as skr_pearson_gemm) */
 int skr_pearson_gemm_op(skr_ctx* ctx, const skr_operand* a, const skr_operand* b, int symmetric, skr_mat* r,
                         int64_t row0, int64_t col0);

@@ -69,6 +69,8 @@ SIGNATURES = {
     "skr_operand_view": (_int, [_p, _i64, _i64, C.POINTER(_p)]),
     "skr_operand_as_mat": (_int, [_p, C.POINTER(_p)]),
     "skr_operand_fill": (_int, [_p, _p, _p, _p, _int, C.c_float, _p, _int, _p, C.POINTER(_int)]),
+    "skr_operand_kind": (_int, [_p, C.POINTER(_int)]),
+    "skr_operand_adopt_layout": (_int, [_p, _p]),
     "skr_pearson_gemm_op": (_int, [_p, _p, _p, _int, _p, _i64, _i64]),
     "skr_pearson_gemm_op_mirror": (_int, [_p, _p, _p, _p, _i64, _i64, _p, _i64, _i64]),
     "skr_threshold_zero_diag": (_int, [_p, _p, C.c_float, _i64]),
@@ -319,6 +321,18 @@ class Operand:
 
     def view(self, row0, nrows):
         return Operand(self.ctx, nrows, self.cols, self.precision, _view_of=self, _row0=row0)
+
+    @property
+    def kind(self):
+        """0 = float32 layout (fp32 kernel), 1 = bf16 halves, 2 = fp16 halves (see skr_operand_kind)."""
+        k = _int(0)
+        check(lib().skr_operand_kind(self._h, C.byref(k)))
+        return k.value
+
+    def adopt_layout(self, like):
+        """Tag this buffer (a receive buffer) with the storage kind of `like`."""
+        check(lib().skr_operand_adopt_layout(self._h, like._h))
+        return self
 
     def as_matrix(self):
         """float32-typed view of the storage, for the RCCL send/recv entry points."""

@@ -17,6 +17,28 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;  // every lane holds the total
 }
 
+__device__ __forceinline__ float wave_max(float v) {
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// Dynamic range a single float32 accumulator per cell can take.  The MFMA adds each product into the
+// accumulator aligned to the accumulator's exponent: once a huge product (two rows sharing one
+// dominant column, e.g. the raw counts of two homopolymers) sits in it, every product below ~2^-24
+// of it is dropped, not summed — for a one-hot row that is ALL the other columns, 1/K of r (2.4e-4
+// at k = 6), and the adds that are not dropped are truncated at the accumulator's unit.  A row is
+// flagged when one column carries at least 1/16 of its energy (max z^2 >= K/16); flagged operands are
+// refilled in the float32 layout and take the fp32 kernel, whose accumulation is blocked and rounded
+// (skr_operand_fill).  Without a dominant column the accumulator grows gradually and stays inside
+// the bar (the contraction also restarts it every 4 096 columns, pearson_bf16.hip).
+__device__ __forceinline__ bool row_needs_fp32(float zmax2, float K) {
+    // With the huge product in the accumulator from the start, every later MFMA add is truncated at
+    // ITS unit — measured on two identical rows with max z^2 = 0.77 K at k = 7: r = 1 - 2.4e-5, i.e.
+    // ~0.25 ulp lost per add (the MFMA adder truncates), where the gradual growth of an ordinary
+    // r ~ 1 pair costs half of that and everything else far less.
+    return zmax2 * 16.f >= K;
+}
+
 struct FillArgs {
     const float* x;
     int64_t rows, cols, kt;
@@ -57,7 +79,7 @@ __global__ __launch_bounds__(256) void operand_fill_kernel(FillArgs a) {
     const int64_t K = a.cols, Kp = a.kt * 32;
     float* row = lds + (size_t)wave * ((K + 3) & ~(int64_t)3);
     const bool vec = (K & 3) == 0;
-    bool any_nan = false, overflow = false;
+    bool any_nan = false, overflow = false, outlier = false;
     for (int64_t r = (int64_t)blockIdx.x * waves + wave; r < a.rows; r += (int64_t)gridDim.x * waves) {
         const float* xr = a.x + (size_t)r * K;
         // ---- pass 1: load, elementwise tail of the normalisation, optional write-back, row sum
@@ -96,6 +118,14 @@ __global__ __launch_bounds__(256) void operand_fill_kernel(FillArgs a) {
             }
             sd = sqrtf(wave_sum(s) / kf);
         }
+        float zmax2 = 0.f;  // largest z^2 of the row (pass 3 needs it up front)
+        if (sizeof(T) != 4) {
+            for (int64_t c = lane; c < K; c += 64) {
+                const float zc = (row[c] - mean) / sd;
+                zmax2 = fmaxf(zmax2, zc * zc);
+            }
+            zmax2 = wave_max(zmax2);
+        }
         // ---- pass 3: emit the operand row, 8 k per lane and step
         float sq = 0.f;
         for (int64_t g = lane; g < a.kt * 4; g += 64) {
@@ -130,9 +160,11 @@ __global__ __launch_bounds__(256) void operand_fill_kernel(FillArgs a) {
         }
         sq = wave_sum(sq);
         if (lane == 0) a.diag[r] = sq / (float)K;
+        if (sizeof(T) != 4 && row_needs_fp32(zmax2, (float)K)) outlier = true;
     }
     if (any_nan) atomicOr(&a.flags[1], 1u);
     if (overflow) atomicOr(&a.flags[3], 1u);
+    if (outlier) atomicOr(&a.flags[4], 1u);
 }
 
 // One WORKGROUP per row, for rows of 32 KiB and more (k >= 7), where a wave-private LDS slice would
@@ -148,7 +180,7 @@ __global__ __launch_bounds__(256) void operand_fill_block_kernel(FillArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t K = a.cols, Kp = a.kt * 32, groups = a.kt * 4;
     const bool vec = (K & 7) == 0;
-    bool any_nan = false, overflow = false;
+    bool any_nan = false, overflow = false, outlier = false;
     auto block_sum = [&](float v) -> float {
         v = wave_sum(v);
         if (lane == 0) red[wave] = v;
@@ -212,6 +244,19 @@ __global__ __launch_bounds__(256) void operand_fill_block_kernel(FillArgs a) {
                 }
             sd = sqrtf(block_sum(s) / kf);
         }
+        float zmax2 = 0.f;
+        if (sizeof(T) != 4) {
+            for (int64_t g = tid; g < groups; g += 256)
+                for (int64_t c = g * 8; c < std::min<int64_t>(K, g * 8 + 8); c++) {
+                    const float zc = (val(c) - mean) / sd;
+                    zmax2 = fmaxf(zmax2, zc * zc);
+                }
+            zmax2 = wave_max(zmax2);
+            if (lane == 0) red[wave] = zmax2;
+            __syncthreads();
+            zmax2 = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            __syncthreads();
+        }
         float sq = 0.f;
         for (int64_t g = tid; g < groups; g += 256) {
             const int64_t tile = g >> 2, sub = g & 3, k0 = g * 8;
@@ -245,9 +290,11 @@ __global__ __launch_bounds__(256) void operand_fill_block_kernel(FillArgs a) {
         }
         sq = block_sum(sq);  // its barriers also fence the LDS row against the next row's pass 1
         if (tid == 0) a.diag[r] = sq / (float)K;
+        if (sizeof(T) != 4 && row_needs_fp32(zmax2, (float)K)) outlier = true;
     }
     if (any_nan) atomicOr(&a.flags[1], 1u);
     if (overflow) atomicOr(&a.flags[3], 1u);
+    if (outlier) atomicOr(&a.flags[4], 1u);
 }
 
 // Register-resident variant for K = VPL * 256 columns (k = 5: VPL 4, k = 6: VPL 16): a wave keeps
@@ -266,7 +313,7 @@ __global__ __launch_bounds__(256) void operand_fill_reg_kernel(FillArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
     constexpr int64_t K = (int64_t)VPL * 256;
-    bool any_nan = false, overflow = false;
+    bool any_nan = false, overflow = false, outlier = false;
     for (int64_t r = (int64_t)blockIdx.x * waves + wave; r < a.rows; r += (int64_t)gridDim.x * waves) {
         const float* xr = a.x + (size_t)r * K;
         float4 v[VPL];
@@ -322,6 +369,13 @@ __global__ __launch_bounds__(256) void operand_fill_reg_kernel(FillArgs a) {
             sq = __fmaf_rn(v[i].w, v[i].w, __fmaf_rn(v[i].z, v[i].z, __fmaf_rn(v[i].y, v[i].y, __fmaf_rn(v[i].x, v[i].x, sq))));
         sq = wave_sum(sq);
         if (lane == 0) a.diag[r] = sq / (float)K;
+        if (sizeof(T) != 4) {
+            float zmax2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPL; i++)
+                zmax2 = fmaxf(fmaxf(zmax2, fmaxf(v[i].x * v[i].x, v[i].y * v[i].y)), fmaxf(v[i].z * v[i].z, v[i].w * v[i].w));
+            if (row_needs_fp32(wave_max(zmax2), (float)K)) outlier = true;
+        }
 #pragma unroll
         for (int i = 0; i < VPL; i++) {
             const int64_t c = i * 256 + lane * 4;
@@ -346,6 +400,7 @@ __global__ __launch_bounds__(256) void operand_fill_reg_kernel(FillArgs a) {
     }
     if (any_nan) atomicOr(&a.flags[1], 1u);
     if (overflow) atomicOr(&a.flags[3], 1u);
+    if (outlier) atomicOr(&a.flags[4], 1u);
 }
 
 // r[i, i] of a self-comparison = <z_i, z_i> / K.  The contraction adds 4 096 squares into one float32
@@ -382,6 +437,77 @@ int check_pair(const skr_ctx* ctx, const skr_mat* a, const skr_mat* b) {
 
 bool is_f32_precision(int p) {
     return p == SKR_PREC_FP32 || p == SKR_PREC_BF16X3 || p == SKR_PREC_BF16X4 || p == SKR_PREC_F16X3;
+}
+
+// launches the fill kernel that suits the row width and the operand's storage kind
+int launch_fill(skr_ctx* ctx, const skr_operand* op, const FillArgs& a) {
+    const size_t row_floats = (size_t)((a.cols + 3) & ~(int64_t)3);
+    const bool wide = row_floats * 4 > 150 * 1024;  // k >= 8: the row does not fit the LDS
+    const int waves = (int)std::max<size_t>(1, std::min<size_t>(4, (64 * 1024) / (row_floats * 4)));
+    const size_t lds = row_floats * 4 * waves;
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / lds));
+    const int64_t want = (a.rows + waves - 1) / waves;
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cu * per_cu));
+    // 4^6 / 4^5 columns with the usual vectors (float32 mean/std computed on the device, or none):
+    // the row fits the register file
+    int reg_mode = -1;
+    if (a.ck == 0 && a.sk == 0 && !a.post && !a.y) reg_mode = 0;
+    else if (a.ck == 1 && a.sk == 1) reg_mode = a.post ? 2 : 1;
+    if ((a.cols == 4096 || a.cols == 1024) && reg_mode >= 0) {
+        const unsigned rgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((a.rows + 3) / 4, (int64_t)ctx->num_cu * 5));
+        SkrProfScope prof(ctx, "operand_fill");
+#define LAUNCH_REG2(T, V)                                                                                              \
+    do {                                                                                                               \
+        if (reg_mode == 0) hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 0>), dim3(rgrid), dim3(256), 0, ctx->stream, a);      \
+        else if (reg_mode == 1) hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 1>), dim3(rgrid), dim3(256), 0, ctx->stream, a); \
+        else hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 2>), dim3(rgrid), dim3(256), 0, ctx->stream, a);                    \
+    } while (0)
+#define LAUNCH_REG(T)                           \
+    do {                                        \
+        if (a.cols == 4096) LAUNCH_REG2(T, 16); \
+        else LAUNCH_REG2(T, 4);                  \
+    } while (0)
+        if (op->kind == 0) LAUNCH_REG(float);
+        else if (op->kind == 1) LAUNCH_REG(__bf16);
+        else LAUNCH_REG(_Float16);
+#undef LAUNCH_REG
+#undef LAUNCH_REG2
+        SKR_HIP(hipGetLastError());
+    } else if (row_floats * 4 >= 32 * 1024) {  // k >= 7: one workgroup per row
+        SkrProfScope prof(ctx, "operand_fill");
+        const size_t blds = wide ? 0 : row_floats * 4;
+        const int64_t bper_cu = wide ? 8 : std::max<int64_t>(1, (int64_t)((150 * 1024) / blds));
+        const unsigned wgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(a.rows, (int64_t)ctx->num_cu * bper_cu));
+#define LAUNCH_BLOCK(T)                                                                                           \
+    do {                                                                                                          \
+        if (wide) {                                                                                               \
+            hipLaunchKernelGGL((operand_fill_block_kernel<T, false>), dim3(wgrid), dim3(256), 0, ctx->stream, a);  \
+        } else {                                                                                                  \
+            SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(operand_fill_block_kernel<T, true>),        \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));                  \
+            hipLaunchKernelGGL((operand_fill_block_kernel<T, true>), dim3(wgrid), dim3(256), blds, ctx->stream, a); \
+        }                                                                                                         \
+    } while (0)
+        if (op->kind == 0) LAUNCH_BLOCK(float);
+        else if (op->kind == 1) LAUNCH_BLOCK(__bf16);
+        else LAUNCH_BLOCK(_Float16);
+#undef LAUNCH_BLOCK
+        SKR_HIP(hipGetLastError());
+    } else {
+        SkrProfScope prof(ctx, "operand_fill");
+#define LAUNCH(T)                                                                                         \
+    do {                                                                                                      \
+        SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(operand_fill_kernel<T>),                    \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
+        hipLaunchKernelGGL(operand_fill_kernel<T>, dim3(grid), dim3(64 * waves), lds, ctx->stream, a);               \
+    } while (0)
+        if (op->kind == 0) LAUNCH(float);
+        else if (op->kind == 1) LAUNCH(__bf16);
+        else LAUNCH(_Float16);
+#undef LAUNCH
+        SKR_HIP(hipGetLastError());
+    }
+    return SKR_OK;
 }
 
 }  // namespace
@@ -491,87 +617,61 @@ extern "C" int skr_operand_fill(skr_ctx* ctx, const skr_mat* x, const skr_mat* c
     SKR_TRY(skr_activate(ctx));
     if (has_nan) *has_nan = 0;
     if (x->rows == 0) return SKR_OK;
-    const size_t row_floats = (size_t)((x->cols + 3) & ~(int64_t)3);
-    const bool wide = row_floats * 4 > 150 * 1024;  // k >= 8: the row does not fit the LDS
-    const int waves = (int)std::max<size_t>(1, std::min<size_t>(4, (64 * 1024) / (row_floats * 4)));
-    const size_t lds = row_floats * 4 * waves;
-    SKR_HIP(hipMemsetAsync(ctx->d_flags + 1, 0, 4, ctx->stream));  // [1] NaN seen
-    SKR_HIP(hipMemsetAsync(ctx->d_flags + 3, 0, 4, ctx->stream));  // [3] fp16 range exceeded ([2] belongs to the counting kernel)
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / lds));
-    const int64_t want = (x->rows + waves - 1) / waves;
-    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cu * per_cu));
-    // 4^6 / 4^5 columns with the usual vectors (float32 mean/std computed on the device, or none):
-    // the row fits the register file
-    int reg_mode = -1;
-    if (a.ck == 0 && a.sk == 0 && !a.post && !a.y) reg_mode = 0;
-    else if (a.ck == 1 && a.sk == 1) reg_mode = a.post ? 2 : 1;
-    if ((x->cols == 4096 || x->cols == 1024) && reg_mode >= 0) {
-        const unsigned rgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((x->rows + 3) / 4, (int64_t)ctx->num_cu * 5));
-        SkrProfScope prof(ctx, "operand_fill");
-#define LAUNCH_REG2(T, V)                                                                                              \
-    do {                                                                                                               \
-        if (reg_mode == 0) hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 0>), dim3(rgrid), dim3(256), 0, ctx->stream, a);      \
-        else if (reg_mode == 1) hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 1>), dim3(rgrid), dim3(256), 0, ctx->stream, a); \
-        else hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 2>), dim3(rgrid), dim3(256), 0, ctx->stream, a);                    \
-    } while (0)
-#define LAUNCH_REG(T)                           \
-    do {                                        \
-        if (x->cols == 4096) LAUNCH_REG2(T, 16); \
-        else LAUNCH_REG2(T, 4);                  \
-    } while (0)
-        if (op->kind == 0) LAUNCH_REG(float);
-        else if (op->kind == 1) LAUNCH_REG(__bf16);
-        else LAUNCH_REG(_Float16);
-#undef LAUNCH_REG
-#undef LAUNCH_REG2
-        SKR_HIP(hipGetLastError());
-    } else if (row_floats * 4 >= 32 * 1024) {  // k >= 7: one workgroup per row
-        SkrProfScope prof(ctx, "operand_fill");
-        const size_t blds = wide ? 0 : row_floats * 4;
-        const int64_t bper_cu = wide ? 8 : std::max<int64_t>(1, (int64_t)((150 * 1024) / blds));
-        const unsigned wgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(x->rows, (int64_t)ctx->num_cu * bper_cu));
-#define LAUNCH_BLOCK(T)                                                                                           \
-    do {                                                                                                          \
-        if (wide) {                                                                                               \
-            hipLaunchKernelGGL((operand_fill_block_kernel<T, false>), dim3(wgrid), dim3(256), 0, ctx->stream, a);  \
-        } else {                                                                                                  \
-            SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(operand_fill_block_kernel<T, true>),        \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));                  \
-            hipLaunchKernelGGL((operand_fill_block_kernel<T, true>), dim3(wgrid), dim3(256), blds, ctx->stream, a); \
-        }                                                                                                         \
-    } while (0)
-        if (op->kind == 0) LAUNCH_BLOCK(float);
-        else if (op->kind == 1) LAUNCH_BLOCK(__bf16);
-        else LAUNCH_BLOCK(_Float16);
-#undef LAUNCH_BLOCK
-        SKR_HIP(hipGetLastError());
-    } else {
-        SkrProfScope prof(ctx, "operand_fill");
-#define LAUNCH(T)                                                                                         \
-    do {                                                                                                      \
-        SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(operand_fill_kernel<T>),                    \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
-        hipLaunchKernelGGL(operand_fill_kernel<T>, dim3(grid), dim3(64 * waves), lds, ctx->stream, a);               \
-    } while (0)
-        if (op->kind == 0) LAUNCH(float);
-        else if (op->kind == 1) LAUNCH(__bf16);
-        else LAUNCH(_Float16);
-#undef LAUNCH
-        SKR_HIP(hipGetLastError());
-    }
+    // flags: [1] NaN seen, [3] fp16 range exceeded, [4] a row needs more dynamic range than one float32
+    // accumulator per cell has ([2] belongs to the counting kernel)
+    SKR_HIP(hipMemsetAsync(ctx->d_flags + 1, 0, 4, ctx->stream));
+    SKR_HIP(hipMemsetAsync(ctx->d_flags + 3, 0, 8, ctx->stream));
+    SKR_TRY(launch_fill(ctx, op, a));
     op->diag_valid = true;
     // values are only bounded by sqrt(K) when the rows were standardised here: check the fp16 range otherwise
     const bool check_range = op->kind == 2 && !row_standardize;
-    if (has_nan || check_range) {
+    const bool split = op->kind != 0;
+    if (has_nan || check_range || split) {
         SKR_HIP(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         SKR_HIP(hipStreamSynchronize(ctx->stream));
         if (has_nan) *has_nan = ctx->h_flags[1] != 0;
+        if (split && ctx->h_flags[4] != 0) {
+            // a row is dominated by so few columns that the split contraction would drop the others
+            // (see row_needs_fp32): same storage, float32 layout, and the fp32 kernel from here on.  The
+            // normalised counts, if they were asked for, are already in y: refill from them as they are.
+            op->kind = 0;
+            op->scale = 1.f;
+            FillArgs b = a;
+            b.out_scale = 1.f;
+            if (a.y) {
+                b.x = a.y;
+                b.y = nullptr;
+                b.ck = b.sk = 0;
+                b.center = b.scale = nullptr;
+                b.post = 0;
+            }
+            SKR_TRY(launch_fill(ctx, op, b));
+            return SKR_OK;
+        }
         if (check_range && ctx->h_flags[3] != 0)
             return skr_set_error(SKR_ERR_INVALID,
                                  "a value exceeds the split-fp16 operand range (|v| <= %g at %lld columns); "
                                  "use SKR_PREC_FP32 for rows that are not row-standardised",
                                  65504.0 / op->scale, (long long)op->cols);
     }
+    return SKR_OK;
+}
+
+/* storage kind an operand ended up with: 0 = float32 (fp32 kernel), 1 = bf16 halves, 2 = fp16 halves */
+extern "C" int skr_operand_kind(const skr_operand* op, int* kind) {
+    SKR_REQUIRE(op && kind, "NULL argument");
+    *kind = op->kind;
+    return SKR_OK;
+}
+
+/* tag a buffer of the same shape with the storage kind (and scale) of `like`: receive buffers must be
+ * read the way the sender wrote them */
+extern "C" int skr_operand_adopt_layout(skr_operand* op, const skr_operand* like) {
+    SKR_REQUIRE(op && like && op->cols == like->cols, "operands of different widths");
+    op->kind = like->kind;
+    op->scale = like->scale;
+    op->precision = like->precision;
+    op->diag_valid = false;
     return SKR_OK;
 }
 
@@ -640,6 +740,18 @@ extern "C" int skr_pearson_gemm_op_mirror(skr_ctx* ctx, const skr_operand* a, co
                                  (float)K * a->scale * b->scale, 2, Ct, rt->cols);
 }
 
+// One of two freshly filled operands fell back to the float32 layout (a row needs the dynamic range of
+// the blocked fp32 accumulation): refill the other one the same way so that one kernel serves both.
+static int match_layouts(skr_ctx* ctx, const skr_mat* xa, skr_operand* oa, const skr_mat* xb, skr_operand* ob,
+                         int row_standardize) {
+    if (oa->kind == ob->kind) return SKR_OK;
+    skr_operand* split = oa->kind != 0 ? oa : ob;
+    const skr_mat* src = oa->kind != 0 ? xa : xb;
+    split->kind = 0;
+    split->scale = 1.f;
+    return skr_operand_fill(ctx, src, nullptr, nullptr, 0, 0.f, nullptr, row_standardize, split, nullptr);
+}
+
 // ---- matrix-level entry points built on operands ------------------------------------------------
 extern "C" int skr_pearson_gemm(skr_ctx* ctx, const skr_mat* a, const skr_mat* b, int precision, int symmetric,
                                 skr_mat* r, int64_t row0, int64_t col0) {
@@ -666,6 +778,7 @@ extern "C" int skr_pearson_gemm(skr_ctx* ctx, const skr_mat* a, const skr_mat* b
         rc = skr_operand_create(ctx, b->rows, b->cols, precision, &ob);
         if (rc == SKR_OK) rc = skr_operand_fill(ctx, b, nullptr, nullptr, 0, 0.f, nullptr, 0, ob, nullptr);
     }
+    if (rc == SKR_OK && !same) rc = match_layouts(ctx, a, oa, b, ob, 0);
     if (rc == SKR_OK) rc = skr_pearson_gemm_op(ctx, oa, same ? oa : ob, symmetric, r, row0, col0);
     skr_operand_free(oa);
     skr_operand_free(ob);
@@ -704,6 +817,7 @@ extern "C" int skr_pearson(skr_ctx* ctx, const skr_mat* counts1, const skr_mat* 
         rc = skr_operand_create(ctx, counts2->rows, counts2->cols, precision, &o2);
         if (rc == SKR_OK) rc = skr_operand_fill(ctx, counts2, nullptr, nullptr, 0, 0.f, nullptr, row_standardize, o2, nullptr);
     }
+    if (rc == SKR_OK && !same) rc = match_layouts(ctx, counts1, o1, counts2, o2, row_standardize);
     if (rc == SKR_OK) rc = skr_pearson_gemm_op(ctx, o1, same ? o1 : o2, same, r, 0, 0);
     skr_operand_free(o1);
     skr_operand_free(o2);

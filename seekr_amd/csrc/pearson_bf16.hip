@@ -79,7 +79,7 @@ template <typename T, int NPROD, int MODE, bool PERSIST>
 __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
     const T* __restrict__ A, const T* __restrict__ B, float* __restrict__ C, float* __restrict__ Ct,
     int64_t M, int64_t N, int64_t kt, int64_t ldc, int64_t ldct, float kdiv, int64_t tiles_m, int64_t tiles_n,
-    int64_t super_n, uint32_t* __restrict__ queues, int64_t slots_per_queue) {
+    int64_t super_n, uint32_t* __restrict__ queues, int64_t slots_per_queue, int64_t pitch_tiles, int accumulate) {
     constexpr int WN = 4, MT = 8, NT = 4, PP = 4;  // 8 waves as 2 x 4, wave tile 128 x 64
     constexpr bool SYM = MODE == SELF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
         return;
     }
     const int64_t row_base = tm * TM, col_base = tn * TN;
-    const int64_t pitch = kt * 64;
+    const int64_t pitch = pitch_tiles * 64;  // elements per operand row; kt may be a chunk of it
 
     // staging: wave w moves pieces PP*w .. PP*w+PP-1 (8 rows x one 128-byte line each) of the A tile
     // and of the B tile.  Uniform tile base (SGPRs) + 32-bit per-lane byte offset (one VGPR per piece).
@@ -218,19 +218,22 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
                 for (int e = 0; e < 4; e++) {
                     const int64_t m = m0 + e;
                     if (n < N && m < M && n >= m) {
-                        C[(size_t)m * ldc + n] = v[e];
-                        if (n > m) Ct[(size_t)n * ldct + m] = v[e];
+                        const float w = accumulate ? C[(size_t)m * ldc + n] + v[e] : v[e];
+                        C[(size_t)m * ldc + n] = w;
+                        if (n > m) Ct[(size_t)n * ldct + m] = w;
                     }
                 }
             } else {
                 if (mirror && n < N) {  // r[n, m0..m0+3]: the lane's 4 rows are contiguous in the mirror
                     float* dst = Ct + (size_t)n * ldct + m0;
                     if (m0 + 3 < M && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
-                        __builtin_nontemporal_store(f32x4v{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4v*>(dst));
+                        f32x4v w{v[0], v[1], v[2], v[3]};
+                        if (accumulate) w += *reinterpret_cast<const f32x4v*>(dst);
+                        __builtin_nontemporal_store(w, reinterpret_cast<f32x4v*>(dst));
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; e++)
-                            if (m0 + e < M) dst[e] = v[e];
+                            if (m0 + e < M) dst[e] = accumulate ? dst[e] + v[e] : v[e];
                     }
                 }
                 // direct tile: transpose 4x4 inside each quad of lanes (lane j of a quad ends up with
@@ -253,11 +256,13 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
                 float* dst = C + (size_t)mrow * ldc + ncol;
                 if (mrow < M) {
                     if (ncol + 3 < N && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
-                        __builtin_nontemporal_store(f32x4v{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4v*>(dst));
+                        f32x4v w{v[0], v[1], v[2], v[3]};
+                        if (accumulate) w += *reinterpret_cast<const f32x4v*>(dst);
+                        __builtin_nontemporal_store(w, reinterpret_cast<f32x4v*>(dst));
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; e++)
-                            if (ncol + e < N) dst[e] = v[e];
+                            if (ncol + e < N) dst[e] = accumulate ? dst[e] + v[e] : v[e];
                     }
                 }
             }
@@ -280,31 +285,40 @@ int launch16(skr_ctx* ctx, const T* A, const T* B, const SplitOut& o, int64_t M,
     const int64_t super_m = (tiles_m + 15) / 16, super_n = (tiles_n + 15) / 16;
     const int64_t slots = super_m * super_n * 256;
     static const bool persist = !(getenv("SEEKR_GEMM_PERSIST") && atoi(getenv("SEEKR_GEMM_PERSIST")) == 0);  // A/B knob
-    if (persist && slots > ctx->num_cu) {
-        uint32_t* queues = ctx->d_flags + 8;  // eight counters, zeroed per launch
-        SKR_HIP(hipMemsetAsync(queues, 0, 8 * sizeof(uint32_t), ctx->stream));
-        auto kern = pearson_gemm_split16_kernel<T, NPROD, MODE, true>;
-        SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    2 * kStageBytes));
-        SkrProfScope prof(ctx, name);
-        // A resident workgroup owns its CU outright (8 waves x ~248 VGPRs, 128 KiB LDS): with RCCL traffic
-        // in flight on the communication stream a few CUs are left free, or the send/recv kernels of
-        // shift s+1 could not start before this launch ends and the overlap of §5 would be lost.
-        static const int reserve_env = getenv("SEEKR_GEMM_RESERVE_CUS") ? atoi(getenv("SEEKR_GEMM_RESERVE_CUS")) : -1;
-        const int reserve = reserve_env >= 0 ? reserve_env : (ctx->nranks > 1 ? 8 : 0);
-        const unsigned grid = (unsigned)std::max(8, ctx->num_cu - reserve);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 2 * kStageBytes, ctx->stream, A, B, o.C, o.Ct, M, N, kt, o.ldc,
-                           o.ldct, K, tiles_m, tiles_n, super_n, queues, slots / 8);
-        SKR_HIP(hipGetLastError());
-        return SKR_OK;
-    }
-    auto kern = pearson_gemm_split16_kernel<T, NPROD, MODE, false>;
-    SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                2 * kStageBytes));
+    // One float32 accumulator per cell is restarted every 4 096 columns: the MFMA adder truncates each
+    // add at the accumulator's unit (~0.25 ulp lost per add, measured), a bias that grows with the number
+    // of adds and with the accumulator — 5e-6 relative on an r ~ 1 pair at K = 4 096, four times that at
+    // 16 384 in one go.  Later chunks add their partial result to C in the epilogue (rounded float32 adds).
+    constexpr int64_t kChunkTiles = 128;
     SkrProfScope prof(ctx, name);
-    hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(512), 2 * kStageBytes, ctx->stream, A, B, o.C, o.Ct, M, N, kt,
-                       o.ldc, o.ldct, K, tiles_m, tiles_n, super_n, (uint32_t*)nullptr, (int64_t)0);
-    SKR_HIP(hipGetLastError());
+    for (int64_t t0 = 0; t0 < kt; t0 += kChunkTiles) {
+        const int64_t ktc = std::min(kChunkTiles, kt - t0);
+        const T* Ac = A + t0 * 64;
+        const T* Bc = B + t0 * 64;
+        const int accumulate = t0 > 0;
+        if (persist && slots > ctx->num_cu) {
+            uint32_t* queues = ctx->d_flags + 8;  // eight counters, zeroed per launch
+            SKR_HIP(hipMemsetAsync(queues, 0, 8 * sizeof(uint32_t), ctx->stream));
+            auto kern = pearson_gemm_split16_kernel<T, NPROD, MODE, true>;
+            SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        2 * kStageBytes));
+            // A resident workgroup owns its CU outright (8 waves x ~248 VGPRs, 128 KiB LDS): with RCCL traffic
+            // in flight on the communication stream a few CUs are left free, or the send/recv kernels of
+            // shift s+1 could not start before this launch ends and the overlap of §5 would be lost.
+            static const int reserve_env = getenv("SEEKR_GEMM_RESERVE_CUS") ? atoi(getenv("SEEKR_GEMM_RESERVE_CUS")) : -1;
+            const int reserve = reserve_env >= 0 ? reserve_env : (ctx->nranks > 1 ? 8 : 0);
+            const unsigned grid = (unsigned)std::max(8, ctx->num_cu - reserve);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 2 * kStageBytes, ctx->stream, Ac, Bc, o.C, o.Ct, M, N, ktc, o.ldc,
+                               o.ldct, K, tiles_m, tiles_n, super_n, queues, slots / 8, kt, accumulate);
+        } else {
+            auto kern = pearson_gemm_split16_kernel<T, NPROD, MODE, false>;
+            SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        2 * kStageBytes));
+            hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(512), 2 * kStageBytes, ctx->stream, Ac, Bc, o.C, o.Ct, M, N, ktc,
+                               o.ldc, o.ldct, K, tiles_m, tiles_n, super_n, (uint32_t*)nullptr, (int64_t)0, kt, accumulate);
+        }
+        SKR_HIP(hipGetLastError());
+    }
     return SKR_OK;
 }
 

@@ -84,6 +84,20 @@ class HipEngine:
                                  shift=shift, y=x if keep_counts else None, row_standardize=True,
                                  want_nan=scale is not None)
 
+    def layout(self, op):
+        """Storage kind of a prepared operand (0 = float32 fallback, see _lib.Operand.kind)."""
+        return op.kind
+
+    def adopt_layout(self, buf, like):
+        if buf is not None:
+            buf.adopt_layout(like)
+
+    def prepare_f32(self, x, op=None):
+        """The rows of `x` (already normalised) as a float32-layout operand: what every rank switches
+        to when any rank's rows need the fp32 kernel's dynamic range."""
+        op = _lib.Operand(self.ctx, x.rows, x.cols, _lib.PREC_FP32) if op is None or op.kind != 0 else op
+        return _lib.operand_fill(self.ctx, x, op=op, precision=_lib.PREC_FP32, row_standardize=True)[0]
+
     def gemm(self, a, b, r, col0, symmetric=False):
         _lib.pearson_gemm_op(self.ctx, a, b, r, symmetric and self.use_symmetry, 0, col0)
 
@@ -225,6 +239,15 @@ def sharded_normalize_prepare(engine, comm, x, n_total, log2="Log2.post", mean=T
     Returns (mean_vec, std_vec, has_nan, operand)."""
     center, scale, post, shift = sharded_stats(engine, comm, x, n_total, log2, mean, std)
     operand, has_nan = engine.prepare(x, center, scale, post, shift, keep_counts=keep_counts, op=op)
+    # A rank whose rows need more dynamic range than the split contraction has (skr_operand_kind) comes
+    # back with a float32-layout operand; shards are multiplied against each other, so then every rank
+    # switches (rare: raw counts of homopolymer-like sequences).  Needs the normalised counts in x.
+    if comm.size > 1 and hasattr(engine, "layout"):
+        fell_back = engine.layout(operand) == 0 and engine.precision != _lib.PREC_FP32
+        if _any_rank(comm, fell_back) and engine.layout(operand) != 0:
+            if not keep_counts:
+                raise NotImplementedError("a rank fell back to the float32 contraction; re-run with keep_counts=True")
+            operand = engine.prepare_f32(x)
     return center, scale, _any_rank(comm, has_nan), operand
 
 
@@ -236,6 +259,9 @@ def sharded_pearson_rowblock(engine, comm, z, bounds, r, recv_bufs):
     receives rank-s's; its GEMM overlaps shift s+1."""
     size, rank = comm.size, comm.rank
     tickets = {}
+    if hasattr(engine, "adopt_layout"):
+        for buf in recv_bufs:
+            engine.adopt_layout(buf, z)
     if size > 1:
         src = (rank - 1) % size
         tickets[1] = comm.shift(z, (rank + 1) % size, recv_bufs[1 % 2], bounds[src + 1] - bounds[src], src)
@@ -301,6 +327,9 @@ def sharded_pearson_symmetric(engine, comm, z, bounds, r_row, r_col, recv_bufs):
     size, rank = comm.size, comm.rank
     plan = half_ring_plan(size, rank, bounds)
     tickets = {}
+    if hasattr(engine, "adopt_layout"):
+        for buf in recv_bufs:
+            engine.adopt_layout(buf, z)
 
     def post(i):
         s, peer = plan[i][0], plan[i][1]
@@ -329,6 +358,8 @@ def allgather_operand(engine, comm, z, bounds, full=None):
     if comm.size == 1:
         return z
     full = engine.empty_operand(bounds[-1], engine.cols(z)) if full is None else full
+    if hasattr(engine, "adopt_layout"):
+        engine.adopt_layout(full, z)
     comm.wait(comm.allgather_rows(z, full, bounds))
     return full
 

@@ -20,10 +20,19 @@ def main():
     bounds = shard_bounds(n_total, size)
     lo, hi = bounds[rank], bounds[rank + 1]
     blob, offsets = synthetic_ascii(11, hi - lo, length, start=lo)
+    raw_mode = os.environ.get("MOCK_RAW_HOMOPOLYMERS") == "1"
+    if raw_mode and rank == 0:  # two identical homopolymers: one-hot raw count rows, only on this rank
+        blob = np.array(blob, copy=True)
+        blob[:2 * length] = ord("A")
     packed = _lib.PackedSeqs.from_buffer(ctx, blob, offsets, "AGTC")
     x = _lib.count_per_kb(ctx, packed, k)
     engine = HipEngine(ctx)
-    mean, std, has_nan, z = sharded_normalize_prepare(engine, comm, x, n_total, "Log2.post", True, True)
+    if raw_mode:  # raw counts straight into Pearson: the shape that needs the fp32 kernel's dynamic range
+        mean, std, has_nan, z = sharded_normalize_prepare(engine, comm, x, n_total, "Log2.none", False, False)
+        assert z.kind == 0, "every rank must have switched to the float32 layout"
+        mean = std = ctx.zeros(1, x.cols)
+    else:
+        mean, std, has_nan, z = sharded_normalize_prepare(engine, comm, x, n_total, "Log2.post", True, True)
     max_shard = max(bounds[g + 1] - bounds[g] for g in range(size))
     recv = [engine.empty_operand(max_shard, x.cols) for _ in range(2)]
     r_row, r_col = ctx.zeros(hi - lo, n_total), ctx.zeros(n_total, hi - lo)

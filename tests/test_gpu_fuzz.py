@@ -1,0 +1,11 @@
+"""Differential fuzzing of BasicCounter / pearson against the oracle (tests/fuzz_differential.py):
+fixed seeds, a bounded number of cases per seed."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_fuzz_cases(seed):
+    from fuzz_differential import fuzz
+    assert fuzz(seed, budget_s=25.0, max_cases=60) >= 10

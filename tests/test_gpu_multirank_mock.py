@@ -109,3 +109,26 @@ def test_bench_under_torchrun_with_two_ranks(mock_lib):
     assert "symmetric" in out["config"]["layout"] and "cpu_baseline" not in out
     # half the ordered pairs are multiplied: own triangle + half of the one cross block
     assert abs(out["roofline"]["pairs_multiplied_per_step"] / out["roofline"]["pairs_delivered_per_step"] - 0.5) < 0.1
+
+
+def test_every_rank_switches_when_one_needs_the_fp32_kernel(mock_lib, tmp_path):
+    """Rank 0 holds two identical homopolymers (one-hot raw count rows): its operand falls back to the
+    float32 layout, the flag is all-reduced and the other ranks follow, so shards stay compatible;
+    the pair's r is 1 to float32 accuracy (the split contraction alone would give 1 - 2.4e-4)."""
+    size, n_total, length, k = 3, 700, 600, 6
+    env = dict(os.environ, WORLD_SIZE=str(size), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), LOCAL_RANK="0",
+               SEEKR_RCCL_LIB=mock_lib, MOCK_RCCL_ASYNC="1", MOCK_RAW_HOMOPOLYMERS="1")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mock_rank_worker.py"), str(tmp_path), str(n_total), str(length),
+                               str(k)], env=dict(env, RANK=str(rank)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for rank in range(size)]
+    for rank, p in enumerate(procs):
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, "rank %d failed:\n%s" % (rank, out.decode()[-3000:])
+    parts = [np.load(str(tmp_path / ("rank%d.npz" % rank))) for rank in range(size)]
+    r0 = parts[0]["r"]                       # rank 0's row block [n_0, N]
+    assert abs(float(r0[0, 1]) - 1.0) < 2e-6 and abs(float(r0[1, 0]) - 1.0) < 2e-6
+    full = np.concatenate([p["r"] for p in parts], axis=0)
+    assert np.allclose(full, full.T, rtol=0, atol=1e-6) and np.allclose(np.diag(full), 1.0, atol=2e-6)
+    x = np.concatenate([p["x"] for p in parts], axis=0)
+    from oracle import seekr_oracle as orc
+    assert np.allclose(full, orc.pearson(x, x), rtol=1e-5, atol=2e-6)

@@ -776,8 +776,8 @@ def test_pearson_split_bf16_vs_oracle(prec, shape, L, ctx):
 
 def test_split_fp16_small_values_and_range(L, ctx):
     """fp16 halves are stored times a power of two (a function of K), so tiny values keep float32-grade
-    relative precision instead of falling into fp16 subnormals; rows that are not row-standardised are
-    range-checked and refused loudly rather than turned into inf."""
+    relative precision instead of falling into fp16 subnormals; rows that are not row-standardised and
+    too large for the halves end in the float32 layout instead of turning into inf."""
     K = 1024
     ones = ctx.from_numpy(np.ones((16, K), np.float32))
     for val in (1e-6, 3e-5, 1e-4, 0.01):
@@ -787,12 +787,40 @@ def test_split_fp16_small_values_and_range(L, ctx):
         got = float(r.to_numpy()[0, 0])
         # what a dot product needs is absolute precision: < 1e-11 here (3e-8 without the scale) ...
         assert abs(got - val) < 1e-11 + 2e-6 * val, (val, got)
+    # values beyond what the scaled fp16 halves can hold (rows that were not standardised): such rows
+    # are "dominated" in the sense of row_needs_fp32 long before they overflow, so the operand takes the
+    # float32 layout and the result is simply right (the range check behind it is a safety net)
     big = ctx.from_numpy(np.full((16, K), 1000.0, np.float32))
-    with pytest.raises(ValueError, match="split-fp16 operand range"):
-        L.pearson_gemm(ctx, big, ones, ctx.empty(16, 16), precision=L.PREC_F16X3)
-    r = ctx.empty(16, 16)  # bf16 halves have float32's exponent range
-    L.pearson_gemm(ctx, big, ones, r, precision=L.PREC_BF16X3)
-    assert abs(float(r.to_numpy()[0, 0]) / 1000.0 - 1.0) < 1e-5
+    for prec in (L.PREC_F16X3, L.PREC_BF16X3):
+        r = ctx.empty(16, 16)
+        L.pearson_gemm(ctx, big, ones, r, precision=prec)
+        assert abs(float(r.to_numpy()[0, 0]) / 1000.0 - 1.0) < 1e-6
+
+
+def test_rows_dominated_by_one_column_take_the_fp32_kernel(L, ctx):
+    """Raw counts of homopolymers are one-hot rows: z = sqrt(K-1) in one column, -1/sqrt(K-1) elsewhere.
+    With one float32 accumulator per cell the MFMA drops every product below ~2^-24 of the huge one —
+    all the other columns, 1/K of r.  The fill detects such rows and the operand falls back to the
+    float32 layout (blocked accumulation); ordinary rows keep the split layout."""
+    from seekr_amd.pearson import pearson
+    rng = np.random.default_rng(0)
+    K = 4096
+    x = (rng.binomial(30, 0.1, size=(600, K)) * np.float32(0.5)).astype(np.float32)
+    op, _ = L.operand_fill(ctx, ctx.from_numpy(x))
+    assert op.kind == 2                                    # ordinary rows: split-fp16
+    x[10, :] = 0; x[10, 77] = 1000.0                       # two identical one-hot rows and a third elsewhere
+    x[20, :] = 0; x[20, 77] = 1000.0
+    x[30, :] = 0; x[30, 4000] = 500.0
+    op, _ = L.operand_fill(ctx, ctx.from_numpy(x))
+    assert op.kind == 0                                    # fell back
+    got = pearson(x, x)
+    want = orc.pearson_f64_truth(x, x)
+    assert abs(got[10, 20] - 1.0) < 1e-6 and abs(got[10, 30] - want[10, 30]) < 2e-6
+    assert np.allclose(got, want, rtol=RTOL, atol=ATOL_R)
+    # one flagged operand against an ordinary one: both end in the same layout
+    y = (rng.binomial(30, 0.1, size=(300, K)) * np.float32(0.5)).astype(np.float32)
+    assert np.allclose(pearson(x, y), orc.pearson_f64_truth(x, y), rtol=RTOL, atol=ATOL_R)
+    assert np.allclose(pearson(y, x), orc.pearson_f64_truth(y, x), rtol=RTOL, atol=ATOL_R)
 
 
 def test_pearson_split_bf16_nan_rows(L, ctx):
