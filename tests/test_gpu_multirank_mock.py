@@ -30,13 +30,11 @@ def free_port():
         return s.getsockname()[1]
 
 
-@pytest.fixture(scope="module")
-def single():
+def single_gpu_reference(n_total, length, k):
     """The same workload on one GPU through the same entry points."""
     from seekr_amd import _lib
     from seekr_amd.distributed import HipEngine, SingleComm, sharded_normalize_prepare
     from seekr_amd.synthetic import synthetic_ascii
-    n_total, length, k = 1101, 600, 6
     ctx = _lib.default_context()
     blob, offsets = synthetic_ascii(11, n_total, length)
     x = _lib.count_per_kb(ctx, _lib.PackedSeqs.from_buffer(ctx, blob, offsets, "AGTC"), k)
@@ -47,8 +45,28 @@ def single():
     return dict(n_total=n_total, length=length, k=k, mean=mean.vector(), std=std.vector(), x=x.to_numpy(), r=r.to_numpy())
 
 
+@pytest.fixture(scope="module")
+def single():
+    return single_gpu_reference(1101, 600, 6)
+
+
+@pytest.fixture(scope="module")
+def single_k7():
+    return single_gpu_reference(520, 900, 7)
+
+
+def test_k7_ranks_on_one_gpu(mock_lib, single_k7, tmp_path):
+    """k = 7: 16 384 columns, i.e. the block-per-row operand fill and four accumulator restarts per
+    contraction (later chunks add into C), in SELF, CROSS and PLAIN mode."""
+    check_ranks(3, 1, mock_lib, single_k7, tmp_path)
+
+
 @pytest.mark.parametrize("size,asynchronous", [(2, 0), (3, 0), (4, 0), (8, 0), (2, 1), (3, 1), (4, 1)])
 def test_ranks_on_one_gpu_equal_single_gpu(size, asynchronous, mock_lib, single, tmp_path):
+    check_ranks(size, asynchronous, mock_lib, single, tmp_path)
+
+
+def check_ranks(size, asynchronous, mock_lib, single, tmp_path):
     """asynchronous = 1: the mock enqueues its copies and waits on the communication stream like RCCL's
     kernels, so the product's event / ticket waits between the two streams are what keeps the data right."""
     env = dict(os.environ, WORLD_SIZE=str(size), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), LOCAL_RANK="0",
@@ -88,7 +106,9 @@ def test_ranks_on_one_gpu_equal_single_gpu(size, asynchronous, mock_lib, single,
         got[p["e_i"], p["e_j"]] = p["e_v"]
     clear = np.abs(single["r"] - 0.05) > 1e-5
     assert np.array_equal(got[clear] != 0, want[clear] != 0) and np.allclose(got[clear], want[clear], rtol=1e-6, atol=1e-6)
-    assert np.count_nonzero(got) > 100
+    assert np.count_nonzero(got[clear]) == np.count_nonzero(want[clear])
+    if single["k"] == 6:
+        assert np.count_nonzero(got) > 100
 
 
 def test_bench_under_torchrun_with_two_ranks(mock_lib):
