@@ -12,39 +12,39 @@ from seekr_amd.kmer_counts import BasicCounter
 KMER_COUNTS_DOC = """
 Description
 -----------
-Generates a kmer count matrix of m rows by n columns,
-where m is the number of transcripts in a fasta file and n is 4^kmer.
-(MI355X implementation; same flags and outputs as `seekr_kmer_counts`.)
+Counts the k-mers of every sequence of a FASTA file on an MI355X and writes the per-kb,
+normalised count matrix: one row per sequence, 4^k columns.  Flags and output files are
+those of the reference command of the same name.
 
 Examples
 --------
-    $ seekr_kmer_counts rnas.fa -o out.csv
-    $ seekr_kmer_counts rnas.fa -o out.npy -k 5 -b -rl
-    $ seekr_kmer_counts rnas.fa -o out.csv -mv mean.npy -sv std.npy
+    labelled CSV, 6-mers:            seekr_kmer_counts transcripts.fa -o counts.csv
+    binary, unlabelled, 5-mers:      seekr_kmer_counts transcripts.fa -o counts.npy -k 5 -b -rl
+    normalise with stored vectors:   seekr_kmer_counts transcripts.fa -o counts.csv -mv mean.npy -sv std.npy
 """
 
 PEARSON_DOC = """
 Description
 -----------
-Generate a matrix of Pearson similarities from two kmer count files.
-(MI355X implementation; same flags and outputs as `seekr_pearson`.)
+All-pairs Pearson correlation between the rows of two k-mer count files, computed on an
+MI355X.  Flags and output files are those of the reference command of the same name.
 
 Examples
 --------
-    $ seekr_pearson kc_out.csv kc_out.csv -o out.csv
-    $ seekr_pearson kc_out.npy kc_out.npy -o out.npy -bi -bo
+    labelled CSV in and out:   seekr_pearson counts.csv counts.csv -o r.csv
+    .npy in and out:           seekr_pearson counts.npy counts.npy -o r.npy -bi -bo
 """
 
 NORM_VECTORS_DOC = """
 Description
 -----------
-Generate two .npy files from a .fa file to use as normalization vectors for other .fa files.
-(MI355X implementation; same flags and outputs as `seekr_norm_vectors`.)
+Column mean and standard deviation of the k-mer counts of a (large) FASTA file, saved as two .npy
+vectors that later runs can normalise against (-mv / -sv of seekr_kmer_counts).
 
 Examples
 --------
-    $ seekr_norm_vectors gencode.fa
-    $ seekr_norm_vectors gencode.fa -k 5 -mv mean_5mers.npy -sv std_5mers.npy
+    defaults (6-mers, mean.npy, std.npy):   seekr_norm_vectors gencode.fa
+    5-mers, named outputs:                  seekr_norm_vectors gencode.fa -k 5 -mv mean5.npy -sv std5.npy
 """
 
 _LOG2 = ["Log2.post", "Log2.pre", "Log2.none"]
@@ -67,21 +67,21 @@ def _run_kmer_counts(fasta, outfile, kmer, binary, centered, standardized, log2,
 
 def console_kmer_counts():
     parser = argparse.ArgumentParser(usage=KMER_COUNTS_DOC, formatter_class=argparse.ArgumentDefaultsHelpFormatter)
-    parser.add_argument("fasta", help="Full path of fasta file.")
-    parser.add_argument("-o", "--outfile", default="counts.seekr", help="Name of file to save counts to.")
-    parser.add_argument("-k", "--kmer", default=6, help="Length of kmers you want to count.")
-    parser.add_argument("-b", "--binary", action="store_true", help="Set if output should be a .npy file.")
+    parser.add_argument("fasta", help="FASTA file with the sequences to count.")
+    parser.add_argument("-o", "--outfile", default="counts.seekr", help="Where the count matrix goes.")
+    parser.add_argument("-k", "--kmer", default=6, help="k, the word length (4^k columns).")
+    parser.add_argument("-b", "--binary", action="store_true", help="Write .npy instead of CSV.")
     parser.add_argument("-uc", "--uncentered", action="store_false",
-                        help="Set if output should not have the mean subtracted.")
+                        help="Leave the column means in (no centring).")
     parser.add_argument("-us", "--unstandardized", action="store_false",
-                        help="Set if output should not be divided by the standard deviation.")
+                        help="Do not divide by the column standard deviations.")
     parser.add_argument("-l", "--log2", default="Log2.post", choices=_LOG2,
-                        help="Decided if and when to log transform counts")
+                        help="log2 before the column statistics (pre), after them (post), or not at all (none).")
     parser.add_argument("-rl", "--remove_labels", action="store_true",
-                        help="Set to save without index and column labels.")
-    parser.add_argument("-mv", "--mean_vector", default=None, help="Optional path to mean vector numpy file.")
-    parser.add_argument("-sv", "--std_vector", default=None, help="Optional path to std vector numpy file.")
-    parser.add_argument("-a", "--alphabet", default="AGTC", help="Valid letters to include in kmer.")
+                        help="Plain CSV without the header row and the name column (required with -b).")
+    parser.add_argument("-mv", "--mean_vector", default=None, help="Centre with this stored mean vector (.npy) instead of the set's own.")
+    parser.add_argument("-sv", "--std_vector", default=None, help="Scale with this stored std vector (.npy) instead of the set's own.")
+    parser.add_argument("-a", "--alphabet", default="AGTC", help="The four letters, in column-index order.")
     args = _parse_args_or_exit(parser)
     _run_kmer_counts(args.fasta, args.outfile, int(args.kmer), args.binary, args.uncentered, args.unstandardized,
                      args.log2, args.remove_labels, args.mean_vector, args.std_vector, args.alphabet)
@@ -118,12 +118,11 @@ def _run_pearson(counts1, counts2, outfile, binary_input, binary_output):
 
 def console_pearson():
     parser = argparse.ArgumentParser(usage=PEARSON_DOC, formatter_class=argparse.ArgumentDefaultsHelpFormatter)
-    parser.add_argument("counts1", help="Full path of a count file produced by kmer_counts.py.")
-    parser.add_argument("counts2", help=("Full path of a second count file produced by kmer_counts.py. "
-                                         "This can be the same path as the first counts file."))
-    parser.add_argument("-o", "--outfile", default="pearson.seekr", help="Path of file to save similarities to.")
-    parser.add_argument("-bi", "--binary_input", action="store_true", help="Set if the input will be a .npy file.")
-    parser.add_argument("-bo", "--binary_output", action="store_true", help="Set if output should be a .npy file.")
+    parser.add_argument("counts1", help="First count file (rows of the result).")
+    parser.add_argument("counts2", help="Second count file (columns of the result); may be the first one again.")
+    parser.add_argument("-o", "--outfile", default="pearson.seekr", help="Where the correlation matrix goes.")
+    parser.add_argument("-bi", "--binary_input", action="store_true", help="The count files are .npy, not labelled CSV.")
+    parser.add_argument("-bo", "--binary_output", action="store_true", help="Write .npy instead of CSV.")
     args = _parse_args_or_exit(parser)
     _run_pearson(args.counts1, args.counts2, args.outfile, args.binary_input, args.binary_output)
 
@@ -137,11 +136,11 @@ def _run_norm_vectors(fasta, mean_vector, std_vector, log2, kmer):
 
 def console_norm_vectors():
     parser = argparse.ArgumentParser(usage=NORM_VECTORS_DOC, formatter_class=argparse.ArgumentDefaultsHelpFormatter)
-    parser.add_argument("fasta", help="path to .fa file")
-    parser.add_argument("-mv", "--mean_vector", default="mean.npy", help="path to output mean vector")
-    parser.add_argument("-sv", "--std_vector", default="std.npy", help="path to output standard deviation vector")
+    parser.add_argument("fasta", help="FASTA file to take the statistics of.")
+    parser.add_argument("-mv", "--mean_vector", default="mean.npy", help="Output: column means (.npy).")
+    parser.add_argument("-sv", "--std_vector", default="std.npy", help="Output: column standard deviations (.npy).")
     parser.add_argument("-l", "--log2", default="Log2.post", choices=_LOG2,
-                        help="Decided if and when to log transform counts")
-    parser.add_argument("-k", "--kmer", default=6, help="length of kmers you want to count")
+                        help="log2 before the column statistics (pre), after them (post), or not at all (none).")
+    parser.add_argument("-k", "--kmer", default=6, help="k, the word length.")
     args = _parse_args_or_exit(parser)
     _run_norm_vectors(args.fasta, args.mean_vector, args.std_vector, args.log2, int(args.kmer))
