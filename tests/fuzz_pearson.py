@@ -1,0 +1,78 @@
+"""Differential fuzzing of seekr_amd.pearson.pearson(a, b, row_standardize) against the oracle:
+random shapes (K not a multiple of anything, single rows, empty-ish), dtypes (float32, float64,
+integers -> float64 path), same-object and different operands, NaN / constant rows."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import seekr_oracle as orc  # noqa: E402
+from seekr_amd.pearson import pearson  # noqa: E402
+
+
+def fuzz(seed, budget_s=60.0, max_cases=10 ** 9):
+    rng = np.random.default_rng(seed)
+    t0, n_cases = time.time(), 0
+    while time.time() - t0 < budget_s and n_cases < max_cases:
+        K = int(rng.choice([1, 2, 3, 4, 5, 16, 31, 32, 33, 64, 100, 255, 256, 257, 1000, 1023, 1024, 1025, 1500, 2048, 4096, 4100]))
+        M, N = int(rng.integers(1, 70)), int(rng.integers(1, 70))
+        dt = rng.choice(["f32", "f32", "f32", "f64", "i64"])
+        same = bool(rng.integers(0, 3) == 0)
+        rs = bool(rng.integers(0, 4) != 0)
+        kind = rng.integers(0, 4)
+        def make(rows):
+            if kind == 0:
+                x = rng.standard_normal((rows, K)) * rng.uniform(0.1, 50)
+            elif kind == 1:
+                x = rng.binomial(20, 0.2, size=(rows, K)).astype(np.float64) * 1.5
+            elif kind == 2:
+                x = np.abs(rng.standard_normal((rows, K))) ** 3
+            else:
+                x = rng.standard_normal((rows, K)); x[rng.integers(0, rows)] = 3.25  # a constant row
+            if dt == "i64":
+                return np.rint(x * 4).astype(np.int64)
+            return x.astype(np.float32 if dt == "f32" else np.float64)
+        a = make(M)
+        b = a if same else make(N)
+        tag = dict(K=K, M=a.shape[0], N=b.shape[0], dt=str(dt), same=same, rs=rs, kind=int(kind))
+        try:
+            with np.errstate(all="ignore"):
+                want = orc.pearson(a, b, rs)
+                truth = orc.pearson_f64_truth(a, b, rs)
+            got = pearson(a, b, row_standardize=rs)
+            assert got.dtype == want.dtype and got.shape == want.shape, ("dtype/shape", tag, got.dtype, want.dtype)
+            with np.errstate(all="ignore"):
+                g = np.where(np.isinf(got), np.nan, got).astype(np.float64)
+                w = np.where(np.isinf(want), np.nan, want).astype(np.float64)
+            # rows that are constant (or nearly: std below the rounding noise of the mean) are garbage in,
+            # NaN / inf / anything out, for numpy as for the device: judge the others
+            def bad_rows(x):
+                x = np.asarray(x, dtype=np.float64)
+                return x.std(axis=1) <= 1e-6 * np.maximum(np.abs(x).max(axis=1), 1e-300) if rs else np.zeros(len(x), bool)
+            live = ~bad_rows(a)[:, None] & ~bad_rows(b)[None, :]
+            assert not np.isnan(g[live]).any() or np.isnan(w[live]).any(), ("unexpected NaN", tag)
+            ok = live & ~np.isnan(w) & ~np.isnan(truth)
+            e_ref = np.where(ok, np.abs(w - truth), 0.0)
+            e_ours = np.where(ok, np.abs(g - truth), 0.0)
+            scale = np.maximum(np.abs(np.where(ok, truth, 0.0)), 1e-300)
+            if got.dtype == np.float64:
+                limit = 1e-12 * np.maximum(scale, 1.0) + 8 * e_ref.max()
+            else:
+                slack = 4.0 * np.maximum(e_ref.max(axis=1, keepdims=True), e_ref.max(axis=0, keepdims=True))
+                limit = (2e-6 + 1e-5 * scale) * (np.maximum(scale.max(), 1.0) if not rs else 1.0) + slack
+            bad = e_ours > limit
+            assert not bad.any(), ("value", tag, float(e_ours[bad].max()), float(e_ref.max()))
+        except AssertionError:
+            d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+            os.makedirs(d, exist_ok=True)
+            np.savez(os.path.join(d, "fuzz_pearson_fail_%d_%d.npz" % (seed, n_cases)), a=a, b=b, rs=rs, same=same)
+            raise
+        n_cases += 1
+    return n_cases
+
+
+if __name__ == "__main__":
+    n = fuzz(int(sys.argv[1]) if len(sys.argv) > 1 else 0, float(sys.argv[2]) if len(sys.argv) > 2 else 60.0)
+    print("pearson fuzz ok: %d cases" % n)

@@ -9,3 +9,9 @@ pytestmark = pytest.mark.gpu
 def test_fuzz_cases(seed):
     from fuzz_differential import fuzz
     assert fuzz(seed, budget_s=25.0, max_cases=60) >= 10
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_fuzz_pearson_api(seed):
+    from fuzz_pearson import fuzz
+    assert fuzz(seed, budget_s=8.0, max_cases=4000) >= 200
