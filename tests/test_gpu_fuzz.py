@@ -15,3 +15,9 @@ def test_fuzz_cases(seed):
 def test_fuzz_pearson_api(seed):
     from fuzz_pearson import fuzz
     assert fuzz(seed, budget_s=8.0, max_cases=4000) >= 200
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_fuzz_fasta_reader(seed):
+    from fuzz_fasta import fuzz
+    assert fuzz(seed, budget_s=6.0, max_cases=3000) >= 200
