@@ -308,21 +308,43 @@ using vec4h = T __attribute__((ext_vector_type(4)));
 // MODE 0: rows as they are; 1: float32 center + scale; 2: center + scale + Log2.post tail.
 // (Compile-time modes: with the runtime ck/sk/post switches of fill_tail inside the unrolled
 // row hipcc unswitches the loop into many copies and spills.)
-template <typename T, int VPL, int MODE>
+// RW = waves that share a row (1: a wave per row; 4: the workgroup's four waves take 4^7 columns
+// together, wave w owning the 256-column pieces w, w + 4, ... and the row sums crossing the waves
+// through 16 bytes of LDS and one barrier each).
+template <typename T, int VPL, int MODE, int RW>
 __global__ __launch_bounds__(256) void operand_fill_reg_kernel(FillArgs a) {
+    __shared__ float red[5][4];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
-    constexpr int64_t K = (int64_t)VPL * 256;
+    constexpr int64_t K = (int64_t)VPL * 256 * RW;
     bool any_nan = false, overflow = false, outlier = false;
-    for (int64_t r = (int64_t)blockIdx.x * waves + wave; r < a.rows; r += (int64_t)gridDim.x * waves) {
+    // sum / max over the row; `slot` separates the reductions of one row so that one barrier each is enough
+    auto row_sum = [&](float v, int slot) -> float {
+        v = wave_sum(v);
+        if (RW == 1) return v;
+        if (lane == 0) red[slot][wave] = v;
+        __syncthreads();
+        return (red[slot][0] + red[slot][1]) + (red[slot][2] + red[slot][3]);
+    };
+    auto row_max = [&](float v, int slot) -> float {
+        v = wave_max(v);
+        if (RW == 1) return v;
+        if (lane == 0) red[slot][wave] = v;
+        __syncthreads();
+        return fmaxf(fmaxf(red[slot][0], red[slot][1]), fmaxf(red[slot][2], red[slot][3]));
+    };
+    const int64_t r_first = RW == 1 ? (int64_t)blockIdx.x * waves + wave : (int64_t)blockIdx.x;
+    const int64_t r_step = RW == 1 ? (int64_t)gridDim.x * waves : (int64_t)gridDim.x;
+    const int piece0 = RW == 1 ? 0 : wave;  // first 256-column piece of this wave
+    for (int64_t r = r_first; r < a.rows; r += r_step) {
         const float* xr = a.x + (size_t)r * K;
         float4 v[VPL];
 #pragma unroll
-        for (int i = 0; i < VPL; i++) v[i] = *reinterpret_cast<const float4*>(xr + i * 256 + lane * 4);
+        for (int i = 0; i < VPL; i++) v[i] = *reinterpret_cast<const float4*>(xr + (i * RW + piece0) * 256 + lane * 4);
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < VPL; i++) {
-            const int64_t c = i * 256 + lane * 4;
+            const int64_t c = (i * RW + piece0) * 256 + lane * 4;
             if (MODE >= 1) {
                 const float4 m = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.center) + c);
                 const float4 d = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.scale) + c);
@@ -343,21 +365,21 @@ __global__ __launch_bounds__(256) void operand_fill_reg_kernel(FillArgs a) {
         }
         if (a.row_standardize) {  // statistics in the order pearson.py:35-38 computes them
             const float kf = (float)K;
-            const float mean = wave_sum(s) / kf;
+            const float mean = row_sum(s, 0) / kf;
             s = 0.f;
 #pragma unroll
             for (int i = 0; i < VPL; i++) {
                 v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
                 s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
             }
-            const float m2 = wave_sum(s) / kf;
+            const float m2 = row_sum(s, 1) / kf;
             s = 0.f;
 #pragma unroll
             for (int i = 0; i < VPL; i++) {
                 const float dx = v[i].x - m2, dy = v[i].y - m2, dz = v[i].z - m2, dw = v[i].w - m2;
                 s += (dx * dx + dy * dy) + (dz * dz + dw * dw);
             }
-            const float sd = sqrtf(wave_sum(s) / kf);
+            const float sd = sqrtf(row_sum(s, 2) / kf);
 #pragma unroll
             for (int i = 0; i < VPL; i++) {
                 v[i].x /= sd; v[i].y /= sd; v[i].z /= sd; v[i].w /= sd;
@@ -367,18 +389,18 @@ __global__ __launch_bounds__(256) void operand_fill_reg_kernel(FillArgs a) {
 #pragma unroll
         for (int i = 0; i < VPL; i++)  // explicit FMAs: every instantiation of the kernel rounds this sum identically
             sq = __fmaf_rn(v[i].w, v[i].w, __fmaf_rn(v[i].z, v[i].z, __fmaf_rn(v[i].y, v[i].y, __fmaf_rn(v[i].x, v[i].x, sq))));
-        sq = wave_sum(sq);
-        if (lane == 0) a.diag[r] = sq / (float)K;
+        sq = row_sum(sq, 3);
+        if (lane == 0 && (RW == 1 || wave == 0)) a.diag[r] = sq / (float)K;
         if (sizeof(T) != 4) {
             float zmax2 = 0.f;
 #pragma unroll
             for (int i = 0; i < VPL; i++)
                 zmax2 = fmaxf(fmaxf(zmax2, fmaxf(v[i].x * v[i].x, v[i].y * v[i].y)), fmaxf(v[i].z * v[i].z, v[i].w * v[i].w));
-            if (row_needs_fp32(wave_max(zmax2), (float)K)) outlier = true;
+            if (row_needs_fp32(row_max(zmax2, 4), (float)K)) outlier = true;
         }
 #pragma unroll
         for (int i = 0; i < VPL; i++) {
-            const int64_t c = i * 256 + lane * 4;
+            const int64_t c = (i * RW + piece0) * 256 + lane * 4;
             if (sizeof(T) == 4) {
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + (size_t)r * K + c) = v[i];
             } else {
@@ -453,19 +475,22 @@ int launch_fill(skr_ctx* ctx, const skr_operand* op, const FillArgs& a) {
     int reg_mode = -1;
     if (a.ck == 0 && a.sk == 0 && !a.post && !a.y) reg_mode = 0;
     else if (a.ck == 1 && a.sk == 1) reg_mode = a.post ? 2 : 1;
-    if ((a.cols == 4096 || a.cols == 1024) && reg_mode >= 0) {
-        const unsigned rgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((a.rows + 3) / 4, (int64_t)ctx->num_cu * 5));
+    if ((a.cols == 16384 || a.cols == 4096 || a.cols == 1024) && reg_mode >= 0) {
+        const int64_t rows_per_wg = a.cols == 16384 ? 1 : 4;
+        const unsigned rgrid = (unsigned)std::max<int64_t>(
+            1, std::min<int64_t>((a.rows + rows_per_wg - 1) / rows_per_wg, (int64_t)ctx->num_cu * 5));
         SkrProfScope prof(ctx, "operand_fill");
-#define LAUNCH_REG2(T, V)                                                                                              \
-    do {                                                                                                               \
-        if (reg_mode == 0) hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 0>), dim3(rgrid), dim3(256), 0, ctx->stream, a);      \
-        else if (reg_mode == 1) hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 1>), dim3(rgrid), dim3(256), 0, ctx->stream, a); \
-        else hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 2>), dim3(rgrid), dim3(256), 0, ctx->stream, a);                    \
+#define LAUNCH_REG2(T, V, RW)                                                                                              \
+    do {                                                                                                                   \
+        if (reg_mode == 0) hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 0, RW>), dim3(rgrid), dim3(256), 0, ctx->stream, a);      \
+        else if (reg_mode == 1) hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 1, RW>), dim3(rgrid), dim3(256), 0, ctx->stream, a); \
+        else hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 2, RW>), dim3(rgrid), dim3(256), 0, ctx->stream, a);                    \
     } while (0)
-#define LAUNCH_REG(T)                           \
-    do {                                        \
-        if (a.cols == 4096) LAUNCH_REG2(T, 16); \
-        else LAUNCH_REG2(T, 4);                  \
+#define LAUNCH_REG(T)                                  \
+    do {                                               \
+        if (a.cols == 16384) LAUNCH_REG2(T, 16, 4);    \
+        else if (a.cols == 4096) LAUNCH_REG2(T, 16, 1); \
+        else LAUNCH_REG2(T, 4, 1);                      \
     } while (0)
         if (op->kind == 0) LAUNCH_REG(float);
         else if (op->kind == 1) LAUNCH_REG(__bf16);

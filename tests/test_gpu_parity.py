@@ -854,3 +854,14 @@ def test_cfg2_slab_split_bf16(L, ctx):
         assert np.abs(blk - truth)[off].max() < 1.2e-6, (prec, np.abs(blk - truth)[off].max())
         assert np.allclose(blk, ref, rtol=RTOL, atol=ATOL_R), prec
         assert np.allclose(np.diag(r), 1.0, atol=4e-6)
+
+
+def test_cfg3_like_pipeline():
+    """SURVEY config 3 stand-in at reduced size: length-skewed transcripts through norm vectors -> counts
+    -> Pearson with the public API, checked against the oracle inside the tool."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "cfg3_pipeline.py"), "--rows", "2500",
+                          "--check-prefix", "300"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "cfg3 pipeline ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
