@@ -242,6 +242,31 @@ int skr_edges(skr_ctx* ctx, const skr_mat* r, int64_t nrows, int64_t col_begin, 
 int skr_topk_rows(skr_ctx* ctx, const skr_mat* r, int64_t nrows, int64_t col_begin, int64_t col_end,
                   int64_t row_global0, int64_t col_global0, int k, skr_mat* out_idx, skr_mat* out_val);
 
+/* ---------------------------------------------------------------- one-call host forms --- */
+/* The two reference calls of the hot path over caller-owned host buffers, for bindings that do
+ * not want to manage device handles (both run the same kernels as the handle-based functions).
+ *
+ * BasicCounter(...).get_counts() (kmer_counts.py:194-209) on packed sequences:
+ *   counts_out  float32 [n, 4^k], row-major
+ *   mean_mode / std_mode   0 = skip (mean=False), 1 = compute (mean=True; the vector lands in
+ *                          mean_out / std_out, float32 [4^k], when that pointer is not NULL),
+ *                          2 = use mean_vec / std_vec (4^k entries of mean_dtype / std_dtype,
+ *                          SKR_F32 or SKR_F64 — a float64 vector is applied in float64 and
+ *                          rounded once, as numpy's in-place `counts -= mean` does)
+ *   has_nan     optional; set when standardisation produced NaN (the warning of :176-187)
+ * Errors as the reference raises them: one sequence with std_mode 1 -> SKR_ERR_INVALID (:124-130),
+ * unknown log2_mode -> SKR_ERR_INVALID (:134-135), len(seq) == k-1 -> SKR_ERR_ZERODIV (:144).   */
+int skr_host_get_counts(skr_ctx* ctx, const skr_seqs* s, int k, int log2_mode, int mean_mode,
+                        const void* mean_vec, int mean_dtype, int std_mode, const void* std_vec,
+                        int std_dtype, float* counts_out, float* mean_out, float* std_out, int* has_nan);
+/* pearson(counts1, counts2, row_standardize) (pearson.py:32-41): a [m, K] and b [n, K] of `dtype`
+ * (SKR_F32 or SKR_F64; pass the same pointer twice for a self-comparison) -> out [m, n] of the
+ * same dtype.  float64 always runs the f64 MFMA; for float32 `precision` picks the arithmetic
+ * (SKR_PREC_F16X3 is the host package's default and falls back to SKR_PREC_FP32 without row
+ * standardisation).                                                                            */
+int skr_host_pearson(skr_ctx* ctx, const void* a, int64_t m, const void* b, int64_t n, int64_t K, int dtype,
+                     int row_standardize, int precision, void* out);
+
 /* ---------------------------------------------------------------- writers --------------- */
 /* The files the reference writes from the count matrix and from r, byte-identical to numpy's:
  *   skr_*_save_npy                   np.save(path, a)              kmer_counts.py:234, pearson.py:43

@@ -64,6 +64,8 @@ SIGNATURES = {
     "skr_row_standardize": (_int, [_p, _p, _p]),
     "skr_pearson_gemm": (_int, [_p, _p, _p, _int, _int, _p, _i64, _i64]),
     "skr_pearson": (_int, [_p, _p, _p, _int, _int, _p]),
+    "skr_host_get_counts": (_int, [_p, _p, _int, _int, _int, _p, _int, _int, _p, _int, _p, _p, _p, C.POINTER(_int)]),
+    "skr_host_pearson": (_int, [_p, _p, _i64, _p, _i64, _i64, _int, _int, _int, _p]),
     "skr_operand_create": (_int, [_p, _i64, _i64, _int, C.POINTER(_p)]),
     "skr_operand_free": (_int, [_p]),
     "skr_operand_view": (_int, [_p, _i64, _i64, C.POINTER(_p)]),

@@ -865,3 +865,29 @@ def test_cfg3_like_pipeline():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "cfg3_pipeline.py"), "--rows", "2500",
                           "--check-prefix", "300"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "cfg3 pipeline ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_c_program_through_one_call_host_forms(tmp_path):
+    """tests/c_abi/host_example.c — plain C, linked against libseekr_hip.so — runs counts + Pearson through
+    skr_host_get_counts / skr_host_pearson; results checked against the oracle."""
+    import subprocess
+    from test_host_cpu import _build_c_example
+    exe = _build_c_example(tmp_path)
+    seqs = skewed_set(77, 300, 150, 900)
+    fa = str(tmp_path / "in.fa")
+    write_fasta(fa, seqs, width=70)
+    c_path, r_path = str(tmp_path / "c.npy"), str(tmp_path / "r.npy")
+    out = subprocess.run([exe, fa, "4", c_path, r_path], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    want, want_mean, want_std = orc.get_counts(seqs, 4, True, True, "Log2.post")
+    got = np.load(c_path)
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=2e-6)
+    assert "mean[0]=%.9g std[0]=%.9g" % (want_mean[0], want_std[0]) in out.stdout
+    r = np.load(r_path)
+    truth = orc.pearson_f64_truth(got, got)
+    assert np.abs(r - truth).max() < 2e-6 + 1e-5
+    assert r.dtype == np.float32 and r.shape == (300, 300)
+    # the reference's error surface: a sequence of length k-1 -> SKR_ERR_ZERODIV (-5) -> exit code 6
+    write_fasta(fa, ["ACG", "ACGTACGT"])
+    out = subprocess.run([exe, fa, "4", c_path, r_path], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 6, out.stdout + out.stderr

@@ -111,3 +111,30 @@ def test_counter_constructor_rules_without_gpu():
         BasicCounter(k=3, log2="log2")
     c = BasicCounter(k=2, alphabet="ACGT", mean=False, std=np.ones(16), silent=True)
     assert c.kmers[:5] == ["AA", "AC", "AG", "AT", "CA"] and c.mean is False
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "host_example")
+    libdir = os.path.join(ROOT, "seekr_amd")
+    cmd = ["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "c_abi", "host_example.c"), "-o", exe, "-L" + libdir, "-lseekr_hip",
+           "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib"]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    return exe
+
+
+def test_header_is_plain_c_and_a_c_program_links(tmp_path):
+    """include/seekr_hip.h must be usable from C (no C++-isms) and the library from a program that is not
+    Python; without a GPU the program fails loudly with the library's error message."""
+    import subprocess
+    from seekr_amd import _lib
+    _lib.lib()  # the shared library is built
+    exe = _build_c_example(tmp_path)
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible: the run itself is covered by the gpu tests")
+    fa = tmp_path / "x.fa"
+    fa.write_text(">a\nACGTACGT\n>b\nTTTTGGGA\n")
+    out = subprocess.run([exe, str(fa), "2", str(tmp_path / "c.npy"), str(tmp_path / "r.npy")], capture_output=True, text=True)
+    assert out.returncode == 3 and "skr_ctx_create" in out.stderr  # 1 + |SKR_ERR_HIP|
