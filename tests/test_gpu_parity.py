@@ -891,3 +891,15 @@ def test_c_program_through_one_call_host_forms(tmp_path):
     write_fasta(fa, ["ACG", "ACGTACGT"])
     out = subprocess.run([exe, fa, "4", c_path, r_path], capture_output=True, text=True, timeout=120)
     assert out.returncode == 6, out.stdout + out.stderr
+
+
+def test_matrices_beyond_4gib():
+    """Byte offsets past 2^32 in every kernel of the path (config 5 shards are 8 GB): tools/big_offsets.py
+    counts 72 000 sequences at k = 7 (4.7 GB matrix) and checks counting, statistics, the fused fill and a
+    contraction of the last rows against the first against the oracle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "big_offsets.py")], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and "big offsets ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
