@@ -16,6 +16,8 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -161,6 +163,47 @@ inline bool py_space(unsigned char c) {
     return c == ' ' || (c >= 0x09 && c <= 0x0d) || (c >= 0x1c && c <= 0x1f);
 }
 
+// What one thread learns from the lines of data[begin, end) (begin is a line start).
+struct FastaPiece {
+    std::string joined;                // sequence characters of the piece, stripped lines back to back
+    std::vector<int64_t> seq_start;    // per header of the piece: offset in `joined` where its sequence begins
+    std::vector<int64_t> header_line;  // per header: line index inside the piece
+    std::string headers;               // header texts, '\n'-joined
+    int64_t n_lines = 0;
+    int64_t blank_line = -1;           // first line that is empty after strip()
+    bool first_is_header = false;
+};
+
+void parse_piece(const char* data, size_t begin, size_t end, FastaPiece* out) {
+    out->joined.reserve(end - begin);
+    size_t pos = begin;
+    while (pos < end) {
+        // end of line: the first '\n' or '\r' (memchr: the loop is bound by memory, not by byte tests)
+        const char* nl = (const char*)memchr(data + pos, '\n', end - pos);
+        const size_t lim = nl ? (size_t)(nl - data) : end;
+        const char* cr = (const char*)memchr(data + pos, '\r', lim - pos);
+        const size_t eol = cr ? (size_t)(cr - data) : lim;
+        size_t next = eol;
+        if (next < end) next += (data[next] == '\r' && next + 1 < end && data[next + 1] == '\n') ? 2 : 1;
+        size_t a = pos, b = eol;
+        while (a < b && py_space((unsigned char)data[a])) a++;
+        while (b > a && py_space((unsigned char)data[b - 1])) b--;
+        if (a == b) {
+            if (out->blank_line < 0) out->blank_line = out->n_lines;
+        } else if (data[a] == '>') {
+            if (out->n_lines == 0) out->first_is_header = true;
+            if (!out->seq_start.empty()) out->headers += '\n';
+            out->headers.append(data + a, b - a);
+            out->seq_start.push_back((int64_t)out->joined.size());
+            out->header_line.push_back(out->n_lines);
+        } else {
+            out->joined.append(data + a, b - a);
+        }
+        out->n_lines++;
+        pos = next;
+    }
+}
+
 }  // namespace
 
 extern "C" int skr_seqs_pack(skr_ctx* ctx, const char* bases, const int64_t* offsets, int64_t n,
@@ -201,58 +244,107 @@ extern "C" int skr_seqs_from_fasta(skr_ctx* ctx, const char* path, const char al
         }
     }
     close(fd);
-    // Pass over the lines (universal newlines: \n, \r\n, \r).  A sequence spread over several
-    // lines is not contiguous in the file, so joined sequences are materialised in `joined`.
-    std::string joined;
-    joined.reserve(fsize);
-    std::vector<std::pair<int64_t, int64_t>> spans;  // (start, len) into `joined`
-    std::string headers;
+    // Lines (universal newlines: \n, \r\n, \r) are parsed by up to 16 threads, each on a piece of the
+    // file cut at line starts; a piece yields its sequence bytes, where each of its headers' sequences
+    // begins in them, and its first blank line.  The pieces are then stitched in file order: sequence
+    // lines at the head of a piece continue the last sequence of the piece before, and the checks that
+    // need the neighbouring lines (a header that follows a header) run on the stitched list.  The
+    // error reported is the one the reference's sequential loop would have reached first.
+    const int want_threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    size_t piece_min = 1u << 20;  // bytes below which another thread is not worth starting
+    if (const char* e = getenv("SEEKR_FASTA_PIECE_BYTES")) piece_min = (size_t)std::max(1, atoi(e));  // tests: force stitching
+    const int n_pieces = (int)std::max<size_t>(1, std::min<size_t>((size_t)want_threads, fsize / piece_min));
+    std::vector<size_t> cut((size_t)n_pieces + 1, fsize);
+    cut[0] = 0;
+    auto line_start = [&](size_t p) {
+        return p == 0 || data[p - 1] == '\n' || (data[p - 1] == '\r' && data[p] != '\n');
+    };
+    for (int i = 1; i < n_pieces; i++) {
+        size_t p = std::max(cut[i - 1], fsize / (size_t)n_pieces * (size_t)i);
+        while (p < fsize && !line_start(p)) p++;
+        cut[i] = p;
+    }
+    std::vector<FastaPiece> pieces((size_t)n_pieces);
+    {
+        std::vector<std::thread> th;
+        for (int i = 1; i < n_pieces; i++) th.emplace_back(parse_piece, data, cut[i], cut[i + 1], &pieces[i]);
+        parse_piece(data, cut[0], cut[1], &pieces[0]);
+        for (auto& t : th) t.join();
+    }
+    // ---- stitch
     int rc = SKR_OK;
-    int64_t lineno = 0;
-    bool have_pending = false;   // a sequence (possibly empty) is being accumulated
-    int64_t pending_start = 0;
-    bool first_line = true;
-    size_t pos = 0;
-    while (pos < fsize && rc == SKR_OK) {
-        size_t eol = pos;
-        while (eol < fsize && data[eol] != '\n' && data[eol] != '\r') eol++;
-        size_t next = eol;
-        if (next < fsize) next += (data[next] == '\r' && next + 1 < fsize && data[next + 1] == '\n') ? 2 : 1;
-        size_t a = pos, b = eol;
-        while (a < b && py_space((unsigned char)data[a])) a++;
-        while (b > a && py_space((unsigned char)data[b - 1])) b--;
-        if (a == b) {
+    int64_t err_line = INT64_MAX;  // line of the first error in file order
+    std::vector<int64_t> joined_off((size_t)n_pieces + 1, 0), line_off((size_t)n_pieces + 1, 0);
+    size_t n_headers = 0, header_bytes = 0;
+    for (int i = 0; i < n_pieces; i++) {
+        joined_off[i + 1] = joined_off[i] + (int64_t)pieces[i].joined.size();
+        line_off[i + 1] = line_off[i] + pieces[i].n_lines;
+        n_headers += pieces[i].seq_start.size();
+        header_bytes += pieces[i].headers.size() + 1;
+    }
+    const int64_t total_joined = joined_off[n_pieces];
+    if (line_off[n_pieces] > 0 && !pieces[0].first_is_header && pieces[0].blank_line != 0) {
+        rc = skr_set_error(SKR_ERR_INVALID, "'%s' does not start with a '>' header line", path);
+        err_line = 0;
+    }
+    for (int i = 0; i < n_pieces; i++)
+        if (pieces[i].blank_line >= 0 && line_off[i] + pieces[i].blank_line < err_line) {
+            err_line = line_off[i] + pieces[i].blank_line;
             rc = skr_set_error(SKR_ERR_FASTA_BLANK, "string index out of range");  // fasta_reader.py:53
+            break;  // later pieces only hold later lines
+        }
+    std::vector<int64_t> starts, hdr_lines;  // per sequence: first byte in the stitched buffer, line of its header
+    starts.reserve(n_headers + 1);
+    hdr_lines.reserve(n_headers);
+    std::string headers;
+    headers.reserve(header_bytes);
+    for (int i = 0; i < n_pieces; i++) {
+        for (size_t h = 0; h < pieces[i].seq_start.size(); h++) {
+            starts.push_back(joined_off[i] + pieces[i].seq_start[h]);
+            hdr_lines.push_back(line_off[i] + pieces[i].header_line[h]);
+        }
+        if (!pieces[i].headers.empty()) {
+            if (!headers.empty()) headers += '\n';
+            headers += pieces[i].headers;
+        }
+    }
+    starts.push_back(total_joined);
+    for (size_t j = 1; j < hdr_lines.size(); j++)
+        if (starts[j] == starts[j - 1]) {  // header j follows header j-1 without sequence bytes in between
+            if (hdr_lines[j] < err_line) {
+                err_line = hdr_lines[j];
+                rc = skr_set_error(SKR_ERR_FASTA_HEADER, "There may be a header without a sequence at line %lld.",
+                                   (long long)hdr_lines[j]);  // fasta_reader.py:58
+            }
             break;
         }
-        if (data[a] == '>') {
-            if (have_pending && (int64_t)joined.size() > pending_start) {
-                spans.emplace_back(pending_start, (int64_t)joined.size() - pending_start);
-            } else if (lineno != 0) {
-                rc = skr_set_error(SKR_ERR_FASTA_HEADER, "There may be a header without a sequence at line %lld.",
-                                   (long long)lineno);  // fasta_reader.py:58
-                break;
-            }
-            if (!headers.empty()) headers += '\n';
-            headers.append(data + a, b - a);
-            have_pending = true;
-            pending_start = (int64_t)joined.size();
-        } else {
-            if (first_line) {
-                rc = skr_set_error(SKR_ERR_INVALID, "'%s' does not start with a '>' header line", path);
-                break;
-            }
-            joined.append(data + a, b - a);
-        }
-        first_line = false;
-        lineno++;
-        pos = next;
+    if (rc != SKR_OK) {
+        if (data) munmap((void*)data, fsize);
+        return rc;
     }
-    if (rc == SKR_OK && have_pending) spans.emplace_back(pending_start, (int64_t)joined.size() - pending_start);
     if (data) munmap((void*)data, fsize);
-    if (rc != SKR_OK) return rc;
-    std::vector<SeqView> seqs(spans.size());
-    for (size_t i = 0; i < spans.size(); i++) seqs[i] = {joined.data() + spans[i].first, spans[i].second};
+    // Sequences stay where the pieces put them; only one that runs over a piece boundary (at most one
+    // per boundary) is copied together.
+    std::vector<SeqView> seqs(hdr_lines.size());
+    std::vector<std::string> bridges;
+    bridges.reserve((size_t)n_pieces);
+    int pc = 0;
+    for (size_t j = 0; j < seqs.size(); j++) {
+        const int64_t lo = starts[j], hi = starts[j + 1];
+        while (pc + 1 < n_pieces && lo >= joined_off[pc + 1]) pc++;
+        if (hi <= joined_off[pc + 1]) {
+            seqs[j] = {pieces[pc].joined.data() + (lo - joined_off[pc]), hi - lo};
+        } else {
+            std::string whole;
+            whole.reserve((size_t)(hi - lo));
+            for (int q = pc; q < n_pieces && joined_off[q] < hi; q++) {
+                const int64_t a0 = std::max(lo, joined_off[q]), a1 = std::min(hi, joined_off[q + 1]);
+                if (a1 > a0) whole.append(pieces[q].joined.data() + (a0 - joined_off[q]), (size_t)(a1 - a0));
+            }
+            bridges.push_back(std::move(whole));
+            seqs[j] = {bridges.back().data(), hi - lo};
+        }
+    }
     return upload_seqs(ctx, seqs, lut, std::move(headers), out);
 }
 

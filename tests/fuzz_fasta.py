@@ -50,6 +50,12 @@ def fuzz(seed, budget_s=30.0, max_cases=10 ** 9):
         with open(path, "w", newline="") as fh:
             fh.write(text)
         k = int(rng.integers(1, 4))
+        # the reader parses big files in pieces on several threads and stitches them; force that on small files
+        piece = int(rng.choice([0, 1, 7, 40, 300]))
+        if piece:
+            os.environ["SEEKR_FASTA_PIECE_BYTES"] = str(piece)
+        else:
+            os.environ.pop("SEEKR_FASTA_PIECE_BYTES", None)
         try:
             headers, seqs = orc.read_fasta(path)
             want_exc = None
@@ -75,9 +81,10 @@ def fuzz(seed, budget_s=30.0, max_cases=10 ** 9):
             os.makedirs(out, exist_ok=True)
             with open(os.path.join(out, "fuzz_fasta_fail_%d_%d.fa" % (seed, n_cases)), "w", newline="") as fh:
                 fh.write(text)
-            print(repr(text[:400]))
+            print("piece bytes", piece, repr(text[:400]))
             raise
         n_cases += 1
+    os.environ.pop("SEEKR_FASTA_PIECE_BYTES", None)
     return n_cases
 
 
