@@ -8,6 +8,7 @@
 //   * every elementwise step is a separately rounded float32 operation (no FMA contraction).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "common.hpp"
 
@@ -18,7 +19,8 @@ namespace {
 constexpr int kColsPerWG = 16;    // 64-byte column strip per workgroup: 4^6 columns -> 256 workgroups, one per CU
 constexpr int kTileRows = 512;    // rows staged in LDS per step (32 KiB)
 constexpr int kDepth = 4;         // tiles in flight per workgroup (register ring): 128 KiB of HBM loads
-constexpr int kThreads = 256;
+constexpr int kThreads = 256;      // staging threads (waves 1..4); wave 0 of the workgroup only walks
+constexpr int kWgThreads = kThreads + 64;
 constexpr int kLanesPerRow = kColsPerWG / 4;             // 16-byte loads
 constexpr int kRowsPerPass = kThreads / kLanesPerRow;    // rows covered by one load instruction
 constexpr int kLoads = kTileRows / kRowsPerPass;         // loads per thread per tile
@@ -43,25 +45,96 @@ __device__ __forceinline__ float div_scale(float x, const void* vec, int64_t col
 // Sequential column sums.  The chain acc = fl32(acc + x[i, j]) over i is inherently serial per
 // column, so the kernel is organised around keeping HBM busy while one lane per column walks:
 //   * a workgroup owns a strip of 16 columns (64 B per row); 4^6 columns give 256 workgroups;
-//   * all 256 threads stream tiles of 512 rows x 16 columns (16-byte loads, t() applied on the
-//     way) through a ring of kDepth register tiles into a double-buffered LDS tile, so 128 KiB
-//     of loads per workgroup are in flight while the walk proceeds;
-//   * lanes 0..15 of wave 0 walk the current LDS tile row by row, each extending one column's
-//     float32 chain (~5 cycles per row: the walk, not HBM latency, paces a tile).
+//   * waves 1..4 (256 threads) stream tiles of 512 rows x 16 columns (16-byte loads, t() applied
+//     on the way) through a ring of kDepth register tiles into a double-buffered LDS tile, so
+//     128 KiB of loads per workgroup are in flight while the walk proceeds;
+//   * wave 0 does nothing but walk: lanes 0..15 go down the current LDS tile row by row, each
+//     extending one column's float32 chain.  The chain of dependent v_add_f32 paces the kernel
+//     (not HBM latency), so the walker carries no staging work: one barrier per tile is all that
+//     stands between two tiles of its chain.
 // ---------------------------------------------------------------------------------------
-template <int CK, bool SQUARE>
-__global__ __launch_bounds__(kThreads) void colsum_seq_kernel(const float* __restrict__ x, int64_t rows,
+template <int CK, bool SQUARE, bool VEC>
+__global__ __launch_bounds__(kWgThreads) void colsum_seq_kernel(const float* __restrict__ x, int64_t rows,
                                                               int64_t cols, const void* __restrict__ center,
                                                               const float* __restrict__ center2,
                                                               float* __restrict__ acc) {
     // column-major tile so that the walker fetches 4 consecutive rows of its column with one
     // ds_read_b128; +4 floats of padding per column keep the 16 walker lanes on distinct banks
     __shared__ __attribute__((aligned(16))) float tile[2][kColsPerWG][kTileRows + 4];
-    const int tid = threadIdx.x;
-    const int64_t col0 = (int64_t)blockIdx.x * kColsPerWG;
+    // Workgroups are dealt to the 8 XCDs round-robin by blockIdx, and each XCD has its own L2.  A strip is
+    // 64 bytes wide — half a cache line — so neighbouring strips placed on different XCDs make HBM deliver
+    // every line twice.  G neighbouring strips (G * 64 contiguous bytes of each row) go to the same XCD.
+    int64_t strip = blockIdx.x;
+    {
+        constexpr int G = 4;
+        const int64_t full = ((int64_t)gridDim.x / (8 * G)) * (8 * G);
+        if (strip < full) {
+            const int64_t xcd = strip % 8, slot = strip / 8;
+            strip = ((slot / G) * 8 + xcd) * G + (slot % G);
+        }
+    }
+    const int64_t col0 = strip * kColsPerWG;
+    const int64_t n_tiles = (rows + kTileRows - 1) / kTileRows;
+    // both roles run the tile loop to a multiple of kDepth: the stagers' loop then has no conditional load in
+    // it, which is what lets hipcc keep counted vmcnt waits (three tiles in flight behind the one being stored)
+    const int64_t n_pad = (n_tiles + kDepth - 1) / kDepth * kDepth;
+    if (threadIdx.x < 64) {  // ---- the walker wave
+        const int wl = threadIdx.x;
+        const bool mine = wl < kColsPerWG && col0 + wl < cols;
+        float running = mine ? acc[col0 + wl] : 0.f;
+        for (int64_t t = -kDepth; t < n_pad; t++) {
+            __syncthreads();  // tile t is in buffer t & 1 (the first kDepth rounds only fill the stagers' ring)
+            if (wl < kColsPerWG && t >= 0 && t < n_tiles) {
+                const int64_t left = rows - t * kTileRows;
+                const int nr = (int)(left < kTileRows ? left : kTileRows);
+                const float* colp = &tile[t & 1][wl][0];
+                if (nr == kTileRows) {
+                    // software-pipelined: the ds_read_b128 of the next 64 rows are in flight while the
+                    // 64 dependent adds of the current ones retire (an LDS read takes ~130 cycles; left
+                    // to the compiler it was exposed once per 64 rows: 13 cycles per row instead of ~8)
+                    // (8 reads per batch: lgkmcnt counts at most 15 outstanding LDS operations)
+                    constexpr int kBatch = 8, kBatches = kTileRows / (4 * kBatch);
+                    float4 q[2][kBatch];
+#pragma unroll
+                    for (int i = 0; i < kBatch; i++) q[0][i] = *reinterpret_cast<const float4*>(colp + 4 * i);
+#pragma unroll
+                    for (int b = 0; b < kBatches; b++) {
+                        if (b + 1 < kBatches) {
+#pragma unroll
+                            for (int i = 0; i < kBatch; i++)
+                                q[(b + 1) & 1][i] = *reinterpret_cast<const float4*>(colp + (b + 1) * 4 * kBatch + 4 * i);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above the adds it overlaps with
+#pragma unroll
+                        for (int i = 0; i < kBatch; i++) {
+                            running = __fadd_rn(running, q[b & 1][i].x);
+                            running = __fadd_rn(running, q[b & 1][i].y);
+                            running = __fadd_rn(running, q[b & 1][i].z);
+                            running = __fadd_rn(running, q[b & 1][i].w);
+                        }
+                    }
+                } else {
+                    const int nr4 = nr & ~3;
+                    for (int r = 0; r < nr4; r += 4) {
+                        const float4 q = *reinterpret_cast<const float4*>(colp + r);
+                        running = __fadd_rn(running, q.x);
+                        running = __fadd_rn(running, q.y);
+                        running = __fadd_rn(running, q.z);
+                        running = __fadd_rn(running, q.w);
+                    }
+                    for (int r = nr4; r < nr; r++) running = __fadd_rn(running, colp[r]);
+                }
+            }
+            // the stagers refill buffer t & 1 with tile t + 2 only after the barrier of tile t + 1,
+            // which this wave reaches when it is done here
+        }
+        if (mine) acc[col0 + wl] = running;
+        return;
+    }
+    // ---- the staging waves
+    const int tid = threadIdx.x - 64;
     const int lane_c4 = (tid % kLanesPerRow) * 4;  // 4 consecutive columns handled by this thread
     const int lane_r = tid / kLanesPerRow;         // row inside a kRowsPerPass-row slab
-    const bool vec_ok = (cols % 4 == 0) && (col0 + kColsPerWG <= cols);
 
     float c2[4] = {0, 0, 0, 0};
     if (SQUARE && center2) {
@@ -69,10 +142,8 @@ __global__ __launch_bounds__(kThreads) void colsum_seq_kernel(const float* __res
             if (col0 + lane_c4 + j < cols) c2[j] = center2[col0 + lane_c4 + j];
     }
 
-    // Loads are unconditional (row index clamped; rows past the end are never walked): a branch
-    // around a load would make hipcc drain vmcnt(0) at every join and serialise the ring.
     auto load_tile = [&](int64_t row_base, float4 (&regs)[kLoads]) {
-        if (vec_ok) {
+        if (VEC) {
 #pragma unroll
             for (int s = 0; s < kLoads; s++) {
                 int64_t r = row_base + s * kRowsPerPass + lane_r;
@@ -123,54 +194,20 @@ __global__ __launch_bounds__(kThreads) void colsum_seq_kernel(const float* __res
         }
     };
 
-    float running = 0.f;
-    if (tid < kColsPerWG && col0 + tid < cols) running = acc[col0 + tid];
-
-    float4 ring[kDepth][kLoads];
-    const int64_t n_tiles = (rows + kTileRows - 1) / kTileRows;
-#pragma unroll
-    for (int d = 0; d < kDepth; d++)
-        if (d < n_tiles) load_tile((int64_t)d * kTileRows, ring[d]);
-    for (int64_t t0 = 0; t0 < n_tiles; t0 += kDepth) {
+    // Every load below is unconditional (row indices clamped; tiles past the end re-read the last row and are
+    // never walked): a branch around a load makes hipcc drain vmcnt(0) at the next use and serialises the ring.
+    // ... and so does a prologue that fills the ring in front of the loop (hipcc then waits vmcnt(0) at the loop
+    // head).  The loop therefore starts one round early with an empty ring: that round stores zeros nobody
+    // walks and issues the loads of tiles 0 .. kDepth-1.
+    float4 ring[kDepth][kLoads] = {};
+    for (int64_t t0 = -kDepth; t0 < n_pad; t0 += kDepth) {
 #pragma unroll
         for (int d = 0; d < kDepth; d++) {  // static ring index: the tiles stay in registers
-            const int64_t t = t0 + d;
-            if (t < n_tiles) {
-                const int buf = d & 1;  // kDepth is even, so this is t & 1
-                store_tile(buf, ring[d]);  // waits only for this tile's (oldest) loads
-                __syncthreads();
-                if (t + kDepth < n_tiles) load_tile((t + kDepth) * kTileRows, ring[d]);
-                if (tid < kColsPerWG) {
-                    const int64_t left = rows - t * kTileRows;
-                    const int nr = (int)(left < kTileRows ? left : kTileRows);
-                    const float* colp = &tile[buf][tid][0];
-                    const int nr4 = nr & ~3;
-                    if (nr == kTileRows) {
-#pragma unroll 16
-                        for (int r = 0; r < kTileRows; r += 4) {
-                            const float4 q = *reinterpret_cast<const float4*>(colp + r);
-                            running = __fadd_rn(running, q.x);
-                            running = __fadd_rn(running, q.y);
-                            running = __fadd_rn(running, q.z);
-                            running = __fadd_rn(running, q.w);
-                        }
-                    } else {
-                        for (int r = 0; r < nr4; r += 4) {
-                            const float4 q = *reinterpret_cast<const float4*>(colp + r);
-                            running = __fadd_rn(running, q.x);
-                            running = __fadd_rn(running, q.y);
-                            running = __fadd_rn(running, q.z);
-                            running = __fadd_rn(running, q.w);
-                        }
-                        for (int r = nr4; r < nr; r++) running = __fadd_rn(running, colp[r]);
-                    }
-                }
-                // buffer `buf` is rewritten two tiles later, after the walker has passed the next
-                // barrier: one barrier per tile is enough
-            }
+            store_tile(d & 1, ring[d]);     // kDepth is even, so d & 1 == t & 1; waits only for this tile's (oldest) loads
+            __syncthreads();
+            load_tile((t0 + d + kDepth) * kTileRows, ring[d]);
         }
     }
-    if (tid < kColsPerWG && col0 + tid < cols) acc[col0 + tid] = running;
 }
 
 __global__ void vec_finish_kernel(float* v, int64_t cols, float n, int take_sqrt) {
@@ -359,14 +396,21 @@ extern "C" int skr_colsum_seq(skr_ctx* ctx, const skr_mat* x, const skr_mat* cen
         SKR_REQUIRE(center2->rows * center2->cols == x->cols, "center2 must hold one float per column");
     }
     SKR_TRY(skr_activate(ctx));
-    if (x->cols == 0) return SKR_OK;
+    if (x->cols == 0 || x->rows == 0) return SKR_OK;  // no rows: acc stays as it is
     const unsigned grid = (unsigned)((x->cols + kColsPerWG - 1) / kColsPerWG);
     const float* c2 = center2 ? (const float*)center2->data : nullptr;
     const void* c1 = center ? center->data : nullptr;
     SkrProfScope prof(ctx, square ? "colsum_seq_sq" : "colsum_seq");
+    const bool vec = x->cols % kColsPerWG == 0;  // every strip is full: 16-byte loads
 #define LAUNCH(CK_, SQ_)                                                                                         \
-    hipLaunchKernelGGL((colsum_seq_kernel<CK_, SQ_>), dim3(grid), dim3(kThreads), 0, ctx->stream,                \
-                       (const float*)x->data, x->rows, x->cols, c1, c2, (float*)acc->data)
+    do {                                                                                                         \
+        if (vec)                                                                                                 \
+            hipLaunchKernelGGL((colsum_seq_kernel<CK_, SQ_, true>), dim3(grid), dim3(kWgThreads), 0, ctx->stream, \
+                               (const float*)x->data, x->rows, x->cols, c1, c2, (float*)acc->data);              \
+        else                                                                                                     \
+            hipLaunchKernelGGL((colsum_seq_kernel<CK_, SQ_, false>), dim3(grid), dim3(kWgThreads), 0, ctx->stream, \
+                               (const float*)x->data, x->rows, x->cols, c1, c2, (float*)acc->data);              \
+    } while (0)
     if (square) {
         if (ck == C_NONE) LAUNCH(C_NONE, true);
         else if (ck == C_F32) LAUNCH(C_F32, true);
