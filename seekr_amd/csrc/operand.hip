@@ -791,7 +791,8 @@ extern "C" int skr_pearson_gemm(skr_ctx* ctx, const skr_mat* a, const skr_mat* b
     if (a->dtype == SKR_F64) {
         SKR_REQUIRE(precision == SKR_PREC_F64, "float64 operands need SKR_PREC_F64");
         return skr_launch_gemm_f64(ctx, (const double*)a->data, (const double*)b->data,
-                                   (double*)r->data + (size_t)row0 * r->cols + col0, a->rows, b->rows, a->cols, r->cols);
+                                   (double*)r->data + (size_t)row0 * r->cols + col0, a->rows, b->rows, a->cols, a->cols,
+                                   b->cols, r->cols, (double)a->cols, symmetric && row0 == col0);
     }
     SKR_REQUIRE(is_f32_precision(precision),
                 "float32 operands need SKR_PREC_FP32, SKR_PREC_BF16X3, SKR_PREC_BF16X4 or SKR_PREC_F16X3");
@@ -820,14 +821,23 @@ extern "C" int skr_pearson(skr_ctx* ctx, const skr_mat* counts1, const skr_mat* 
     const bool same = counts1 == counts2;
     if (counts1->dtype == SKR_F64) {
         if (!row_standardize) return skr_pearson_gemm(ctx, counts1, counts2, precision, 0, r, 0, 0);
+        SKR_REQUIRE(precision == SKR_PREC_F64, "float64 operands need SKR_PREC_F64");
+        SKR_REQUIRE(r->dtype == SKR_F64 && r->ctx == ctx, "result matrix must be a float64 matrix of this ctx");
+        if (counts1->rows == 0 || counts2->rows == 0) return SKR_OK;
+        // standardised rows are zero-padded to whole 16-k stages of the tiled contraction (zeros add nothing)
+        const int64_t K = counts1->cols, Kp = (K + 15) / 16 * 16;
         skr_mat *z1 = nullptr, *z2 = nullptr;
-        int rc = skr_mat_create(ctx, counts1->rows, counts1->cols, SKR_F64, &z1);
+        int rc = skr_mat_create(ctx, counts1->rows, Kp, SKR_F64, &z1);
         if (rc == SKR_OK) rc = skr_row_standardize(ctx, counts1, z1);
         if (rc == SKR_OK && !same) {
-            rc = skr_mat_create(ctx, counts2->rows, counts2->cols, SKR_F64, &z2);
+            rc = skr_mat_create(ctx, counts2->rows, Kp, SKR_F64, &z2);
             if (rc == SKR_OK) rc = skr_row_standardize(ctx, counts2, z2);
         }
-        if (rc == SKR_OK) rc = skr_pearson_gemm(ctx, z1, same ? z1 : z2, precision, same, r, 0, 0);
+        if (rc == SKR_OK) {
+            const skr_mat* zb = same ? z1 : z2;
+            rc = skr_launch_gemm_f64(ctx, (const double*)z1->data, (const double*)zb->data, (double*)r->data, z1->rows,
+                                     zb->rows, Kp, Kp, Kp, r->cols, (double)K, same);
+        }
         skr_mat_free(z1);
         skr_mat_free(z2);
         return rc;

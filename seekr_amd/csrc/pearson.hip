@@ -263,6 +263,105 @@ __global__ __launch_bounds__(256) void pearson_gemm_f64_kernel(const double* __r
             }
 }
 
+
+// The same contraction, LDS-tiled: 128 x 128 block tile, 16 k per stage, 4 waves as 2 x 2, each wave
+// 64 x 64 = 4 x 4 MFMA tiles (64 float64 accumulators per lane).  The one-wave-per-32x32 kernel above
+// streams 4 flop per byte through the L2 (17 TFLOP/s, L2-bandwidth-bound); a 128 x 128 tile moves 16
+// flop per byte, and the operand tiles reach the LDS by 16-byte LDS-DMA, double buffered, one barrier
+// per stage.  The LDS image of an LDS-DMA is lane-linear, and 16 rows at a 128-byte pitch share two
+// bank groups: read as they lie, every ds_read_b64 cost 128 conflict cycles and the LDS (80 % busy)
+// held the matrix cores at 40 %.  So, as in the 16-bit kernel, the swizzle goes on the per-lane SOURCE
+// address — 16-byte chunk c of row r lives at chunk position c ^ ((r >> 1) & 7) — and is undone on
+// the read: two lanes per bank, the minimum for 512 bytes.
+// SYM (self-comparison): tiles below the diagonal are skipped and written as mirrors of the ones above.
+constexpr int DT = 128, DK = 16;
+constexpr int kRowBytes64 = DK * 8;                 // 128
+constexpr int kStageBytes64 = 2 * DT * kRowBytes64;  // A tile + B tile: 32 KiB
+
+template <bool SYM>
+__global__ __launch_bounds__(256, 2) void pearson_gemm_f64_tiled_kernel(
+    const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C, int64_t M, int64_t N, int64_t K,
+    int64_t lda, int64_t ldb, int64_t ldc, double kdiv, int64_t tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int64_t tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    if (SYM && tn < tm) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t row_base = tm * DT, col_base = tn * DT;
+
+    // staging: one LDS-DMA wave-instruction moves 8 rows x 128 bytes; wave w moves pieces 4w .. 4w+3 of A and of B
+    const char* a_src[4];
+    const char* b_src[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int row = (wave * 4 + p) * 8 + (lane >> 3);
+        const int64_t ra = std::min<int64_t>(row_base + row, M - 1);  // rows past the end re-read the last one
+        const int64_t rb = std::min<int64_t>(col_base + row, N - 1);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        a_src[p] = reinterpret_cast<const char*>(A + (size_t)ra * lda) + chunk * 16;
+        b_src[p] = reinterpret_cast<const char*>(B + (size_t)rb * ldb) + chunk * 16;
+    }
+    auto stage = [&](int buf, int64_t k0) {
+        char* abase = smem + buf * kStageBytes64;
+        char* bbase = abase + DT * kRowBytes64;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            lds_dma16(a_src[p] + k0 * 8, abase + (wave * 4 + p) * 1024);
+            lds_dma16(b_src[p] + k0 * 8, bbase + (wave * 4 + p) * 1024);
+        }
+    };
+    const int r16 = lane & 15, kq = lane >> 4;
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[i][j][e] = 0.0;
+
+    int cur = 0;
+    stage(0, 0);
+    __syncthreads();
+    for (int64_t k0 = 0; k0 < K; k0 += DK) {
+        if (k0 + DK < K) stage(cur ^ 1, k0 + DK);
+        const char* abase = smem + cur * kStageBytes64 + (wm * 64 + r16) * kRowBytes64 + (kq & 1) * 8;
+        const char* bbase = smem + cur * kStageBytes64 + DT * kRowBytes64 + (wn * 64 + r16) * kRowBytes64 + (kq & 1) * 8;
+#pragma unroll
+        for (int kk = 0; kk < DK / 4; kk++) {
+            double a[4], b[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                // rows of one fragment differ by multiples of 16, so (row >> 1) & 7 is (r16 >> 1) for A and B alike
+                const int pos = ((kk * 2 + (kq >> 1)) ^ (r16 >> 1)) << 4;
+                a[t] = *reinterpret_cast<const double*>(abase + t * 16 * kRowBytes64 + pos);
+                b[t] = *reinterpret_cast<const double*>(bbase + t * 16 * kRowBytes64 + pos);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    const bool mirror = SYM && tm != tn;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int64_t m = row_base + wm * 64 + i * 16 + kq + 4 * e;
+                const int64_t n = col_base + wn * 64 + j * 16 + r16;
+                if (m < M && n < N) {
+                    const double v = acc[i][j][e] / kdiv;
+                    C[(size_t)m * ldc + n] = v;
+                    if (mirror) C[(size_t)n * ldc + m] = v;
+                }
+            }
+}
+
 }  // namespace
 
 extern "C" int skr_row_standardize(skr_ctx* ctx, const skr_mat* x, skr_mat* z) {
@@ -298,12 +397,28 @@ int skr_launch_gemm_f32(skr_ctx* ctx, const float* A, const float* B, float* C, 
 }
 
 int skr_launch_gemm_f64(skr_ctx* ctx, const double* A, const double* B, double* C, int64_t M, int64_t N, int64_t K,
-                        int64_t ldc) {
-    const int64_t tiles_m = (M + 31) / 32, tiles_n = (N + 31) / 32;
-    const unsigned grid = (unsigned)((tiles_m * tiles_n + 3) / 4);
+                        int64_t lda, int64_t ldb, int64_t ldc, double kdiv, int symmetric) {
     SkrProfScope prof(ctx, "pearson_gemm_f64");
-    hipLaunchKernelGGL(pearson_gemm_f64_kernel, dim3(grid), dim3(256), 0, ctx->stream, A, B, C, M, N, K, K, K, ldc,
-                       (double)K, tiles_n);
+    if (K % DK == 0 && lda % 2 == 0 && ldb % 2 == 0) {  // whole stages, 16-byte aligned rows: the tiled kernel
+        const int64_t tiles_m = (M + DT - 1) / DT, tiles_n = (N + DT - 1) / DT;
+        const bool sym = symmetric && A == B && M == N && lda == ldb;  // mirrors land inside the same square block
+        if (sym) {
+            SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pearson_gemm_f64_tiled_kernel<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes64));
+            hipLaunchKernelGGL(pearson_gemm_f64_tiled_kernel<true>, dim3((unsigned)(tiles_m * tiles_n)), dim3(256),
+                               2 * kStageBytes64, ctx->stream, A, B, C, M, N, K, lda, ldb, ldc, kdiv, tiles_n);
+        } else {
+            SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pearson_gemm_f64_tiled_kernel<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes64));
+            hipLaunchKernelGGL(pearson_gemm_f64_tiled_kernel<false>, dim3((unsigned)(tiles_m * tiles_n)), dim3(256),
+                               2 * kStageBytes64, ctx->stream, A, B, C, M, N, K, lda, ldb, ldc, kdiv, tiles_n);
+        }
+    } else {
+        const int64_t tiles_m = (M + 31) / 32, tiles_n = (N + 31) / 32;
+        const unsigned grid = (unsigned)((tiles_m * tiles_n + 3) / 4);
+        hipLaunchKernelGGL(pearson_gemm_f64_kernel, dim3(grid), dim3(256), 0, ctx->stream, A, B, C, M, N, K, lda, ldb, ldc,
+                           kdiv, tiles_n);
+    }
     SKR_HIP(hipGetLastError());
     return SKR_OK;
 }
