@@ -1,82 +1,92 @@
-"""FASTA reader with the semantics of the reference `seekr.fasta_reader.Reader`
-(fasta_reader.py:9-109): same constructor, same methods, same error behaviour.
+"""Host-side FASTA access with the behaviour of `seekr.fasta_reader.Reader` (fasta_reader.py:9-109).
 
-This class produces Python strings for callers that want them (`get_seqs`, `get_headers`,
-`get_data`, header rewriting).  The counting path itself does not go through it: the
-native reader in libseekr_hip (`skr_seqs_from_fasta`) parses and packs the file directly.
+Python strings for the callers that want them (headers, sequences, rewritten headers).  Counting does
+not go through here: `skr_seqs_from_fasta` in libseekr_hip parses and packs the file natively; this
+module is the small pure-Python counterpart that keeps the reference's class usable (`seqs` of a
+BasicCounter, labelled CSV rows, `supply_basic_header`).
 """
+
+HEADER_MARK = ">"
+
+
+def split_records(stripped_lines):
+    """(headers, sequences) from lines that have already been `str.strip()`ped.
+
+    Rules of fasta_reader.py:47-63, including its failure modes: an empty line fails on `line[0]`
+    (IndexError), a header that follows another header — anywhere but on the first line — trips the
+    assertion, sequences are upper-cased, and a header at the very end gets an empty sequence."""
+    headers, sequences, pieces = [], [], []
+    for index, line in enumerate(stripped_lines):
+        first = line[0]
+        if first != HEADER_MARK:
+            pieces.append(line)
+            continue
+        if pieces:
+            sequences.append("".join(pieces).upper())
+            pieces = []
+        elif index:
+            raise AssertionError("There may be a header without a sequence at line {}.".format(index))
+        headers.append(line)
+    sequences.append("".join(pieces).upper())
+    return headers, sequences
+
+
+def interleave(headers, sequences):
+    """[h0, s0, h1, s1, ...] — the shape the reference keeps in `Reader.data`."""
+    out = []
+    for pair in zip(headers, sequences):
+        out.extend(pair)
+    if len(sequences) > len(headers):  # sequence lines without any header: the reference keeps them as one record
+        out.extend(sequences[len(headers):])
+    return out
 
 
 class Reader:
-    """Normalises a FASTA file: one upper-case sequence string per header.
-
-    Parameters mirror the reference (fasta_reader.py:34-39): `infasta` path to read,
-    `outfasta` path used by `save`, `names` iterable of replacement names used by
-    `supply_basic_header`.  `data` holds the header/sequence lines after a `get_*` call.
-    """
+    """`Reader(infasta, outfasta=None, names=None)`; `data` is filled by the `get_*` methods."""
 
     def __init__(self, infasta=None, outfasta=None, names=None):
-        self.infasta = infasta
-        self.outfasta = outfasta
-        self.names = names
+        self.infasta, self.outfasta, self.names = infasta, outfasta, names
         self.data = None
 
-    # fasta_reader.py:41-45
-    def _read_data(self):
-        with open(self.infasta) as handle:
-            self.data = [line.strip() for line in handle]
-
-    # fasta_reader.py:47-63
-    def _upper_seq_per_line(self):
-        records = []
-        parts = []
-        for lineno, text in enumerate(self.data):
-            if text[0] == ">":  # a blank line raises IndexError here, as upstream
-                if parts:
-                    records.append("".join(parts).upper())
-                    parts = []
-                else:
-                    assert lineno == 0, "There may be a header without a sequence at line {}.".format(lineno)
-                records.append(text)
-            elif text:
-                parts.append(text)
-        records.append("".join(parts).upper())
-        self.data = records
+    def _load(self):
+        with open(self.infasta) as fh:
+            stripped = [raw.strip() for raw in fh]
+        headers, sequences = split_records(stripped)
+        self.data = interleave(headers, sequences)
+        return headers, sequences
 
     def get_lines(self):
-        self._read_data()
-        self._upper_seq_per_line()
+        self._load()
         return self.data
 
-    def get_seqs(self):
-        return self.get_lines()[1::2]
-
     def get_headers(self):
-        return self.get_lines()[0::2]
+        self._load()
+        return self.data[0::2]
+
+    def get_seqs(self):
+        self._load()
+        return self.data[1::2]
 
     def get_data(self, tuples_only=False):
-        lines = self.get_lines()
-        headers, seqs = lines[0::2], lines[1::2]
-        pairs = zip(headers, seqs)
-        if tuples_only:
-            return pairs
-        return pairs, headers, seqs
+        self._load()
+        headers, sequences = self.data[0::2], self.data[1::2]
+        tuples = zip(headers, sequences)
+        return tuples if tuples_only else (tuples, headers, sequences)
 
-    # fasta_reader.py:90-103
     def supply_basic_header(self):
-        """Rewrite headers GENCODE-style, keeping only a common name and the length."""
+        """GENCODE-looking headers `>||||name||length|` from `names` (default: the file's own headers),
+        fasta_reader.py:90-103.  Returns the new line list; `data` itself is left alone."""
         if self.names is None:
             self.names = iter(self.get_headers())
-        rewritten = []
-        for pos, text in enumerate(self.data):
-            if text[0] == ">":
-                label = next(self.names).strip(">")
-                rewritten.append(">||||{}||{}|".format(label, len(self.data[pos + 1])))
-            else:
-                rewritten.append(text)
-        return rewritten
+        lines = []
+        for at, line in enumerate(self.data):
+            if line[0] == HEADER_MARK:
+                name = next(self.names).strip(HEADER_MARK)
+                line = "{0}||||{1}||{2}|".format(HEADER_MARK, name, len(self.data[at + 1]))
+            lines.append(line)
+        return lines
 
-    # fasta_reader.py:105-109
     def save(self):
-        with open(self.outfasta, "w") as handle:
-            handle.writelines(line + "\n" for line in self.data)
+        """Writes `data`, one entry per line, to `outfasta` (fasta_reader.py:105-109)."""
+        with open(self.outfasta, "w") as fh:
+            fh.write("".join(entry + "\n" for entry in self.data))
