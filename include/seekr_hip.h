@@ -122,6 +122,15 @@ int skr_count_u32(skr_ctx* ctx, const skr_seqs* s, int k, skr_mat* out);
  * Returns SKR_ERR_ZERODIV if any sequence has length k-1.                                   */
 int skr_count_per_kb(skr_ctx* ctx, const skr_seqs* s, int k, int log2_pre, skr_mat* out);
 
+/* Any alphabet (kmer_counts.py:120-122 takes any string): `alen` letters give alen^k columns,
+ * column = sum code(c_p) * alen^(k-1-p), code = position in `alphabet` — the LAST position for a
+ * repeated letter, as the reference's dict {kmer: index} resolves it.  Sequences come as one ASCII
+ * buffer + n+1 offsets (no case folding, like skr_seqs_pack); `out` is [n, alen^k] SKR_F32 /
+ * SKR_F64 (per-kb values as skr_count_per_kb) or SKR_U32 (raw counts).  The 2-bit kernels behind
+ * skr_count_per_kb are the fast path for 4 distinct letters; this one serves everything else.   */
+int skr_count_generic(skr_ctx* ctx, const char* bases, const int64_t* offsets, int64_t n, const char* alphabet,
+                      int alen, int k, int log2_pre, skr_mat* out);
+
 /* ---------------------------------------------------------------- normalisation (K4+K5) - */
 /* Sequential float32 column sums in row order, continuing from `acc` (1 x cols, SKR_F32):
  *     acc[j] = fl32(acc[j] + t(x[i, j]))   for i = 0 .. rows-1

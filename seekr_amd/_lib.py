@@ -64,6 +64,7 @@ SIGNATURES = {
     "skr_row_standardize": (_int, [_p, _p, _p]),
     "skr_pearson_gemm": (_int, [_p, _p, _p, _int, _int, _p, _i64, _i64]),
     "skr_pearson": (_int, [_p, _p, _p, _int, _int, _p]),
+    "skr_count_generic": (_int, [_p, _p, _p, _i64, C.c_char_p, _int, _int, _int, _p]),
     "skr_host_get_counts": (_int, [_p, _p, _int, _int, _int, _p, _int, _int, _p, _int, _p, _p, _p, C.POINTER(_int)]),
     "skr_host_pearson": (_int, [_p, _p, _i64, _p, _i64, _i64, _int, _int, _int, _p]),
     "skr_operand_create": (_int, [_p, _i64, _i64, _int, C.POINTER(_p)]),
@@ -447,6 +448,21 @@ def count_per_kb(ctx, seqs, k, log2_pre=False, dtype=np.float32, out=None):
     if out is None:
         out = ctx.empty(seqs.n, 4 ** k, dtype)
     check(lib().skr_count_per_kb(ctx._h, seqs._h, int(k), 1 if log2_pre else 0, out._h))
+    return out
+
+
+def count_generic(ctx, seqs, alphabet, k, dtype=np.float32, log2_pre=False):
+    """Counts for an alphabet the 2-bit path does not cover (not 4 letters, or a repeated letter):
+    [n, len(alphabet)^k] per-kb values (float32 / float64) or raw counts (uint32)."""
+    seqs = list(seqs)
+    lengths = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
+    offsets = np.zeros(len(seqs) + 1, dtype=np.int64)
+    np.cumsum(lengths, out=offsets[1:])
+    blob = "".join(seqs).encode("latin-1", "replace")
+    alpha = alphabet.encode("latin-1", "replace")
+    out = ctx.empty(len(seqs), len(alpha) ** k, dtype)
+    check(lib().skr_count_generic(ctx._h, C.cast(C.c_char_p(blob), _p), offsets.ctypes.data_as(_p), len(seqs), alpha,
+                                  len(alpha), int(k), 1 if log2_pre else 0, out._h))
     return out
 
 

@@ -16,6 +16,10 @@
 // k >= 8 (4^k bins no longer fit the LDS): the same kernel with GLOBAL = true counts straight into
 // the sequence's output row, used as a uint32 histogram in HBM (zeroed by a memset first, L2
 // atomics), and the flush converts the row in place.
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
 #include "common.hpp"
 
 namespace {
@@ -231,7 +235,134 @@ int check_count_args(skr_ctx* ctx, const skr_seqs* s, int k, const skr_mat* out)
     return SKR_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Any alphabet (kmer_counts.py:120-122 takes any string: A = len(alphabet) letters, A^k columns,
+// column = sum code(c_p) * A^(k-1-p)).  Nothing here is bit-packed: sequences stay ASCII on the device,
+// a window's column is computed from its k characters, counts go to a uint32 scratch histogram
+// (one row per sequence of the batch, L2 atomics) and a second kernel turns the batch into the
+// output dtype with the same per-kb arithmetic as the 4-letter path.  A correctness path for the rare
+// caller; the 4-letter kernels above are the tuned ones.
+// ---------------------------------------------------------------------------------------
+struct GenericLut {
+    int8_t code[256];  // -1: not in the alphabet
+};
+
+__global__ __launch_bounds__(kThreads) void count_generic_kernel(const unsigned char* __restrict__ bases,
+                                                                 const int64_t* __restrict__ offsets, int64_t seq0,
+                                                                 int64_t n_seqs, int k, int alen, int64_t nbins,
+                                                                 GenericLut lut, uint32_t* __restrict__ hist) {
+    for (int64_t s = blockIdx.x; s < n_seqs; s += gridDim.x) {
+        const unsigned char* seq = bases + offsets[seq0 + s];
+        const int64_t len = offsets[seq0 + s + 1] - offsets[seq0 + s];
+        uint32_t* row = hist + (size_t)s * nbins;
+        for (int64_t w = threadIdx.x; w + k <= len; w += kThreads) {
+            int64_t idx = 0;
+            bool ok = true;
+            for (int p = 0; p < k; p++) {
+                const int c = lut.code[seq[w + p]];
+                ok &= c >= 0;
+                idx = idx * alen + (c >= 0 ? c : 0);
+            }
+            if (ok) atomicAdd(&row[idx], 1u);
+        }
+    }
+}
+
+template <typename OutT, bool LOG2>
+__global__ __launch_bounds__(kThreads) void convert_generic_kernel(const uint32_t* __restrict__ hist,
+                                                                   const int64_t* __restrict__ offsets, int64_t seq0,
+                                                                   int64_t n_seqs, int k, int64_t nbins, OutT* __restrict__ out) {
+    for (int64_t s = blockIdx.y; s < n_seqs; s += gridDim.y) {
+        const int64_t len = offsets[seq0 + s + 1] - offsets[seq0 + s];
+        const double inc = 1000.0 / (double)(len - k + 1);  // len == k-1 was refused on the host
+        for (int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x; b < nbins; b += (int64_t)gridDim.x * kThreads) {
+            const uint32_t n = hist[(size_t)s * nbins + b];
+            OutT v;
+            if (sizeof(OutT) == 8) {
+                v = (OutT)per_kb_value_f64(n, inc);
+            } else if (std::is_same<OutT, uint32_t>::value) {
+                v = (OutT)n;
+            } else {
+                float t = per_kb_value(n, inc);
+                if (LOG2) t = skr_log2_cr(t + 1.0f);
+                v = (OutT)t;
+            }
+            out[(size_t)(seq0 + s) * nbins + b] = v;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int skr_count_generic(skr_ctx* ctx, const char* bases, const int64_t* offsets, int64_t n, const char* alphabet,
+                                 int alen, int k, int log2_pre, skr_mat* out) {
+    SKR_REQUIRE(ctx && alphabet && out && out->ctx == ctx, "NULL or foreign argument");
+    SKR_REQUIRE(n >= 0 && (n == 0 || offsets), "bad sequence count / offsets");
+    SKR_REQUIRE(alen >= 1 && alen <= 127 && k >= 1, "alphabet of 1..127 letters and k >= 1 expected");
+    double bins_d = 1.0;
+    for (int p = 0; p < k; p++) bins_d *= alen;
+    if (bins_d > (double)(1 << 26))
+        return skr_set_error(SKR_ERR_UNSUPPORTED, "%d^%d columns: rows are supported up to 2^26 columns", alen, k);
+    const int64_t nbins = (int64_t)bins_d;
+    SKR_REQUIRE(out->rows == n && out->cols == nbins, "output must be [%lld, %lld], got [%lld, %lld]", (long long)n,
+                (long long)nbins, (long long)out->rows, (long long)out->cols);
+    SKR_REQUIRE(!(log2_pre && out->dtype != SKR_F32), "log2_pre is implemented for SKR_F32 output only");
+    if (n == 0) return SKR_OK;
+    SKR_REQUIRE(bases || offsets[n] == offsets[0], "bases is NULL");
+    for (int64_t i = 0; i < n; i++) {
+        SKR_REQUIRE(offsets[i + 1] >= offsets[i], "offsets must be non-decreasing (at %lld)", (long long)i);
+        if (out->dtype != SKR_U32 && offsets[i + 1] - offsets[i] == k - 1)  // kmer_counts.py:144
+            return skr_set_error(SKR_ERR_ZERODIV, "division by zero (a sequence has length k-1 = %d)", k - 1);
+    }
+    GenericLut lut;
+    memset(lut.code, -1, sizeof(lut.code));
+    // a repeated letter keeps its LAST position, as the reference's dict {kmer: index} does (:122)
+    for (int c = 0; c < alen; c++) lut.code[(unsigned char)alphabet[c]] = (int8_t)c;
+    SKR_TRY(skr_activate(ctx));
+    const size_t total = (size_t)(offsets[n] - offsets[0]);
+    unsigned char* d_bases = nullptr;
+    int64_t* d_off = nullptr;
+    uint32_t* d_hist = nullptr;
+    const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(n, ((int64_t)256 << 20) / (nbins * 4)));
+    auto cleanup = [&] {
+        (void)hipStreamSynchronize(ctx->stream);
+        if (d_bases) (void)hipFree(d_bases);
+        if (d_off) (void)hipFree(d_off);
+        if (d_hist) (void)hipFree(d_hist);
+    };
+    hipError_t e = hipMalloc((void**)&d_bases, std::max<size_t>(total, 1));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_off, (size_t)(n + 1) * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_hist, (size_t)batch * nbins * 4);
+    std::vector<int64_t> rel((size_t)n + 1);
+    for (int64_t i = 0; i <= n; i++) rel[i] = offsets[i] - offsets[0];
+    if (e == hipSuccess && total) e = hipMemcpyAsync(d_bases, bases + offsets[0], total, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_off, rel.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+    for (int64_t s0 = 0; s0 < n && e == hipSuccess; s0 += batch) {
+        const int64_t ns = std::min(batch, n - s0);
+        e = hipMemsetAsync(d_hist, 0, (size_t)ns * nbins * 4, ctx->stream);
+        if (e != hipSuccess) break;
+        SkrProfScope prof(ctx, "count_generic");
+        hipLaunchKernelGGL(count_generic_kernel, dim3((unsigned)std::min<int64_t>(ns, (int64_t)ctx->num_cu * 8)), dim3(kThreads),
+                           0, ctx->stream, d_bases, d_off, s0, ns, k, alen, nbins, lut, d_hist);
+        const dim3 cgrid((unsigned)std::min<int64_t>((nbins + kThreads - 1) / kThreads, 64), (unsigned)std::min<int64_t>(ns, 4096));
+        if (out->dtype == SKR_U32)
+            hipLaunchKernelGGL((convert_generic_kernel<uint32_t, false>), cgrid, dim3(kThreads), 0, ctx->stream, d_hist, d_off, s0,
+                               ns, k, nbins, (uint32_t*)out->data);
+        else if (out->dtype == SKR_F64)
+            hipLaunchKernelGGL((convert_generic_kernel<double, false>), cgrid, dim3(kThreads), 0, ctx->stream, d_hist, d_off, s0, ns,
+                               k, nbins, (double*)out->data);
+        else if (log2_pre)
+            hipLaunchKernelGGL((convert_generic_kernel<float, true>), cgrid, dim3(kThreads), 0, ctx->stream, d_hist, d_off, s0, ns,
+                               k, nbins, (float*)out->data);
+        else
+            hipLaunchKernelGGL((convert_generic_kernel<float, false>), cgrid, dim3(kThreads), 0, ctx->stream, d_hist, d_off, s0, ns,
+                               k, nbins, (float*)out->data);
+        e = hipGetLastError();
+    }
+    cleanup();
+    if (e != hipSuccess) return skr_set_error(SKR_ERR_HIP, "generic-alphabet counting failed: %s", hipGetErrorString(e));
+    return SKR_OK;
+}
 
 extern "C" int skr_count_u32(skr_ctx* ctx, const skr_seqs* s, int k, skr_mat* out) {
     SKR_TRY(check_count_args(ctx, s, k, out));

@@ -169,7 +169,11 @@ __global__ __launch_bounds__(256, 2) void pearson_gemm_f32_kernel(const float* _
     // A single f32 accumulator over K = 4096 strictly sequential FMAs drifts by ~2e-6 on r ~ 1
     // (error grows like sqrt(K)); BLAS in the reference sums in blocks.  Every kFlush k-tiles
     // the running tile sum is folded into `total`, which cuts the drift by the block count.
-    constexpr int kFlush = 16;  // 16 * BK = 512 k per partial sum
+    // The MFMA's accumulate step truncates instead of rounding, which matters on rows dominated by one
+    // column (a homopolymer's one-hot profile): once the big product is in the accumulator every further
+    // add loses up to an ulp of it, one-sidedly — 2e-5 on r = 1 after 500 of them.  Partial sums of 64 k
+    // keep that below 4e-6; the fold is 64 VALU adds per 8 192 MFMA cycles.
+    constexpr int kFlush = 2;  // 2 * BK = 64 k per partial sum
     f32x16 total[2][2];
 #pragma unroll
     for (int i = 0; i < 2; i++)

@@ -56,7 +56,8 @@ class BasicCounter:
     log2 : 'Log2.post' | 'Log2.pre' | 'Log2.none'
     leave, silent : progress-bar options (cosmetic; counting is one kernel launch)
     label : bool                   label rows/columns of a csv
-    alphabet : str                 4 letters; column order follows `itertools.product`
+    alphabet : str                 column order follows `itertools.product`; 4 distinct letters take the
+                                   2-bit kernels, any other string the general counting kernel
     """
 
     def __init__(self, infasta=None, outfile=None, k=6, binary=True, mean=True, std=True, log2="Log2.post",
@@ -65,10 +66,14 @@ class BasicCounter:
         self._seqs = None
         self._packed = None  # PackedSeqs resident in HBM (native FASTA path)
         self.alphabet = alphabet
+        # 4 distinct letters: 2 bits per base and the tuned kernels; any other alphabet string the
+        # reference accepts (kmer_counts.py:120-122) goes through the general counting kernel
+        self._two_bit = len(alphabet) == 4 and len(set(alphabet)) == 4
         if infasta is not None:
             # kmer_counts.py:103-105 reads the file here; errors of the reader surface here too
-            self._packed = _lib.default_context().pack_fasta(infasta, alphabet) if len(alphabet) == 4 else None
-            if self._packed is None:
+            if self._two_bit:
+                self._packed = _lib.default_context().pack_fasta(infasta, alphabet)
+            else:
                 self._seqs = Reader(infasta).get_seqs()
         self.outfile = outfile
         self.k = k
@@ -128,9 +133,13 @@ class BasicCounter:
         reference's dict-driven assignment."""
         self._check_k()
         ctx = self._ctx()
-        packed = ctx.pack([seq], self.alphabet)
-        n = _lib.count_u32(ctx, packed, self.k).to_numpy()[0]
-        vals = _lib.count_per_kb(ctx, packed, self.k, dtype=np.float64).to_numpy()[0]
+        if self._two_bit:
+            packed = ctx.pack([seq], self.alphabet)
+            n = _lib.count_u32(ctx, packed, self.k).to_numpy()[0]
+            vals = _lib.count_per_kb(ctx, packed, self.k, dtype=np.float64).to_numpy()[0]
+        else:
+            n = _lib.count_generic(ctx, [seq], self.alphabet, self.k, np.uint32).to_numpy()[0]
+            vals = _lib.count_generic(ctx, [seq], self.alphabet, self.k, np.float64).to_numpy()[0]
         present = n > 0
         row[present] = vals[present]
         return row
@@ -210,10 +219,18 @@ class BasicCounter:
         self._check_k()
         ctx = self._ctx()
         bar = self._progress()
-        packed = self._packed_seqs()
-        dev = _lib.count_per_kb(ctx, packed, self.k, log2_pre=(self.log2 == "Log2.pre"))
+        if self._two_bit:
+            packed = self._packed_seqs()
+            dev = _lib.count_per_kb(ctx, packed, self.k, log2_pre=(self.log2 == "Log2.pre"))
+            n_counted = packed.n
+        else:
+            if self._seqs is None:
+                raise TypeError("BasicCounter has no sequences: pass infasta or assign `seqs`")
+            dev = _lib.count_generic(ctx, self._seqs, self.alphabet, self.k, np.float32,
+                                     log2_pre=(self.log2 == "Log2.pre"))
+            n_counted = len(self._seqs)
         if bar is not None:
-            bar.update(packed.n)
+            bar.update(n_counted)
             bar.close()
         mean_mode, mean_vec = 0, None
         if self.mean is True:

@@ -65,6 +65,10 @@ def fuzz(seed, budget_s=60.0, max_cases=10 ** 9, replay=None):
    try:
         k = int(rng.integers(1, 8))
         alphabet = "".join(rng.permutation(list("AGTC")))
+        if rng.integers(0, 4) == 0:  # an alphabet the 2-bit path does not cover: the general counting kernel
+            alphabet = str(rng.choice(["ACGTN", "AT", "AGTA", "GCA", "ACGTRYN", "NNA", "T"]))
+            while len(alphabet) ** k > 4096:
+                k -= 1
         n = int(rng.integers(2, 60))
         seqs = [random_seq(k) for _ in range(n)]
         log2 = str(rng.choice(["Log2.none", "Log2.pre", "Log2.post"]))

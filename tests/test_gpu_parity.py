@@ -538,8 +538,8 @@ def test_k7_pipeline_16384_columns(L, ctx):
     assert np.allclose(pearson(ref, ref[:100]), want[:, :100], rtol=RTOL, atol=ATOL_R)
     with pytest.raises(NotImplementedError):
         run(seqs[:3], k=13, mean=False, std=False, log2="Log2.none")
-    with pytest.raises(NotImplementedError):
-        run(seqs[:3], k=3, mean=False, std=False, log2="Log2.none", alphabet="ACGTN")
+    # 5 letters: no 2-bit packing, the general counting kernel serves it (test_g7_alphabets_other_than_four_letters)
+    assert run(seqs[:3], k=3, mean=False, std=False, log2="Log2.none", alphabet="ACGTN").counts.shape == (3, 125)
 
 
 @pytest.mark.parametrize("k", [8, 9])
@@ -903,3 +903,46 @@ def test_matrices_beyond_4gib():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "big_offsets.py")], capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0 and "big offsets ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_g7_alphabets_other_than_four_letters(golden_dir, tmp_path):
+    """Alphabets of 1, 2, 5 and 20 letters and with a repeated letter (the general counting kernel) against the
+    reference's output: raw counts and `occurrences` bit-exact, normalised matrices within the bar."""
+    from make_golden_g7 import CASES, sequences
+    from seekr_amd.kmer_counts import BasicCounter
+    g7 = np.load(os.path.join(golden_dir, "g7_alphabets.npz"))
+    for name, alphabet, k, letters in CASES:
+        seqs = sequences(name, letters)
+        for tag, kw in (("raw", dict(mean=False, std=False, log2="Log2.none")),
+                        ("pre", dict(mean=True, std=False, log2="Log2.pre")),
+                        ("post", dict(mean=True, std=True, log2="Log2.post"))):
+            c = BasicCounter(k=k, alphabet=alphabet, silent=True, **kw)
+            c.seqs = list(seqs)
+            with contextlib.redirect_stdout(io.StringIO()):
+                c.get_counts()
+            want = g7["%s_%s" % (name, tag)]
+            assert c.counts.shape == want.shape and c.counts.dtype == np.float32
+            if tag == "raw":
+                assert np.array_equal(c.counts.view(np.uint32), want.view(np.uint32)), name
+            else:
+                assert np.array_equal(np.isnan(c.counts), np.isnan(want)), (name, tag)
+                ok = ~np.isnan(want)
+                np.testing.assert_allclose(c.counts[ok], want[ok], rtol=1e-5, atol=2e-6, err_msg=name + tag)
+        c = BasicCounter(k=k, alphabet=alphabet, silent=True)
+        row = c.occurrences(np.full(len(alphabet) ** k, -1.0), seqs[0])
+        assert np.array_equal(row, g7[name + "_occ"]), name
+    # from a FASTA file (the reader upper-cases) and through save(): labelled CSV with the 25 2-mers of ACGTN
+    fa = str(tmp_path / "n.fa")
+    write_fasta(fa, sequences("acgtn", "ACGTN"), lower=True)
+    out = str(tmp_path / "n.csv")
+    c = BasicCounter(fa, out, k=2, alphabet="ACGTN", binary=False, label=True, mean=False, std=False, log2="Log2.none",
+                     silent=True)
+    c.make_count_file()
+    assert np.array_equal(c.counts.view(np.uint32), g7["acgtn_raw"].view(np.uint32))
+    header = open(out).readline().strip().split(",")
+    assert header[0] == "" and header[1:4] == ["AA", "AC", "AG"] and len(header) == 26
+    # len == k-1 raises as in the reference, also on this path
+    c = BasicCounter(k=3, alphabet="ACGTN", silent=True, mean=False, std=False)
+    c.seqs = ["ACGTA", "AC"]
+    with pytest.raises(ZeroDivisionError):
+        c.get_counts()

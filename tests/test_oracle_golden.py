@@ -272,3 +272,20 @@ def test_synthetic_prefix_property():
     a = orc.synthetic_codes(2, 25, 100, start=9_990)
     b = orc.synthetic_codes(2, 10_015, 100)
     assert np.array_equal(a, b[9_990:])
+
+
+def test_g7_alphabets_other_than_four_letters(golden_dir):
+    """The oracle on alphabets of 1, 2, 5 and 20 letters and with a repeated letter, against the reference's
+    own output (tests/golden/make_golden_g7.py)."""
+    from make_golden_g7 import CASES, sequences
+    g7 = np.load(os.path.join(golden_dir, "g7_alphabets.npz"))
+    for name, alphabet, k, letters in CASES:
+        seqs = sequences(name, letters)
+        raw = orc.raw_counts_py(seqs, k, alphabet)
+        assert np.array_equal(raw.view(np.uint32), g7[name + "_raw"].view(np.uint32)), name
+        assert np.array_equal(orc.raw_counts(seqs, k, alphabet).view(np.uint32), raw.view(np.uint32)), name
+        with np.errstate(all="ignore"):
+            pre = orc.normalize(raw, True, False, "Log2.pre")[0]
+            post = orc.normalize(raw, True, True, "Log2.post")[0]
+        np.testing.assert_array_equal(pre, g7[name + "_pre"])
+        np.testing.assert_array_equal(post, g7[name + "_post"])
