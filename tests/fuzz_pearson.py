@@ -16,12 +16,13 @@ def fuzz(seed, budget_s=60.0, max_cases=10 ** 9):
     rng = np.random.default_rng(seed)
     t0, n_cases = time.time(), 0
     while time.time() - t0 < budget_s and n_cases < max_cases:
-        K = int(rng.choice([1, 2, 3, 4, 5, 16, 31, 32, 33, 64, 100, 255, 256, 257, 1000, 1023, 1024, 1025, 1500, 2048, 4096, 4100]))
+        K = int(rng.choice([1, 2, 3, 4, 5, 16, 31, 32, 33, 64, 100, 255, 256, 257, 625, 729, 1000, 1023, 1024, 1025, 1500, 2048, 3125,
+                            4096, 4100, 16384]))
         M, N = int(rng.integers(1, 70)), int(rng.integers(1, 70))
         dt = rng.choice(["f32", "f32", "f32", "f64", "i64"])
         same = bool(rng.integers(0, 3) == 0)
         rs = bool(rng.integers(0, 4) != 0)
-        kind = rng.integers(0, 4)
+        kind = rng.integers(0, 6)
         def make(rows):
             if kind == 0:
                 x = rng.standard_normal((rows, K)) * rng.uniform(0.1, 50)
@@ -29,8 +30,23 @@ def fuzz(seed, budget_s=60.0, max_cases=10 ** 9):
                 x = rng.binomial(20, 0.2, size=(rows, K)).astype(np.float64) * 1.5
             elif kind == 2:
                 x = np.abs(rng.standard_normal((rows, K))) ** 3
-            else:
+            elif kind == 3:
                 x = rng.standard_normal((rows, K)); x[rng.integers(0, rows)] = 3.25  # a constant row
+            elif kind == 4:
+                # count-like and sparse: one-hot rows (homopolymers), a few hot columns, and rows repeated
+                # exactly or scaled — pairs with r = 1 whose products are dominated by one column
+                x = np.zeros((rows, K))
+                for i in range(rows):
+                    hot = rng.integers(0, K, size=int(rng.choice([1, 1, 2, 3, 8])))
+                    x[i, hot] = rng.uniform(1, 12, size=len(hot))
+                    if rng.integers(0, 3) == 0:
+                        x[i] += rng.binomial(3, 0.1, K) * 0.5
+                for i in range(1, rows):
+                    if rng.integers(0, 4) == 0:
+                        x[i] = x[rng.integers(0, i)] * rng.choice([1.0, 2.0, 0.37])
+            else:
+                base = rng.standard_normal((1, K)) * 3
+                x = base + rng.standard_normal((rows, K)) * rng.choice([1e-3, 1e-2, 0.3])  # near-duplicates: r ~ 1
             if dt == "i64":
                 return np.rint(x * 4).astype(np.int64)
             return x.astype(np.float32 if dt == "f32" else np.float64)
