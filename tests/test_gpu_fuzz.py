@@ -21,3 +21,9 @@ def test_fuzz_pearson_api(seed):
 def test_fuzz_fasta_reader(seed):
     from fuzz_fasta import fuzz
     assert fuzz(seed, budget_s=6.0, max_cases=3000) >= 200
+
+
+@pytest.mark.parametrize("seed", [31, 32])
+def test_fuzz_consumers(seed):
+    from fuzz_consumers import fuzz
+    assert fuzz(seed, budget_s=6.0, max_cases=1500) >= 100
