@@ -152,3 +152,10 @@ def test_every_rank_switches_when_one_needs_the_fp32_kernel(mock_lib, tmp_path):
     x = np.concatenate([p["x"] for p in parts], axis=0)
     from oracle import seekr_oracle as orc
     assert np.allclose(full, orc.pearson(x, x), rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("n_total,size", [(6, 4), (6, 8), (3, 3), (17, 5)])
+def test_tiny_and_empty_shards(n_total, size, mock_lib, tmp_path):
+    """Fewer rows than ranks (empty shards), one row per rank, odd splits: k = 2, i.e. 16 columns and the
+    float32 contraction."""
+    check_ranks(size, 1, mock_lib, single_gpu_reference(n_total, 400, 2), tmp_path)
