@@ -94,7 +94,7 @@ struct SkrProfScope {
 int skr_ctx_workspace(skr_ctx* ctx, size_t bytes, void** out);
 // GEMM launchers (pearson.hip, pearson_bf16.hip), used by operand.hip
 int skr_launch_gemm_f32(skr_ctx* ctx, const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kp,
-                        int64_t lda, int64_t ldb, int64_t ldc, int64_t K);
+                        int64_t lda, int64_t ldb, int64_t ldc, int64_t K, int symmetric);
 int skr_launch_gemm_f64(skr_ctx* ctx, const double* A, const double* B, double* C, int64_t M, int64_t N, int64_t K,
                         int64_t lda, int64_t ldb, int64_t ldc, double kdiv, int symmetric);
 int skr_launch_gemm_split(skr_ctx* ctx, int precision, const void* As, const void* Bs, float* C, int64_t M, int64_t N,

@@ -717,7 +717,8 @@ extern "C" int skr_pearson_gemm_op(skr_ctx* ctx, const skr_operand* a, const skr
     const bool self = a->data == b->data && M == N;
     if (a->kind == 0) {
         const int64_t Kp = a->kt * 32;
-        SKR_TRY(skr_launch_gemm_f32(ctx, (const float*)a->data, (const float*)b->data, C, M, N, Kp, Kp, Kp, r->cols, K));
+        SKR_TRY(skr_launch_gemm_f32(ctx, (const float*)a->data, (const float*)b->data, C, M, N, Kp, Kp, Kp, r->cols, K,
+                                    symmetric && self && row0 == col0));
     } else {
         SKR_TRY(skr_launch_gemm_split(ctx, a->precision, a->data, b->data, C, M, N, a->kt, r->cols,
                                       (float)K * a->scale * b->scale, symmetric && self ? 1 : 0, nullptr, 0));
@@ -758,8 +759,8 @@ extern "C" int skr_pearson_gemm_op_mirror(skr_ctx* ctx, const skr_operand* a, co
         // float32 operands: a_i . b_j and b_j . a_i accumulate the same products in the same k
         // order, so a second contraction gives the bit-identical transposed block
         const int64_t Kp = a->kt * 32;
-        SKR_TRY(skr_launch_gemm_f32(ctx, (const float*)a->data, (const float*)b->data, C, M, N, Kp, Kp, Kp, r->cols, K));
-        return skr_launch_gemm_f32(ctx, (const float*)b->data, (const float*)a->data, Ct, N, M, Kp, Kp, Kp, rt->cols, K);
+        SKR_TRY(skr_launch_gemm_f32(ctx, (const float*)a->data, (const float*)b->data, C, M, N, Kp, Kp, Kp, r->cols, K, 0));
+        return skr_launch_gemm_f32(ctx, (const float*)b->data, (const float*)a->data, Ct, N, M, Kp, Kp, Kp, rt->cols, K, 0);
     }
     return skr_launch_gemm_split(ctx, a->precision, a->data, b->data, C, M, N, a->kt, r->cols,
                                  (float)K * a->scale * b->scale, 2, Ct, rt->cols);

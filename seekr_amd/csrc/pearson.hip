@@ -89,6 +89,8 @@ __device__ __forceinline__ void tile_of_block(int64_t bid, int64_t nblk, int64_t
     *tn = in / gsize;
 }
 
+// SYM (self-comparison, square result block): tiles below the diagonal are skipped and written as mirrors.
+template <bool SYM>
 __global__ __launch_bounds__(256, 2) void pearson_gemm_f32_kernel(const float* __restrict__ A,
                                                                    const float* __restrict__ B, float* __restrict__ C,
                                                                    int64_t M, int64_t N, int64_t K, int64_t lda,
@@ -99,7 +101,15 @@ __global__ __launch_bounds__(256, 2) void pearson_gemm_f32_kernel(const float* _
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     int64_t tm, tn;
-    tile_of_block(blockIdx.x, (int64_t)gridDim.x, tiles_m, tiles_n, &tm, &tn);
+    if (SYM) {
+        // plain row-major order: the grouped order hands each XCD a contiguous range of tile rows, and with the
+        // lower triangle skipped the first XCD would keep all of its tiles while the last kept none
+        tm = blockIdx.x / tiles_n;
+        tn = blockIdx.x % tiles_n;
+        if (tn < tm) return;
+    } else {
+        tile_of_block(blockIdx.x, (int64_t)gridDim.x, tiles_m, tiles_n, &tm, &tn);
+    }
     const int64_t row_base = tm * BM, col_base = tn * BN;
 
     // ---- staging addresses: wave w moves pieces 4w..4w+3 (rows 32w..32w+31) of A and of B
@@ -217,6 +227,24 @@ __global__ __launch_bounds__(256, 2) void pearson_gemm_f32_kernel(const float* _
             for (int e = 0; e < 16; e++) {
                 const int64_t m = row_base + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (m < M && n < N) C[(size_t)m * ldc + n] = __fdiv_rn(total[mt][nt][e], kdiv);
+            }
+            if (SYM && tm != tn && n < N) {
+                // mirror: this lane's 16 values are 4 runs of 4 consecutive rows m — 16-byte stores into row n
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int64_t m0 = row_base + wm * 64 + mt * 32 + 8 * q + 4 * h;
+                    float* dst = C + (size_t)n * ldc + m0;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = __fdiv_rn(total[mt][nt][4 * q + e], kdiv);
+                    if (m0 + 3 < M && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            if (m0 + e < M) dst[e] = v[e];
+                    }
+                }
             }
         }
 }
@@ -389,13 +417,21 @@ extern "C" int skr_row_standardize(skr_ctx* ctx, const skr_mat* x, skr_mat* z) {
 
 // ---- launchers used by operand.hip -----------------------------------------------------------
 int skr_launch_gemm_f32(skr_ctx* ctx, const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kp,
-                        int64_t lda, int64_t ldb, int64_t ldc, int64_t K) {
+                        int64_t lda, int64_t ldb, int64_t ldc, int64_t K, int symmetric) {
     const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-    SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pearson_gemm_f32_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
+    const bool sym = symmetric && A == B && M == N && lda == ldb;  // mirrors land inside the same square block
     SkrProfScope prof(ctx, "pearson_gemm_f32");
-    hipLaunchKernelGGL(pearson_gemm_f32_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 2 * kStageBytes,
-                       ctx->stream, A, B, C, M, N, Kp, lda, ldb, ldc, (float)K, tiles_m, tiles_n);
+    if (sym) {
+        SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pearson_gemm_f32_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
+        hipLaunchKernelGGL(pearson_gemm_f32_kernel<true>, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 2 * kStageBytes,
+                           ctx->stream, A, B, C, M, N, Kp, lda, ldb, ldc, (float)K, tiles_m, tiles_n);
+    } else {
+        SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pearson_gemm_f32_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
+        hipLaunchKernelGGL(pearson_gemm_f32_kernel<false>, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 2 * kStageBytes,
+                           ctx->stream, A, B, C, M, N, Kp, lda, ldb, ldc, (float)K, tiles_m, tiles_n);
+    }
     SKR_HIP(hipGetLastError());
     return SKR_OK;
 }
