@@ -87,6 +87,9 @@ int parse_field(const char* s, size_t n, double* out) {
         }
     }
     if (!any) return 1;
+    // "-0", "-000": in a column of nothing but integers pandas parses int64 and the sign of the zero is gone,
+    // in any other column it is -0.0 — the field alone does not say which
+    if (neg && mant == 0 && !seen_dot && p == end) return 1;
     if (p < end) {
         if (*p != 'e' && *p != 'E') return 1;
         p++;

@@ -1,0 +1,9 @@
+"""The native CSV reader against pandas on random files (host code: runs without a GPU)."""
+import pytest
+
+
+@pytest.mark.parametrize("seed", [101, 102])
+def test_fuzz_csv_reader_against_pandas(seed):
+    from fuzz_csv_reader import fuzz
+    files, native = fuzz(seed, budget_s=8.0, max_cases=4000)
+    assert files >= 300 and native >= 100
