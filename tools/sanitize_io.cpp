@@ -6,7 +6,7 @@
 #include <random>
 #include <string>
 #include <vector>
-#include "../include/seekr_hip.h"
+#include "../seekr_amd/csrc/common.hpp"
 int main() {
     std::mt19937_64 g(1);
     std::vector<float> a(300 * 257);
@@ -53,6 +53,36 @@ int main() {
         rc = skr_csv_read("/tmp/seekr_san/b.csv", 2, &csv);
         if (csv) skr_csv_free(csv);
     }
+    // ---- FASTA reader: hostile and random files, parsed in forced multi-piece mode.  Without a GPU the call
+    // ends in an error at the upload, after the parser, the stitcher and the packer have all run.
+    skr_ctx* fake = new skr_ctx();
+    const char* fastas[] = {"", ">", ">h", ">h\n", "ACGT", ">a\nAC\n>b\n", ">a\r\nAC\r\n\r\n>b\r\nGT", ">a\rACGT\r>b\rTT\r",
+                            ">a\n>b\nAC\n", "\n>a\nAC", ">a\n \t \nAC\n", ">a\nACGT\n>b\nacgtnnnn\n>c\nA\n"};
+    setenv("SEEKR_FASTA_PIECE_BYTES", "3", 1);
+    int parsed = 0;
+    auto try_file = [&](const std::string& text) {
+        FILE* fh = fopen("/tmp/seekr_san/f.fa", "wb");
+        fwrite(text.data(), 1, text.size(), fh);
+        fclose(fh);
+        skr_seqs* sq = nullptr;
+        const int rc2 = skr_seqs_from_fasta(fake, "/tmp/seekr_san/f.fa", "AGTC", &sq);
+        if (rc2 == SKR_OK && sq) skr_seqs_free(sq);
+        parsed++;
+    };
+    for (const char* t : fastas) try_file(t);
+    const char alphabet[] = "ACGTNacgt>\n\r \t;|0";
+    for (int rep = 0; rep < 3000; rep++) {
+        std::string text;
+        const int len = (int)(g() % 400);
+        if (g() % 4) text += ">first\n";
+        for (int i = 0; i < len; i++) {
+            const uint64_t r = g();
+            text += (r % 13 == 0) ? '\n' : (r % 47 == 0 ? '>' : alphabet[r % (sizeof(alphabet) - 1)]);
+        }
+        if (rep % 3 == 0) setenv("SEEKR_FASTA_PIECE_BYTES", std::to_string(1 + g() % 64).c_str(), 1);
+        try_file(text);
+    }
+    printf("fasta reader: %d files parsed under the sanitizers\n", parsed);
     puts("sanitizer driver done");
     return 0;
 }
