@@ -29,8 +29,15 @@ def study(name, x):
     lo8 = np.clip(np.rint(lo * sh * 2048.0), -127, 127)
     cross = (hi8 @ lo8.T + lo8 @ hi8.T) / (sh * sh.T * 2048.0)
     r_i8 = (hi @ hi.T + cross) / (K * s * s)
+    # the same with dithered rounding (a fixed pseudo-random offset per cell instead of 0.5): the error of a
+    # few-valued row stops being a function of the value and averages out like noise
+    u1, u2 = rng.random(hi.shape), rng.random(hi.shape)
+    hi8d = np.floor(hi * sh + u1)
+    lo8d = np.clip(np.floor(lo * sh * 2048.0 + u2), -127, 127)
+    crossd = (hi8d @ lo8d.T + lo8d @ hi8d.T) / (sh * sh.T * 2048.0)
+    r_i8d = (hi @ hi.T + crossd) / (K * s * s)
     bar = 2e-6 + 1e-5 * np.abs(truth)
-    for tag, r in (("fp16 x 3", r_f16x3), ("fp16 + int8 cross", r_i8), ("hi*hi only", hi @ hi.T / (K * s * s))):
+    for tag, r in (("fp16 x 3", r_f16x3), ("fp16 + int8 cross", r_i8), ("... dithered", r_i8d), ("hi*hi only", hi @ hi.T / (K * s * s))):
         e = np.abs(r - truth)
         print("%-34s %-18s max |err| %.2e   max err/bar %.3f   rms %.2e" % (name, tag, e.max(), (e / bar).max(), np.sqrt((e ** 2).mean())))
 
