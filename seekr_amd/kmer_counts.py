@@ -49,7 +49,7 @@ class BasicCounter:
     ----------
     infasta : str, optional        path of the FASTA file to count
     outfile : str, optional        where `save` writes
-    k : int                        k-mer length (1..7 on the LDS-histogram path)
+    k : int                        k-mer length (1..7: histogram in LDS; 8..12: in the output row in HBM)
     binary : bool                  save as .npy if True, else csv
     mean, std : bool | ndarray | str
         True = compute from the data, False = skip, str = np.load(path), array = use as given
