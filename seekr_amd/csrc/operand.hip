@@ -9,6 +9,26 @@
 
 namespace {
 
+// hi half of the two-halves split.  Rounded to nearest, every copy of a repeated value gets the same residual,
+// and a count profile that is mostly zeros becomes thousands of identical (hi, lo) pairs whose tiny hi*lo
+// products the MFMA's truncating accumulate cuts all in the same direction: 2e-5 on r = 0.96 (found by the
+// fuzzer; alphabet of 7 letters, 90 % of the columns structurally zero).  So fp16 halves are rounded down or up
+// by a hash of the COLUMN: the residuals of a repeated value come with both signs, the truncation errors cancel
+// like noise, and hi + lo still carries the value to 2^-21 relative.  (bf16 halves keep round-to-nearest.)
+extern "C" __device__ _Float16 __ocml_cvtrtn_f16_f32(float);
+extern "C" __device__ _Float16 __ocml_cvtrtp_f16_f32(float);
+template <typename T>
+__device__ __forceinline__ T split_hi(float zs, int64_t col) {
+    return (T)zs;  // hardware convert: RNE, NaN stays NaN
+}
+template <>
+__device__ __forceinline__ _Float16 split_hi<_Float16>(float zs, int64_t col) {
+    // directed conversions of the device library (a rounding-mode switch around v_cvt_f16_f32): +0.15 ms on the
+    // 50 000 x 4 096 fill; a hand-written neighbour step (branches) cost +0.5 ms, a biased RNE convert +0.23 ms
+    const bool up = (((uint32_t)col * 0x9E3779B1u) >> 31) != 0;
+    return up ? __ocml_cvtrtp_f16_f32(zs) : __ocml_cvtrtn_f16_f32(zs);
+}
+
 template <typename T>
 using vec8 = T __attribute__((ext_vector_type(8)));
 
@@ -149,7 +169,7 @@ __global__ __launch_bounds__(256) void operand_fill_kernel(FillArgs a) {
                 for (int j = 0; j < 8; j++) {
                     const float zs = z[j] * a.out_scale;
                     if (fabsf(zs) > 65504.f) overflow = true;
-                    const T hh = (T)zs;                 // hardware convert: RNE, NaN stays NaN
+                    const T hh = split_hi<T>(zs, k0 + j);
                     hi[j] = hh;
                     lo[j] = (T)(zs - (float)hh);        // exact difference, then RNE
                 }
@@ -279,7 +299,7 @@ __global__ __launch_bounds__(256) void operand_fill_block_kernel(FillArgs a) {
                 for (int j = 0; j < 8; j++) {
                     const float zs = z[j] * a.out_scale;
                     if (fabsf(zs) > 65504.f) overflow = true;
-                    const T hh = (T)zs;
+                    const T hh = split_hi<T>(zs, k0 + j);
                     hi[j] = hh;
                     lo[j] = (T)(zs - (float)hh);
                 }
@@ -410,7 +430,7 @@ __global__ __launch_bounds__(256) void operand_fill_reg_kernel(FillArgs a) {
                 for (int j = 0; j < 4; j++) {
                     const float zs = z[j] * a.out_scale;
                     if (fabsf(zs) > 65504.f) overflow = true;
-                    const T hh = (T)zs;
+                    const T hh = split_hi<T>(zs, c + j);
                     hi[j] = hh;
                     lo[j] = (T)(zs - (float)hh);
                 }
