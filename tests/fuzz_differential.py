@@ -71,6 +71,13 @@ def fuzz(seed, budget_s=60.0, max_cases=10 ** 9, replay=None):
                 k -= 1
         n = int(rng.integers(2, 60))
         seqs = [random_seq(k) for _ in range(n)]
+        for i in range(1, n):  # mutated copies: pairs with r close to 1, where the bar is relative
+            if rng.integers(0, 4) == 0 and len(seqs[i - 1]) > k + 2:
+                parent = np.array(list(seqs[int(rng.integers(0, i))]))
+                if len(parent) > k + 2:
+                    hits = rng.random(len(parent)) < rng.choice([0.0, 0.01, 0.05, 0.2])
+                    parent[hits] = LETTERS[rng.integers(0, 4, int(hits.sum()))]
+                    seqs[i] = "".join(parent[: int(rng.integers(k + 2, len(parent) + 1))])
         log2 = str(rng.choice(["Log2.none", "Log2.pre", "Log2.post"]))
         mean, std = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
         tag = dict(k=k, alphabet=alphabet, n=n, log2=log2, mean=mean, std=std)
