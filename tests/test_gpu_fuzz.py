@@ -47,3 +47,23 @@ def test_regression_rows_that_are_mostly_one_repeated_value(golden_dir):
     err = np.abs(r - truth)
     assert (err <= 2e-6 + 1e-5 * np.abs(truth)).all(), float(err.max())
     assert abs(truth[1, 6] - 0.9564) < 1e-3 and err[1, 6] < 1.1e-5
+
+
+def test_constructed_worst_case_stays_at_the_bar():
+    """Near-copies of a profile whose columns are 97 % one repeated value (tools/margin_probe.py): every product is
+    positive and the truncating accumulate works one-sidedly.  At K = 4 096 the error must stay inside the bar."""
+    import numpy as np
+    from oracle import seekr_oracle as orc
+    from seekr_amd.pearson import pearson
+    rng = np.random.default_rng(0)
+    K, n = 4096, 48
+    proto = np.zeros(K, np.float32)
+    hot = rng.random(K) > 0.97
+    proto[hot] = rng.integers(1, 9, int(hot.sum()))
+    x = np.tile(proto, (n, 1))
+    for i in range(1, n):
+        idx = rng.integers(0, K, int(rng.choice([0, 1, 3, 10, 40])))
+        x[i, idx] = rng.integers(0, 9, len(idx))
+    truth = orc.pearson_f64_truth(x, x)
+    err = np.abs(pearson(x, x) - truth)
+    assert (err <= 2e-6 + 1e-5 * np.abs(truth)).all(), float((err / (2e-6 + 1e-5 * np.abs(truth))).max())
