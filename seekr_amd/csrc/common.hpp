@@ -98,7 +98,7 @@ int skr_launch_gemm_f32(skr_ctx* ctx, const float* A, const float* B, float* C, 
 int skr_launch_gemm_f64(skr_ctx* ctx, const double* A, const double* B, double* C, int64_t M, int64_t N, int64_t K,
                         int64_t lda, int64_t ldb, int64_t ldc, double kdiv, int symmetric);
 int skr_launch_gemm_split(skr_ctx* ctx, int precision, const void* As, const void* Bs, float* C, int64_t M, int64_t N,
-                          int64_t kt, int64_t ldc, float kdiv, int mode, float* Ct, int64_t ldct);
+                          int64_t kt, int64_t ldc, float kdiv, int mode, float* Ct, int64_t ldct, int chunk_tiles = 128);
 
 // A Pearson operand prepared for the matrix cores.  Storage is kt*32 float-sized words per row
 // (kt = ceil(cols/32)) in both layouts: zero-padded float32, or split-interleaved 16-bit halves
@@ -112,6 +112,7 @@ struct skr_operand {
     float scale = 1.f;        // stored values = z * scale (fp16 halves only; a function of cols)
     float* diag = nullptr;    // [rows] <z_i, z_i>/K, written by skr_operand_fill (not exchanged between GPUs)
     bool diag_valid = false;  // false for buffers that only ever received rows from a peer
+    bool coherent = false;    // rows are mostly one repeated value: the contraction restarts its accumulators twice as often
     bool owner = true;
     size_t row_bytes() const { return (size_t)kt * 128; }
 };

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void operand_fill_kernel(FillArgs a) {
     const int64_t K = a.cols, Kp = a.kt * 32;
     float* row = lds + (size_t)wave * ((K + 3) & ~(int64_t)3);
     const bool vec = (K & 3) == 0;
-    bool any_nan = false, overflow = false, outlier = false;
+    bool any_nan = false, overflow = false, outlier = false, coherent = false;
     for (int64_t r = (int64_t)blockIdx.x * waves + wave; r < a.rows; r += (int64_t)gridDim.x * waves) {
         const float* xr = a.x + (size_t)r * K;
         // ---- pass 1: load, elementwise tail of the normalisation, optional write-back, row sum
@@ -145,6 +145,13 @@ __global__ __launch_bounds__(256) void operand_fill_kernel(FillArgs a) {
                 zmax2 = fmaxf(zmax2, zc * zc);
             }
             zmax2 = wave_max(zmax2);
+            // share of the row held by its minimum (see operand_fill_reg_kernel); equal raw values give equal z
+            float vmin = row[0];
+            for (int64_t c = lane; c < K; c += 64) vmin = fminf(vmin, row[c]);
+            vmin = -wave_max(-vmin);
+            float same = 0.f;
+            for (int64_t c = lane; c < K; c += 64) same += (float)(row[c] == vmin);
+            if (wave_sum(same) >= 0.85f * (float)K) coherent = true;
         }
         // ---- pass 3: emit the operand row, 8 k per lane and step
         float sq = 0.f;
@@ -185,6 +192,7 @@ __global__ __launch_bounds__(256) void operand_fill_kernel(FillArgs a) {
     if (any_nan) atomicOr(&a.flags[1], 1u);
     if (overflow) atomicOr(&a.flags[3], 1u);
     if (outlier) atomicOr(&a.flags[4], 1u);
+    if (coherent) atomicOr(&a.flags[5], 1u);
 }
 
 // One WORKGROUP per row, for rows of 32 KiB and more (k >= 7), where a wave-private LDS slice would
@@ -333,11 +341,11 @@ using vec4h = T __attribute__((ext_vector_type(4)));
 // through 16 bytes of LDS and one barrier each).
 template <typename T, int VPL, int MODE, int RW>
 __global__ __launch_bounds__(256) void operand_fill_reg_kernel(FillArgs a) {
-    __shared__ float red[5][4];
+    __shared__ float red[7][4];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
     constexpr int64_t K = (int64_t)VPL * 256 * RW;
-    bool any_nan = false, overflow = false, outlier = false;
+    bool any_nan = false, overflow = false, outlier = false, coherent = false;
     // sum / max over the row; `slot` separates the reductions of one row so that one barrier each is enough
     auto row_sum = [&](float v, int slot) -> float {
         v = wave_sum(v);
@@ -417,6 +425,19 @@ __global__ __launch_bounds__(256) void operand_fill_reg_kernel(FillArgs a) {
             for (int i = 0; i < VPL; i++)
                 zmax2 = fmaxf(fmaxf(zmax2, fmaxf(v[i].x * v[i].x, v[i].y * v[i].y)), fmaxf(v[i].z * v[i].z, v[i].w * v[i].w));
             if (row_needs_fp32(row_max(zmax2, 4), (float)K)) outlier = true;
+            // Share of the row held by one repeated value — for count data its minimum, the empty bins.  Near-copies
+            // of such a row have only positive products, small ones added to a sum that is already large, and the
+            // truncating accumulate then loses up to an ulp of the sum per add (tools/margin_probe.py: the bar is
+            // reached at 97 %); the contraction restarts its accumulators twice as often for flagged operands.
+            float zmin = v[0].x;
+#pragma unroll
+            for (int i = 0; i < VPL; i++) zmin = fminf(fminf(zmin, fminf(v[i].x, v[i].y)), fminf(v[i].z, v[i].w));
+            zmin = -row_max(-zmin, 5);
+            float same = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPL; i++)
+                same += (float)((v[i].x == zmin) + (v[i].y == zmin) + (v[i].z == zmin) + (v[i].w == zmin));
+            if (row_sum(same, 6) >= 0.85f * (float)K) coherent = true;
         }
 #pragma unroll
         for (int i = 0; i < VPL; i++) {
@@ -443,6 +464,7 @@ __global__ __launch_bounds__(256) void operand_fill_reg_kernel(FillArgs a) {
     if (any_nan) atomicOr(&a.flags[1], 1u);
     if (overflow) atomicOr(&a.flags[3], 1u);
     if (outlier) atomicOr(&a.flags[4], 1u);
+    if (coherent) atomicOr(&a.flags[5], 1u);
 }
 
 // r[i, i] of a self-comparison = <z_i, z_i> / K.  The contraction adds 4 096 squares into one float32
@@ -663,9 +685,10 @@ extern "C" int skr_operand_fill(skr_ctx* ctx, const skr_mat* x, const skr_mat* c
     if (has_nan) *has_nan = 0;
     if (x->rows == 0) return SKR_OK;
     // flags: [1] NaN seen, [3] fp16 range exceeded, [4] a row needs more dynamic range than one float32
-    // accumulator per cell has ([2] belongs to the counting kernel)
+    // accumulator per cell has, [5] a row is mostly one repeated value ([2] belongs to the counting kernel)
     SKR_HIP(hipMemsetAsync(ctx->d_flags + 1, 0, 4, ctx->stream));
-    SKR_HIP(hipMemsetAsync(ctx->d_flags + 3, 0, 8, ctx->stream));
+    SKR_HIP(hipMemsetAsync(ctx->d_flags + 3, 0, 12, ctx->stream));
+    op->coherent = false;
     SKR_TRY(launch_fill(ctx, op, a));
     op->diag_valid = true;
     // values are only bounded by sqrt(K) when the rows were standardised here: check the fp16 range otherwise
@@ -675,6 +698,7 @@ extern "C" int skr_operand_fill(skr_ctx* ctx, const skr_mat* x, const skr_mat* c
         SKR_HIP(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         SKR_HIP(hipStreamSynchronize(ctx->stream));
         if (has_nan) *has_nan = ctx->h_flags[1] != 0;
+        op->coherent = split && ctx->h_flags[5] != 0;
         if (split && ctx->h_flags[4] != 0) {
             // a row is dominated by so few columns that the split contraction would drop the others
             // (see row_needs_fp32): same storage, float32 layout, and the fp32 kernel from here on.  The
@@ -716,6 +740,7 @@ extern "C" int skr_operand_adopt_layout(skr_operand* op, const skr_operand* like
     op->kind = like->kind;
     op->scale = like->scale;
     op->precision = like->precision;
+    op->coherent = like->coherent;
     op->diag_valid = false;
     return SKR_OK;
 }
@@ -741,7 +766,8 @@ extern "C" int skr_pearson_gemm_op(skr_ctx* ctx, const skr_operand* a, const skr
                                     symmetric && self && row0 == col0));
     } else {
         SKR_TRY(skr_launch_gemm_split(ctx, a->precision, a->data, b->data, C, M, N, a->kt, r->cols,
-                                      (float)K * a->scale * b->scale, symmetric && self ? 1 : 0, nullptr, 0));
+                                      (float)K * a->scale * b->scale, symmetric && self ? 1 : 0, nullptr, 0,
+                                      (a->coherent || b->coherent) ? 64 : 128));
     }
     if (self && a->diag_valid && a->diag) {
         hipLaunchKernelGGL(patch_diag_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream, C, r->cols,
@@ -783,7 +809,7 @@ extern "C" int skr_pearson_gemm_op_mirror(skr_ctx* ctx, const skr_operand* a, co
         return skr_launch_gemm_f32(ctx, (const float*)b->data, (const float*)a->data, Ct, N, M, Kp, Kp, Kp, rt->cols, K, 0);
     }
     return skr_launch_gemm_split(ctx, a->precision, a->data, b->data, C, M, N, a->kt, r->cols,
-                                 (float)K * a->scale * b->scale, 2, Ct, rt->cols);
+                                 (float)K * a->scale * b->scale, 2, Ct, rt->cols, (a->coherent || b->coherent) ? 64 : 128);
 }
 
 // One of two freshly filled operands fell back to the float32 layout (a row needs the dynamic range of

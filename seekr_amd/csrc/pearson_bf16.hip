@@ -280,16 +280,18 @@ struct SplitOut {
 
 template <typename T, int NPROD, int MODE>
 int launch16(skr_ctx* ctx, const T* A, const T* B, const SplitOut& o, int64_t M, int64_t N, int64_t kt, float K,
-             const char* name) {
+             const char* name, int64_t chunk_tiles) {
     const int64_t tiles_m = (M + TM - 1) / TM, tiles_n = (N + TN - 1) / TN;
     const int64_t super_m = (tiles_m + 15) / 16, super_n = (tiles_n + 15) / 16;
     const int64_t slots = super_m * super_n * 256;
     static const bool persist = !(getenv("SEEKR_GEMM_PERSIST") && atoi(getenv("SEEKR_GEMM_PERSIST")) == 0);  // A/B knob
     // One float32 accumulator per cell is restarted every 4 096 columns: the MFMA adder truncates each
-    // add at the accumulator's unit (~0.25 ulp lost per add, measured), a bias that grows with the number
+    // add at the accumulator's unit (~0.25 ulp lost per add, measured; `chunk_tiles` = 64, i.e. every 2 048 columns, for
+    // operands whose rows are mostly one repeated value: tools/margin_probe.py), a bias that grows with the number
     // of adds and with the accumulator — 5e-6 relative on an r ~ 1 pair at K = 4 096, four times that at
     // 16 384 in one go.  Later chunks add their partial result to C in the epilogue (rounded float32 adds).
-    constexpr int64_t kChunkTiles = 128;
+    static const int64_t env_chunk = getenv("SEEKR_GEMM_CHUNK_TILES") ? std::max(1, atoi(getenv("SEEKR_GEMM_CHUNK_TILES"))) : 0;  // A/B knob
+    const int64_t kChunkTiles = env_chunk ? env_chunk : chunk_tiles;
     SkrProfScope prof(ctx, name);
     for (int64_t t0 = 0; t0 < kt; t0 += kChunkTiles) {
         const int64_t ktc = std::min(kChunkTiles, kt - t0);
@@ -324,11 +326,11 @@ int launch16(skr_ctx* ctx, const T* A, const T* B, const SplitOut& o, int64_t M,
 
 template <typename T, int NPROD>
 int gemm_split(skr_ctx* ctx, const T* As, const T* Bs, const SplitOut& o, int64_t M, int64_t N, int64_t kt, float K,
-               int mode, const char* name) {
+               int mode, const char* name, int64_t chunk_tiles) {
     switch (mode) {
-        case SELF: return launch16<T, NPROD, SELF>(ctx, As, Bs, o, M, N, kt, K, name);
-        case CROSS: return launch16<T, NPROD, CROSS>(ctx, As, Bs, o, M, N, kt, K, name);
-        default: return launch16<T, NPROD, PLAIN>(ctx, As, Bs, o, M, N, kt, K, name);
+        case SELF: return launch16<T, NPROD, SELF>(ctx, As, Bs, o, M, N, kt, K, name, chunk_tiles);
+        case CROSS: return launch16<T, NPROD, CROSS>(ctx, As, Bs, o, M, N, kt, K, name, chunk_tiles);
+        default: return launch16<T, NPROD, PLAIN>(ctx, As, Bs, o, M, N, kt, K, name, chunk_tiles);
     }
 }
 
@@ -338,18 +340,18 @@ int gemm_split(skr_ctx* ctx, const T* As, const T* Bs, const SplitOut& o, int64_
 // K: the divisor (columns x the operands' storage scales).  mode 0: C = A B^T / K; 1: A == B, one triangle computed and mirrored inside C; 2: C as mode 0 and
 // Ct[j * ldct + i] = C[i * ldc + j] as well.
 int skr_launch_gemm_split(skr_ctx* ctx, int precision, const void* As, const void* Bs, float* C, int64_t M, int64_t N,
-                          int64_t kt, int64_t ldc, float K, int mode, float* Ct, int64_t ldct) {
+                          int64_t kt, int64_t ldc, float K, int mode, float* Ct, int64_t ldct, int chunk_tiles) {
     SplitOut o{C, ldc, mode == SELF ? C : Ct, mode == SELF ? ldc : ldct};
     switch (precision) {
         case SKR_PREC_BF16X3:
             return gemm_split<__bf16, 3>(ctx, (const __bf16*)As, (const __bf16*)Bs, o, M, N, kt, K, mode,
-                                         "pearson_gemm_bf16x3");
+                                         "pearson_gemm_bf16x3", chunk_tiles);
         case SKR_PREC_BF16X4:
             return gemm_split<__bf16, 4>(ctx, (const __bf16*)As, (const __bf16*)Bs, o, M, N, kt, K, mode,
-                                         "pearson_gemm_bf16x4");
+                                         "pearson_gemm_bf16x4", chunk_tiles);
         case SKR_PREC_F16X3:
             return gemm_split<_Float16, 3>(ctx, (const _Float16*)As, (const _Float16*)Bs, o, M, N, kt, K, mode,
-                                           "pearson_gemm_f16x3");
+                                           "pearson_gemm_f16x3", chunk_tiles);
         default: return skr_set_error(SKR_ERR_INVALID, "not a split precision: %d", precision);
     }
 }
