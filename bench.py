@@ -58,21 +58,28 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(k, length, x_norm_head):
+def cpu_baseline(k, length, x_norm_head, repeats=3):
     """The oracle (a port with the reference's structure: per-window dict increments in pure
-    Python, numpy row standardisation + np.inner) timed on a bounded prefix of the workload."""
+    Python, numpy row standardisation + np.inner) timed on a bounded prefix of the workload:
+    `repeats` runs of each leg, median taken."""
     from oracle import seekr_oracle as orc
-    n_count = 30000  # ~10 s of counting + ~5 s of Pearson on the GPU box's host
+    n_count = 6000  # ~2 s per repeat of counting + ~2 s per repeat of Pearson on the GPU box's host
     seqs = orc.codes_to_seqs(synthetic_codes(SEED, n_count, length))
-    t0 = time.perf_counter()
-    orc.raw_counts_py(seqs, k)
-    t_count = time.perf_counter() - t0
+    t_counts = []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        orc.raw_counts_py(seqs, k)
+        t_counts.append(time.perf_counter() - t0)
+    t_count = float(np.median(t_counts))
     rate_bases = n_count * length / t_count
     n_p = x_norm_head.shape[0]
     orc.pearson(x_norm_head[:512], x_norm_head[:512])  # BLAS warm-up
-    t0 = time.perf_counter()
-    orc.pearson(x_norm_head, x_norm_head)
-    t_p = time.perf_counter() - t0
+    t_ps = []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        orc.pearson(x_norm_head, x_norm_head)
+        t_ps.append(time.perf_counter() - t0)
+    t_p = float(np.median(t_ps))
     rate_pairs = n_p * n_p / t_p
     try:
         from threadpoolctl import threadpool_info
@@ -80,7 +87,63 @@ def cpu_baseline(k, length, x_norm_head):
     except Exception:  # noqa: BLE001
         blas_threads = os.cpu_count()
     return {"rate_bases": rate_bases, "rate_pairs": rate_pairs, "t_count": t_count, "t_pearson": t_p,
-            "n_count": n_count, "n_pearson": n_p, "blas_threads": blas_threads}
+            "n_count": n_count, "n_pearson": n_p, "blas_threads": blas_threads, "repeats": repeats}
+
+
+def verify_rows(ctx, r, x_norm, n_check=32, seed=1):
+    """After the timed region: `n_check` random rows of the r the bench just produced (all columns, so
+    both the multiplied and the mirrored triangle) against the oracle's pearson (pearson.py:35-41) on the
+    host copy of the normalised counts.  Returns (ok, worst error / bar); bar = 2e-6 + 1e-5 |r|."""
+    from oracle import seekr_oracle as orc
+    n = x_norm.shape[0]
+    rows = np.sort(np.random.default_rng(seed).choice(n, min(n_check, n), replace=False))
+    a = x_norm[rows]
+    got = np.stack([r.to_numpy(int(row), 1).reshape(-1) for row in rows])
+    worst = 0.0
+    for c0 in range(0, n, 16384):
+        want = orc.pearson(a, x_norm[c0:c0 + 16384])
+        err = np.abs(got[:, c0:c0 + 16384] - want) / (2e-6 + 1e-5 * np.abs(want))
+        worst = max(worst, float(np.max(err)))  # a NaN (there is none in this workload) fails the check
+        if not np.isfinite(worst):
+            return False, worst
+    return worst <= 1.0, worst
+
+
+def end_to_end(ctx, k, length, n_seqs, precision):
+    """PCIe- and file-inclusive rates through the drop-in API (never `value`): FASTA file -> host
+    float32 per-kb counts (BasicCounter: native reader + packer + H2D + kernel + D2H), and host ->
+    host pearson() on a prefix (the result copy over PCIe dominates)."""
+    import tempfile
+    from seekr_amd.kmer_counts import BasicCounter
+    from seekr_amd.pearson import pearson
+    blob, _ = synthetic_ascii(SEED, n_seqs, length)
+    rows = blob.reshape(n_seqs, length)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "cfg.fa")
+        with open(path, "wb") as fh:
+            fh.write(b"".join(b">s%d\n" % i + rows[i].tobytes() + b"\n" for i in range(n_seqs)))
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            c = BasicCounter(path, k=k, mean=False, std=False, log2="Log2.none", silent=True)
+            c.get_counts()
+            times.append(time.perf_counter() - t0)
+    t_counts = float(np.median(times))
+    n_p = min(12000, n_seqs)
+    head = np.ascontiguousarray(c.counts[:n_p])
+    pearson(head[:256], head[:256])
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        pearson(head, head)
+        times.append(time.perf_counter() - t0)
+    t_p = float(np.median(times))
+    return {"fasta_to_host_counts_mbases_per_s": round(n_seqs * length / t_counts / 1e6, 1),
+            "fasta_to_host_counts_s": round(t_counts, 4),
+            "host_to_host_pearson_mpairs_per_s": round(n_p * float(n_p) / t_p / 1e6, 1),
+            "host_to_host_pearson_rows": n_p, "host_to_host_pearson_s": round(t_p, 4),
+            "note": "median of 3; file read + pack + H2D + kernels + D2H through seekr_amd.BasicCounter / "
+                    "seekr_amd.pearson (raw counts; Pearson result copied to the host: PCIe-bound)"}
 
 
 def pmc_traffic(kernel_key):
@@ -192,7 +255,7 @@ def main():
     gemm_key = {"fp32": "pearson_gemm_f32_kernel", "bf16x3": "split16_kernelIDF16bLi3", "bf16x4": "split16_kernelIDF16bLi4",
                 "f16x3": "split16_kernelIDF16_Li3"}[args.precision]
     gemm_traffic = pmc_traffic(gemm_key) if default_shape else None
-    count_traffic = pmc_traffic("count_kmers_kernel<0>") if default_shape else None
+    count_traffic = pmc_traffic("count_kmers_kernel<0") if default_shape else None  # <0, ...>: the float32, non-Log2.pre instantiation
     roofline = {"kernel": gemm_name, "bound": "mfma", "achieved": round(achieved_tf, 2), "peak": peak_tf,
                 "unit": "TFLOP/s", "frac": round(achieved_tf / peak_tf, 4),
                 "traffic": round(gemm_traffic["bytes"] / 1e9, 2) if gemm_traffic else None,
@@ -240,22 +303,33 @@ def main():
         "roofline": roofline, "roofline_count": roofline_count,
         "kernels_ms_per_step": {n: round(v["ms_total"] / steps, 4) for n, v in sorted(kern.items())},
     }
+    if size == 1:
+        # correctness probe of the r this run produced, outside the timed region: 32 random rows x all columns
+        # against the oracle on the host copy of the normalised counts (x holds them: keep_counts=True)
+        x_host = x.to_numpy()
+        ok, worst = verify_rows(ctx, r, x_host)
+        out["verified"] = bool(ok)
+        out["verified_detail"] = {"rows": min(32, n_loc), "columns": n_total, "worst_error_over_bar": round(worst, 4),
+                                  "bar": "|dr| <= 2e-6 + 1e-5 |r| against oracle.pearson (pearson.py:35-41)"}
     if size == 1 and not args.no_cpu_baseline:
-        head = x.to_numpy(0, min(20000, n_loc))
+        head = x_host[:min(12000, n_loc)]
         cb = cpu_baseline(k, length, head)
         t_cpu = n_total * length / cb["rate_bases"] + pairs_per_step / cb["rate_pairs"]
         out["cpu_baseline"] = {
             "value": round(pairs_per_step / t_cpu / 1e6, 3), "unit": "M seq-pairs/s (whole step, extrapolated)",
             "cores": cb["blas_threads"], "kind": "port",
-            "sample": "oracle (pure-Python per-window counting, 1 core) on the first {} sequences: {:.2f} s = {:.3f} "
-                      "Mbases/s; oracle numpy Pearson ({} BLAS threads of {} cores) on the first {} rows: {:.2f} s = "
-                      "{:.2f} M pairs/s; T_cpu(N) = bases/rate_count + N^2/rate_pairs".format(
-                          cb["n_count"], cb["t_count"], cb["rate_bases"] / 1e6, cb["blas_threads"], os.cpu_count(),
-                          cb["n_pearson"], cb["t_pearson"], cb["rate_pairs"] / 1e6),
+            "sample": "median of {} repeats each: oracle (pure-Python per-window counting, 1 core) on the first {} "
+                      "sequences: {:.2f} s = {:.3f} Mbases/s; oracle numpy Pearson ({} BLAS threads of {} cores) on the "
+                      "first {} rows: {:.2f} s = {:.2f} M pairs/s; T_cpu(N) = bases/rate_count + N^2/rate_pairs".format(
+                          cb["repeats"], cb["n_count"], cb["t_count"], cb["rate_bases"] / 1e6, cb["blas_threads"],
+                          os.cpu_count(), cb["n_pearson"], cb["t_pearson"], cb["rate_pairs"] / 1e6),
             "count_mbases_per_s": round(cb["rate_bases"] / 1e6, 4),
             "pearson_mpairs_per_s": round(cb["rate_pairs"] / 1e6, 3),
         }
         out["speedup_vs_cpu_port"] = round(value / out["cpu_baseline"]["value"], 1)
+        del x_host, head
+        r.free()
+        out["e2e"] = end_to_end(ctx, k, length, min(n_total, 50000), args.precision)
     print(json.dumps(out), flush=True)
 
 
