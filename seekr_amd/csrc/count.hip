@@ -1,21 +1,37 @@
 // K2 + K3 — k-mer counting: sliding-window 4^k indexer, per-sequence LDS histogram, and the
 // per-kb scaling fused into the histogram flush (kmer_counts.py:140-151, 194-202).
 //
-// One 256-thread workgroup owns one sequence at a time (persistent grid-stride loop over the
-// sequences, 8 workgroups per CU at k=6).  Two threads share a packed word: thread t of a sweep
-// takes 8 of the 16 windows that start inside word w = sweep*128 + t/2; it holds words w and w+1
-// (consecutive lanes -> consecutive words, coalesced; prefetched one sequence ahead), and every
-// window's column index is a bit-field of that 64-bit pair because the packer stores the first
-// base in the top bits.  Counts go to a 4^k-bin uint32 histogram in LDS (16 KiB at k=6, 64 KiB
-// at k=7) with ds_add_u32; runs of equal indices inside a thread (homopolymers) are merged
-// before the atomic.  The flush converts bins to the reference's float32 per-kb values (a
-// 16-entry per-sequence table covers almost every bin), zeroes them for the next sequence, and
-// streams the dense row to HBM as 16-byte stores — the row write (4*4^k bytes per sequence) is
-// the algorithmic traffic that bounds this kernel.  Two barriers per sequence.
+// count_rows_kernel (k <= 7, the tuned path).  A work item is one sequence (or one 8 192-window tile
+// of a long sequence) and is owned by ONE WAVE at k <= 6 (64-thread workgroups: no barrier anywhere,
+// ~19 independent waves per CU) or by a 4-wave workgroup at k = 7.  Lane l of a sweep takes the 16
+// windows that start in packed word 64*sweep + l; it holds that word and the next (coalesced loads,
+// the first sweeps prefetched one item ahead).  The packer stores the first base in the top bits, so
+// window j of the pair is r_j = v_alignbit(hi, lo, 32 - 2j) and its column the top 2k bits of r_j:
+// no branch, five vector instructions per window.  Bins are 16-bit counters packed two to an LDS
+// word (bin b and bin b + 4^k/2 share word b mod 4^k/2: the top bit of the column picks the half):
+// 8 KiB per item at k = 6, 32 KiB at k = 7 — an item never has more than 8 192 windows, so a bin cannot
+// overflow.  Counting is ds_add_u32 (no return).  When all 64 lanes of a sweep hold the same two
+// packed words (homopolymers and every repeat whose period divides 16 bases) the 64 x 16 atomics —
+// 64 lanes on one address each — are replaced by 16 adds of 64 from one lane (wave-level aggregation
+// by readfirstlane + ballot).  Windows past the end or over a non-alphabet base are redirected to a
+// trash word instead of being branched around.
+// The flush reads four words per lane step (8 bins), zeroes them, converts the counts through a
+// 16-entry per-item table of the reference's float32 per-kb values (built by 16 lanes only when the
+// window count differs from the previous item's) and streams the two 16-byte pieces of the dense row
+// with nontemporal stores — the row write (4*4^k bytes per sequence) is the algorithmic traffic that
+// bounds the kernel.
 //
-// k >= 8 (4^k bins no longer fit the LDS): the same kernel with GLOBAL = true counts straight into
-// the sequence's output row, used as a uint32 histogram in HBM (zeroed by a memset first, L2
-// atomics), and the flush converts the row in place.
+// Long sequences (more than 8 192 windows) are cut into tiles of 8 192 windows (the k-1 bases of halo
+// are simply the next packed words) that are counted like sequences into a scratch matrix of uint32
+// partial histograms; reduce_tiles_kernel sums a sequence's tiles and converts.  A chromosome-sized
+// sequence thus spreads over the whole chip instead of serialising on one CU.
+//
+// count_kmers_kernel (the round-1 kernel: one 256-thread workgroup per sequence, uint32 bins) is kept
+// for float64 output and, with GLOBAL = true, for k >= 8 (4^k bins no longer fit the LDS): it counts
+// straight into the sequence's output row, used as a uint32 histogram in HBM (zeroed by a memset first,
+// L2 atomics), and converts the row in place.
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 #include <vector>
@@ -197,6 +213,330 @@ __global__ __launch_bounds__(kThreads) void count_kmers_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// The tuned path (k <= 7): see the file header.
+// ---------------------------------------------------------------------------------------
+constexpr int kItemWindows = 8192;  // windows per work item: longer sequences are cut into tiles of this many; also keeps a 16-bit bin from overflowing
+
+struct CountArgs {
+    const uint32_t* packed;
+    const int64_t* word_off;
+    const int64_t* len;
+    const uint32_t* mask;
+    const int64_t* mask_off;
+    const int64_t* item_seq;    // TILES: sequence of each tile
+    const int64_t* item_word0;  // TILES: first packed word of the tile inside its sequence
+    int64_t n_items;            // sequences, or tiles
+    void* out;                  // rows [n_seqs, 4^k] of the OUT type; TILES: uint32 [n_items, 4^k] partial histograms
+    int k;
+};
+
+__device__ __forceinline__ void lds_add_u32(uint32_t* lds_base, uint32_t byte_addr, uint32_t v) {
+    (void)__hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(lds_base) + byte_addr), v, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_WORKGROUP);  // result unused: ds_add_u32
+}
+
+template <int OUT, int WPS, bool TILES>
+__global__ __launch_bounds__(WPS * 64) void count_rows_kernel(const CountArgs a) {
+    constexpr int T = WPS * 64;
+    constexpr int P = WPS == 1 ? 2 : 1;  // sweeps of packed words prefetched one item ahead (2 048 / 4 096 bases)
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int tid = threadIdx.x;
+    const int k = a.k;
+    const uint32_t nbins = 1u << (2 * k);
+    const uint32_t nwords = nbins >> 1;                 // two 16-bit bins per word: bin b and bin b + nwords
+    const uint32_t hist_words = nwords < 4 ? 4 : nwords;
+    uint32_t* hist = lds;                               // [hist_words] | trash [64] | tab [16]
+    const uint32_t trash_addr = (hist_words + (tid & 63)) * 4;  // one word per lane: no two lanes of a wave collide on it
+    float* tab = reinterpret_cast<float*>(lds + hist_words + 64);
+    const uint32_t sh = 30 - 2 * k;                     // (r >> sh) & amask = byte address of the window's word
+    const uint32_t amask = (nwords - 1) << 2;
+    const uint32_t win_mask = (1u << k) - 1u;           // k consecutive validity bits
+
+    for (uint32_t w = tid * 4; w < hist_words + 64; w += T * 4) *reinterpret_cast<uint4*>(&hist[w]) = make_uint4(0, 0, 0, 0);
+
+    // The packed words of the NEXT item are fetched while the current one is flushed.  Unconditional loads,
+    // indices clamped into the padded arrays: a branch around them would make hipcc drain vmcnt(0) at the join.
+    int64_t n_seq = 0, nL = 0, n_woff = 0, n_moff = -1, n_w0 = 0;
+    uint32_t n_hi[P], n_lo[P];
+    auto windows_of = [&](int64_t L, int64_t w0) -> int64_t {  // windows this item counts
+        const int64_t Wtot = L - k + 1;
+        int64_t Wi = Wtot - (w0 << 4);
+        if (TILES) Wi = Wi < kItemWindows ? Wi : kItemWindows;
+        else if (Wtot > kItemWindows) Wi = 0;  // a long sequence: its tiles are counted by the TILES launch
+        return Wi > 0 ? Wi : 0;
+    };
+    auto prefetch = [&](int64_t it) {
+        it = it < a.n_items ? it : a.n_items - 1;
+        n_seq = TILES ? a.item_seq[it] : it;
+        n_w0 = TILES ? a.item_word0[it] : 0;
+        nL = a.len[n_seq];
+        n_woff = a.word_off[n_seq] + n_w0;
+        n_moff = a.mask_off[n_seq];
+        const int64_t nww = (windows_of(nL, n_w0) + 15) >> 4;
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const int64_t w = p * T + tid;
+            const int64_t wc = w < nww ? w : nww;
+            n_hi[p] = a.packed[n_woff + wc];
+            n_lo[p] = a.packed[n_woff + wc + 1];
+        }
+    };
+    prefetch(blockIdx.x);
+    if (WPS > 1) __syncthreads();
+    int64_t tab_W = INT64_MIN;  // window count the table was built for
+    // current item: metadata and first sweeps in registers.  The loads of item i+1 are issued at the START of
+    // item i's counting and consumed (moved into c_*) BEFORE item i's row is stored: a wave never waits for
+    // its own stores — vmcnt counts loads and stores together, in order, so a load issued after a row's stores
+    // could only be waited for with all of them.
+    int64_t seq = n_seq, L = nL, woff = n_woff, moff = n_moff, w0 = n_w0;
+    uint32_t c_hi[P], c_lo[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        c_hi[p] = n_hi[p];
+        c_lo[p] = n_lo[p];
+    }
+
+    for (int64_t it = blockIdx.x; it < a.n_items; it += gridDim.x) {
+        prefetch(it + gridDim.x);  // in flight during the counting
+        const int64_t Wtot = L - k + 1;  // windows, counting every character (kmer_counts.py:143-144)
+        const int64_t Wi = windows_of(L, w0);
+        const bool skip = !TILES && Wtot > kItemWindows;
+        const int64_t nww = (Wi + 15) >> 4;
+        const double inc = Wtot > 0 ? 1000.0 / (double)Wtot : 0.0;
+        if ((OUT == OUT_F32 || OUT == OUT_F32_LOG2) && Wtot != tab_W) {
+            // the item's output value for every small count (almost all bins): 16 lanes do the float64 work,
+            // the flush just looks it up; sets of equal-length sequences build it once
+            if (tid < kTabSize) {
+                float t = per_kb_value((uint32_t)tid, inc);
+                if (OUT == OUT_F32_LOG2) t = skr_log2_cr(t + 1.0f);  // kmer_counts.py:189-192: counts += 1; log2
+                tab[tid] = t;
+            }
+            tab_W = Wtot;
+        }
+
+        auto sweep = [&](int64_t base, uint32_t hi, uint32_t lo) {
+            const int64_t w = base + tid;
+            if (moff < 0 && Wi - ((base + T - 1) << 4) >= 16) {
+                // every lane of the workgroup has 16 whole windows.  Wave-level aggregation: if all 64 lanes
+                // hold the same two words, each of the 16 columns would get 64 adds on one address
+                const uint32_t h0 = __builtin_amdgcn_readfirstlane(hi), l0 = __builtin_amdgcn_readfirstlane(lo);
+                const bool same = __builtin_amdgcn_ballot_w64(((hi ^ h0) | (lo ^ l0)) != 0) == 0;
+                if (same) {
+                    if ((tid & 63) == 0) {
+#pragma unroll
+                        for (int j = 0; j < 16; j++) {
+                            const uint32_t r = j ? __builtin_amdgcn_alignbit(hi, lo, 32 - 2 * j) : hi;
+                            lds_add_u32(hist, (r >> sh) & amask, (int32_t)r < 0 ? 0x400000u : 64u);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        const uint32_t r = j ? __builtin_amdgcn_alignbit(hi, lo, 32 - 2 * j) : hi;
+                        lds_add_u32(hist, (r >> sh) & amask, (int32_t)r < 0 ? 0x10000u : 1u);
+                    }
+                }
+            } else {
+                // a sweep that holds the end of the item or non-alphabet bases: windows that do not count are
+                // sent to a trash word (still counted in W: kmer_counts.py:143-149)
+                const int64_t left = Wi - (w << 4);
+                const int lim = left < 0 ? 0 : (left > 16 ? 16 : (int)left);
+                uint32_t invalid = 0;  // bit j: base 16(w0+w)+j is not in the alphabet
+                if (moff >= 0) {
+                    const int64_t aw = w0 + (w < nww ? w : nww);
+                    const uint32_t* mwords = a.mask + moff + (aw >> 1);
+                    invalid = (uint32_t)(((unsigned long long)mwords[0] | ((unsigned long long)mwords[1] << 32)) >> ((aw & 1) * 16));
+                }
+                if (lim > 0) {  // lanes past the end of the item do nothing
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        const uint32_t r = j ? __builtin_amdgcn_alignbit(hi, lo, 32 - 2 * j) : hi;
+                        const bool ok = j < lim && ((invalid >> j) & win_mask) == 0;
+                        lds_add_u32(hist, ok ? ((r >> sh) & amask) : trash_addr, (int32_t)r < 0 ? 0x10000u : 1u);
+                    }
+                }
+            }
+        };
+#pragma unroll
+        for (int p = 0; p < P; p++)
+            if ((int64_t)p * T < nww) sweep((int64_t)p * T, c_hi[p], c_lo[p]);
+        for (int64_t base = (int64_t)P * T; base < nww; base += T) {  // longer items
+            const int64_t w = base + tid;
+            const int64_t wc = w < nww ? w : nww;
+            sweep(base, a.packed[woff + wc], a.packed[woff + wc + 1]);
+        }
+        // the next item's words have arrived (only the previous row's stores are older): take them now
+        const int64_t t_seq = n_seq, t_L = nL, t_woff = n_woff, t_moff = n_moff, t_w0 = n_w0;
+        uint32_t t_hi[P], t_lo[P];
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            asm volatile("v_mov_b32 %0, %1" : "=v"(t_hi[p]) : "v"(n_hi[p]));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(t_lo[p]) : "v"(n_lo[p]));
+        }
+        if (WPS > 1) __syncthreads();
+        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // one wave: the LDS executes its instructions in order
+
+        // ---- flush: bins -> output values, dense row to HBM; the bins are zeroed on the way out
+        if (!skip) {
+            auto value_of = [&](uint32_t n) -> float {
+                if (n < (uint32_t)kTabSize) return tab[n];
+                float t = per_kb_value(n, inc);
+                if (OUT == OUT_F32_LOG2) t = skr_log2_cr(t + 1.0f);
+                return t;
+            };
+            const size_t row = (size_t)(TILES ? it : seq) * nbins;
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+            for (uint32_t w4 = tid * 4; w4 < nwords; w4 += T * 4) {
+                const uint4 c = *reinterpret_cast<const uint4*>(&hist[w4]);
+                *reinterpret_cast<uint4*>(&hist[w4]) = make_uint4(0, 0, 0, 0);
+                if (nwords < 4) {  // k = 1: two words, four bins
+                    const uint32_t cw[2] = {c.x, c.y};
+                    for (int i = 0; i < 2; i++) {
+                        if (OUT == OUT_U32) {
+                            reinterpret_cast<uint32_t*>(a.out)[row + i] = cw[i] & 0xFFFFu;
+                            reinterpret_cast<uint32_t*>(a.out)[row + 2 + i] = cw[i] >> 16;
+                        } else {
+                            reinterpret_cast<float*>(a.out)[row + i] = value_of(cw[i] & 0xFFFFu);
+                            reinterpret_cast<float*>(a.out)[row + 2 + i] = value_of(cw[i] >> 16);
+                        }
+                    }
+                } else if (OUT == OUT_U32) {
+                    u4* dst = reinterpret_cast<u4*>(reinterpret_cast<uint32_t*>(a.out) + row + w4);
+                    const u4 lo4{c.x & 0xFFFFu, c.y & 0xFFFFu, c.z & 0xFFFFu, c.w & 0xFFFFu};
+                    const u4 hi4{c.x >> 16, c.y >> 16, c.z >> 16, c.w >> 16};
+                    if (TILES) {  // read again in a moment by reduce_tiles_kernel: leave them in the L2
+                        dst[0] = lo4;
+                        *reinterpret_cast<u4*>(reinterpret_cast<uint32_t*>(dst) + nwords) = hi4;
+                    } else {
+                        __builtin_nontemporal_store(lo4, dst);
+                        __builtin_nontemporal_store(hi4, reinterpret_cast<u4*>(reinterpret_cast<uint32_t*>(dst) + nwords));
+                    }
+                } else {
+                    f4 lo4, hi4;
+                    if (((c.x | c.y | c.z | c.w) & 0xFFF0FFF0u) == 0) {  // all eight counts below 16: table
+                        lo4 = f4{tab[c.x & 15u], tab[c.y & 15u], tab[c.z & 15u], tab[c.w & 15u]};
+                        hi4 = f4{tab[c.x >> 16], tab[c.y >> 16], tab[c.z >> 16], tab[c.w >> 16]};
+                    } else {
+                        lo4 = f4{value_of(c.x & 0xFFFFu), value_of(c.y & 0xFFFFu), value_of(c.z & 0xFFFFu), value_of(c.w & 0xFFFFu)};
+                        hi4 = f4{value_of(c.x >> 16), value_of(c.y >> 16), value_of(c.z >> 16), value_of(c.w >> 16)};
+                    }
+                    // the row is written once and not read again by this kernel: keep it out of the L2
+                    f4* dst = reinterpret_cast<f4*>(reinterpret_cast<float*>(a.out) + row + w4);
+                    __builtin_nontemporal_store(lo4, dst);
+                    __builtin_nontemporal_store(hi4, reinterpret_cast<f4*>(reinterpret_cast<float*>(dst) + nwords));
+                }
+            }
+        }
+        if (WPS > 1) __syncthreads();  // zeroed bins visible before the next item is counted
+        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        seq = t_seq, L = t_L, woff = t_woff, moff = t_moff, w0 = t_w0;
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            c_hi[p] = t_hi[p];
+            c_lo[p] = t_lo[p];
+        }
+    }
+}
+
+// Sum of a long sequence's tile histograms -> its output row (same per-kb arithmetic as the flush above).
+template <int OUT>
+__global__ __launch_bounds__(256) void reduce_tiles_kernel(const uint32_t* __restrict__ partial, const int64_t* __restrict__ long_seq,
+                                                           const int64_t* __restrict__ tile_begin, const int64_t* __restrict__ len,
+                                                           int k, void* __restrict__ out) {
+    const uint32_t nbins = 1u << (2 * k);
+    const int64_t ls = blockIdx.y;
+    const int64_t seq = long_seq[ls];
+    const int64_t t0 = tile_begin[ls], t1 = tile_begin[ls + 1];
+    const double inc = 1000.0 / (double)(len[seq] - k + 1);
+    for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < nbins; b += gridDim.x * 256) {
+        uint32_t n = 0;
+        for (int64_t t = t0; t < t1; t++) n += partial[(size_t)t * nbins + b];
+        if (OUT == OUT_U32) {
+            reinterpret_cast<uint32_t*>(out)[(size_t)seq * nbins + b] = n;
+        } else {
+            float v = per_kb_value(n, inc);
+            if (OUT == OUT_F32_LOG2) v = skr_log2_cr(v + 1.0f);
+            reinterpret_cast<float*>(out)[(size_t)seq * nbins + b] = v;
+        }
+    }
+}
+
+// k <= 7, float32 / uint32 output: count_rows_kernel over the sequences, then the tiles of the long ones.
+template <int OUT, int WPS>
+int launch_rows(skr_ctx* ctx, const skr_seqs* s, int k, void* out) {
+    const uint32_t nbins = 1u << (2 * k);
+    const size_t lds = ((size_t)std::max<uint32_t>(4u, nbins >> 1) + 64 + kTabSize) * 4;
+    auto grid_for_kernel = [&](const void* kern, int threads, int64_t items, unsigned* grid) -> int {
+        SKR_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int per_cu = 0;
+        SKR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds));
+        per_cu = std::max(1, std::min(per_cu, 2048 / threads));
+        // persistent, statically strided items: every workgroup must be resident from the start
+        *grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(items, (int64_t)ctx->num_cu * per_cu));
+        return SKR_OK;
+    };
+    CountArgs a{s->d_packed, s->d_word_off, s->d_len, s->d_mask, s->d_mask_off, nullptr, nullptr, s->n, out, k};
+    unsigned grid = 1;
+    auto kern = count_rows_kernel<OUT, WPS, false>;
+    SKR_TRY(grid_for_kernel(reinterpret_cast<const void*>(kern), WPS * 64, s->n, &grid));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WPS * 64), lds, ctx->stream, a);
+    SKR_HIP(hipGetLastError());
+    if (s->max_len - k + 1 <= kItemWindows) return SKR_OK;
+
+    // ---- long sequences: tiles of kItemWindows windows -> uint32 partial histograms -> reduce + convert
+    std::vector<int64_t> long_seq, tile_begin{0}, item_seq, item_word0;
+    auto run_batch = [&]() -> int {
+        const int64_t n_long = (int64_t)long_seq.size(), n_tiles = (int64_t)item_seq.size();
+        if (n_long == 0) return SKR_OK;
+        const size_t idx_bytes = (size_t)(2 * n_tiles + 2 * n_long + 1) * sizeof(int64_t);
+        const size_t part_off = (idx_bytes + 255) & ~(size_t)255;
+        void* ws = nullptr;
+        SKR_TRY(skr_ctx_workspace(ctx, part_off + (size_t)n_tiles * nbins * 4, &ws));
+        int64_t* d_item_seq = reinterpret_cast<int64_t*>(ws);
+        int64_t* d_item_word0 = d_item_seq + n_tiles;
+        int64_t* d_long_seq = d_item_word0 + n_tiles;
+        int64_t* d_tile_begin = d_long_seq + n_long;
+        uint32_t* d_partial = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ws) + part_off);
+        SKR_HIP(hipMemcpyAsync(d_item_seq, item_seq.data(), (size_t)n_tiles * 8, hipMemcpyHostToDevice, ctx->stream));
+        SKR_HIP(hipMemcpyAsync(d_item_word0, item_word0.data(), (size_t)n_tiles * 8, hipMemcpyHostToDevice, ctx->stream));
+        SKR_HIP(hipMemcpyAsync(d_long_seq, long_seq.data(), (size_t)n_long * 8, hipMemcpyHostToDevice, ctx->stream));
+        SKR_HIP(hipMemcpyAsync(d_tile_begin, tile_begin.data(), (size_t)(n_long + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        CountArgs t{s->d_packed, s->d_word_off, s->d_len, s->d_mask, s->d_mask_off, d_item_seq, d_item_word0, n_tiles, d_partial, k};
+        auto tkern = count_rows_kernel<OUT_U32, 4, true>;
+        unsigned tgrid = 1;
+        SKR_TRY(grid_for_kernel(reinterpret_cast<const void*>(tkern), 256, n_tiles, &tgrid));
+        hipLaunchKernelGGL(tkern, dim3(tgrid), dim3(256), lds, ctx->stream, t);
+        SKR_HIP(hipGetLastError());
+        const dim3 rgrid((unsigned)std::min<uint32_t>((nbins + 255) / 256, 64), (unsigned)n_long);
+        hipLaunchKernelGGL(reduce_tiles_kernel<OUT>, rgrid, dim3(256), 0, ctx->stream, d_partial, d_long_seq, d_tile_begin, s->d_len, k,
+                           out);
+        SKR_HIP(hipGetLastError());
+        SKR_HIP(hipStreamSynchronize(ctx->stream));  // the host vectors above are the source of the async copies
+        long_seq.clear();
+        item_seq.clear();
+        item_word0.clear();
+        tile_begin.assign(1, 0);
+        return SKR_OK;
+    };
+    const int64_t batch_tiles = std::max<int64_t>(1, ((int64_t)1 << 31) / ((int64_t)nbins * 4));  // ~2 GB of partial histograms
+    for (int64_t i = 0; i < s->n; i++) {
+        const int64_t W = s->h_len[i] - k + 1;
+        if (W <= kItemWindows) continue;
+        const int64_t tiles = (W + kItemWindows - 1) / kItemWindows;
+        if (!item_seq.empty() && (int64_t)item_seq.size() + tiles > batch_tiles) SKR_TRY(run_batch());
+        if ((int64_t)long_seq.size() >= 65535) SKR_TRY(run_batch());  // gridDim.y limit
+        long_seq.push_back(i);
+        for (int64_t t = 0; t < tiles; t++) {
+            item_seq.push_back(i);
+            item_word0.push_back(t * (kItemWindows / 16));
+        }
+        tile_begin.push_back((int64_t)item_seq.size());
+    }
+    return run_batch();
+}
+
 template <int OUT>
 int launch_count(skr_ctx* ctx, const skr_seqs* s, int k, void* out, const char* name) {
     if (k > 7) {  // histogram in the output row itself
@@ -209,6 +549,14 @@ int launch_count(skr_ctx* ctx, const skr_seqs* s, int k, void* out, const char* 
         SKR_HIP(hipGetLastError());
         return SKR_OK;
     }
+    if (s->n < 1) return SKR_OK;
+    if (OUT != OUT_F64) {
+        SkrProfScope prof(ctx, name);
+        // k <= 6: one wave per sequence (8 KiB of bins at k = 6); k = 7: 32 KiB of bins shared by four waves
+        const int wps = k <= 6 ? 1 : 4;
+        constexpr int O = OUT == OUT_F64 ? OUT_F32 : OUT;  // (never instantiated for float64)
+        return wps == 1 ? launch_rows<O, 1>(ctx, s, k, out) : launch_rows<O, 4>(ctx, s, k, out);
+    }
     const size_t lds = (size_t)4 << (2 * k);
     SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(count_kmers_kernel<OUT, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -216,7 +564,6 @@ int launch_count(skr_ctx* ctx, const skr_seqs* s, int k, void* out, const char* 
     int per_cu = (int)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1));
     if (per_cu < 1) per_cu = 1;
     int64_t grid = std::min<int64_t>(s->n, (int64_t)ctx->num_cu * per_cu);
-    if (grid < 1) return SKR_OK;
     SkrProfScope prof(ctx, name);
     hipLaunchKernelGGL((count_kmers_kernel<OUT, false>), dim3((unsigned)grid), dim3(kThreads), lds, ctx->stream, s->d_packed,
                        s->d_word_off, s->d_len, s->d_mask, s->d_mask_off, s->n, k, out, ctx->d_flags);

@@ -382,6 +382,39 @@ def test_counts_bitexact_vs_oracle_ragged(k, L, ctx):
     assert np.array_equal(f64, orc.per_kb_from_counts(n_ref, [len(s) for s in seqs], k, dtype=np.float64))
 
 
+@pytest.mark.parametrize("k", [3, 6, 7])
+def test_long_sequences_are_cut_into_tiles(k, L, ctx):
+    """Sequences of more than 8 192 windows are counted as tiles of 8 192 windows spread over the chip and
+    summed (count.hip: reduce_tiles_kernel) — the reference handles any length (kmer_counts.py:140-151;
+    its shipped background holds the ~90 kb Airn).  Lengths on both sides of every tile boundary, N runs
+    across a boundary, homopolymers (one bin holds every window: far past a 16-bit counter), a 5 Mbase
+    sequence; raw counts bit-exact against the C oracle, per-kb float32 bit-exact."""
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(100 + k)
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def rnd(n):
+        return letters[rng.integers(0, 4, size=n)].copy()
+
+    arrs = [rnd(n) for n in (8191 + k - 1, 8192 + k - 1, 8193 + k - 1, 16384 + k - 1, 16385 + k, 30011, 90_000, 5_000_000)]
+    with_n = rnd(40_000)
+    with_n[8180:8215] = ord("N")        # a run of N across the first tile boundary
+    with_n[16384 + 3] = ord("N")
+    with_n[-1] = ord("N")
+    arrs += [with_n, np.full(70_000, ord("T"), np.uint8), np.frombuffer(b"AC" * 20_000, np.uint8),
+             np.frombuffer(b"ACG" * 11_000, np.uint8), rnd(700), rnd(2000), np.full(9000, ord("A"), np.uint8)]
+    seqs = [a.tobytes().decode() for a in arrs]
+    blob, offsets = co.seqs_to_blob(seqs)
+    n_ref = co.count_u32(blob, offsets, k)
+    packed = ctx.pack(seqs, "AGTC")
+    assert np.array_equal(L.count_u32(ctx, packed, k).to_numpy(), n_ref)
+    lens = [len(s) for s in seqs]
+    assert_bits(L.count_per_kb(ctx, packed, k).to_numpy(), co.per_kb_f32(n_ref, lens, k), "per-kb of long sequences, k=%d" % k)
+    want_pre = orc.log2_plus_one(co.per_kb_f32(n_ref, lens, k))
+    got_pre = L.count_per_kb(ctx, packed, k, log2_pre=True).to_numpy()
+    assert np.allclose(got_pre, want_pre, rtol=RTOL, atol=ATOL_LOG)
+
+
 def test_normalize_bitexact_vs_oracle_odd_shapes(L, ctx):
     rng = np.random.default_rng(3)
     for rows, cols in ((7, 4), (300, 16), (1025, 64), (513, 100), (2500, 1024)):

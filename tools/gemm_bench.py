@@ -1,0 +1,73 @@
+"""Pearson contraction A/B bench: variants (environment knobs read at every launch) interleaved in ONE
+process, median and min of HIP-event times per launch (cdna_hip_programming.md rule 24), on random
+normalised-count-like operands (never zeros: MI355X_MICROARCH.md, DVFS give-back).
+
+    python tools/gemm_bench.py [--rows 50000] [--cols 4096] [--mode self|plain] [--rounds 7] NAME=ENV=VAL[,ENV=VAL] ...
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+from seekr_amd import _lib  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=50000)
+    ap.add_argument("--rows-b", type=int, default=0)
+    ap.add_argument("--cols", type=int, default=4096)
+    ap.add_argument("--mode", default="self", choices=["self", "plain"])
+    ap.add_argument("--precision", default="f16x3")
+    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("variants", nargs="*")
+    args = ap.parse_args()
+    variants = []
+    for spec in args.variants or ["base="]:
+        name, _, envs = spec.partition("=")
+        variants.append((name, dict(e.split("=", 1) for e in envs.split(",") if e)))
+    ctx = _lib.default_context()
+    prec = _lib.PRECISIONS[args.precision]
+    rng = np.random.default_rng(0)
+    m = args.rows
+    n = args.rows_b or m
+
+    def operand(rows, seed):
+        # binomial counts -> Log2-like values: what the pipeline feeds the contraction
+        chunk = 8192
+        op = _lib.Operand(ctx, rows, args.cols, prec)
+        for r0 in range(0, rows, chunk):
+            nr = min(chunk, rows - r0)
+            x = np.log2(rng.binomial(1995, 1.0 / 4096, size=(nr, args.cols)).astype(np.float32) * np.float32(0.5) + 1.0)
+            d = ctx.from_numpy(x.astype(np.float32))
+            _lib.operand_fill(ctx, d, op=op.view(r0, nr), precision=prec)
+            d.free()
+        return op
+
+    a = operand(m, 1)
+    b = a if args.mode == "self" else operand(n, 2)
+    r = ctx.empty(m, n)
+    res = {name: [] for name, _ in variants}
+    for _ in range(args.rounds):
+        for name, env in variants:
+            os.environ.update(env)
+            ctx.prof_reset()
+            ctx.prof_enable(True)
+            _lib.pearson_gemm_op(ctx, a, b, r, symmetric=args.mode == "self")
+            ctx.sync()
+            ctx.prof_enable(False)
+            res[name].append(sum(ctx.prof_query(nm)[0] for nm in ctx.prof_names() if nm.startswith("pearson_gemm")))
+            for key in env:
+                os.environ.pop(key, None)
+    pairs = float(m) * n
+    mult = pairs if args.mode == "plain" else m * (m + 256) / 2.0
+    for name, ts in res.items():
+        ts = np.array(ts[1:])
+        med = float(np.median(ts))
+        print("%-16s median %.3f ms  min %.3f ms  -> %.1f G pairs/s delivered, MFMA executed %.0f TF (%.3f of 2.5 PF)"
+              % (name, med, ts.min(), pairs / med / 1e6, 3 * 2 * args.cols * mult / med / 1e9, 3 * 2 * args.cols * mult / med / 1e9 / 2500))
+
+
+if __name__ == "__main__":
+    main()
