@@ -338,6 +338,14 @@ int skr_comm_wait(skr_ctx* ctx, int64_t ticket);
 /* all-reduce of a few host doubles (op: 0 = sum, 1 = max, 2 = min)                          */
 int skr_comm_allreduce_f64(skr_ctx* ctx, double* values, int n, int op);
 
+
+/* ---------------------------------------------------------------- diagnostics ------------- */
+/* With SEEKR_GEMM_DIAG=1 in the environment the split-fp16 contraction runs a diagnostic build
+ * whose workgroups stamp s_memtime / s_memrealtime around the k loop and the epilogue of every
+ * tile (in-kernel clock and phase anatomy; MI355X_MICROARCH.md "DVFS give-back" item 6).  This
+ * copies the records of the last such launch to the host: out[max_records][8] uint64.          */
+int skr_gemm_diag_read(skr_ctx* ctx, unsigned long long* out, int64_t max_records, int64_t* n_records);
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,6 +101,7 @@ SIGNATURES = {
     "skr_comm_allgather_rows": (_int, [_p, _p, _p, C.POINTER(_i64), C.POINTER(_i64)]),
     "skr_comm_wait": (_int, [_p, _i64]),
     "skr_comm_allreduce_f64": (_int, [_p, C.POINTER(C.c_double), _int, _int]),
+    "skr_gemm_diag_read": (_int, [_p, _p, _i64, C.POINTER(_i64)]),
 }
 
 _lib = None

@@ -25,6 +25,7 @@
 // matrix Ct — r(h,g) = r(g,h)^T costs stores, not a second contraction (distributed half-ring).
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -75,11 +76,15 @@ __device__ __forceinline__ f32x4v mfma16x16(vec8<_Float16> a, vec8<_Float16> b, 
 // the placement.  What this buys over one workgroup per tile: the stores of tile t drain while the
 // main loop of tile t+1 runs (with one 128 KiB workgroup per CU nothing else overlaps them), and
 // the slots a self-comparison skips cost one atomic instead of a workgroup launch.
-template <typename T, int NPROD, int MODE, bool PERSIST>
+// DIAG (a diagnostic build, launched only under SEEKR_GEMM_DIAG=1, tools/gemm_diag.py): lane 0 of each workgroup stamps
+// s_memtime (shader cycles) and s_memrealtime (100 MHz) around the k loop and the epilogue of every tile into a buffer of
+// its own (MI355X_MICROARCH.md, DVFS give-back item 6); no output value depends on a stamp.
+template <typename T, int NPROD, int MODE, bool PERSIST, bool DIAG = false>
 __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
     const T* __restrict__ A, const T* __restrict__ B, float* __restrict__ C, float* __restrict__ Ct,
     int64_t M, int64_t N, int64_t kt, int64_t ldc, int64_t ldct, float kdiv, int64_t tiles_m, int64_t tiles_n,
-    int64_t super_n, uint32_t* __restrict__ queues, int64_t slots_per_queue, int64_t pitch_tiles, int accumulate) {
+    int64_t super_n, uint32_t* __restrict__ queues, int64_t slots_per_queue, int64_t pitch_tiles, int accumulate,
+    unsigned long long* __restrict__ diag) {
     constexpr int WN = 4, MT = 8, NT = 4, PP = 4;  // 8 waves as 2 x 4, wave tile 128 x 64
     constexpr bool SYM = MODE == SELF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -87,6 +92,7 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+
     const int home = PERSIST ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7) : 0;  // HW_REG_XCC_ID[3:0]
     int helping = 0;  // queues tried so far: home, home+1, ...
   for (;;) {
@@ -115,7 +121,15 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
         if (PERSIST) continue;
         return;
     }
+    unsigned long long st[6];
+    if (DIAG) {
+        st[0] = __builtin_amdgcn_s_memtime();
+        st[1] = __builtin_amdgcn_s_memrealtime();
+    }
     const int64_t row_base = tm * TM, col_base = tn * TN;
+    // K x scale^2 is a power of two for every 4-letter alphabet: the division is then an exact multiplication
+    // (ten instructions fewer per cell of the epilogue); any other divisor is divided by, as np.inner(...)/K is
+    const float rk = (__float_as_uint(kdiv) & 0x007FFFFFu) == 0 && kdiv > 0x1.0p-100f && kdiv < 0x1.0p100f ? 1.0f / kdiv : 0.f;
     const int64_t pitch = pitch_tiles * 64;  // elements per operand row; kt may be a chunk of it
 
     // staging: wave w moves pieces PP*w .. PP*w+PP-1 (8 rows x one 128-byte line each) of the A tile
@@ -175,6 +189,7 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
     int cur = 0;
     stage(0, 0);
     __syncthreads();
+    if (DIAG) st[2] = __builtin_amdgcn_s_memtime();
     for (int64_t t = 0; t < kt; t++) {
         if (t + 1 < kt) stage(cur ^ 1, t + 1);
         const char* base = smem + cur * kStageBytes;
@@ -201,6 +216,7 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
         __syncthreads();
         cur ^= 1;
     }
+    if (DIAG) st[3] = __builtin_amdgcn_s_memtime();
     const bool mirror = MODE == CROSS || (SYM && tm != tn);
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
@@ -210,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
             const int64_t m0 = row_base + wm * 128 + mt * 16 + 4 * q;
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; e++) v[e] = acc[mt][nt][e] / kdiv;
+            for (int e = 0; e < 4; e++) v[e] = rk != 0.f ? acc[mt][nt][e] * rk : acc[mt][nt][e] / kdiv;
             if (SYM && tm == tn) {
                 // diagonal tile: hi*lo and lo*hi enter the accumulator in a different order for
                 // (i,j) and (j,i); keep the upper element and mirror it so r is exactly symmetric
@@ -267,6 +283,20 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
                 }
             }
         }
+    if (DIAG) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tile's stores have left the CU
+        st[4] = __builtin_amdgcn_s_memtime();
+        st[5] = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            const unsigned long long rec = atomicAdd(&diag[0], 1ull);
+            if (rec < (1ull << 16)) {
+                unsigned long long* d = diag + 8 + rec * 8;
+                for (int i = 0; i < 6; i++) d[i] = st[i];
+                d[6] = (unsigned long long)tm << 32 | (unsigned long long)tn;
+                d[7] = (unsigned long long)home << 32 | blockIdx.x;
+            }
+        }
+    }
     if (!PERSIST) return;
   }
 }
@@ -284,7 +314,7 @@ int launch16(skr_ctx* ctx, const T* A, const T* B, const SplitOut& o, int64_t M,
     const int64_t tiles_m = (M + TM - 1) / TM, tiles_n = (N + TN - 1) / TN;
     const int64_t super_m = (tiles_m + 15) / 16, super_n = (tiles_n + 15) / 16;
     const int64_t slots = super_m * super_n * 256;
-    static const bool persist = !(getenv("SEEKR_GEMM_PERSIST") && atoi(getenv("SEEKR_GEMM_PERSIST")) == 0);  // A/B knob
+    const bool persist = !(getenv("SEEKR_GEMM_PERSIST") && atoi(getenv("SEEKR_GEMM_PERSIST")) == 0);  // A/B knob
     // One float32 accumulator per cell is restarted every 4 096 columns: the MFMA adder truncates each
     // add at the accumulator's unit (~0.25 ulp lost per add, measured; `chunk_tiles` = 64, i.e. every 2 048 columns, for
     // operands whose rows are mostly one repeated value: tools/margin_probe.py), a bias that grows with the number
@@ -302,6 +332,16 @@ int launch16(skr_ctx* ctx, const T* A, const T* B, const SplitOut& o, int64_t M,
             uint32_t* queues = ctx->d_flags + 8;  // eight counters, zeroed per launch
             SKR_HIP(hipMemsetAsync(queues, 0, 8 * sizeof(uint32_t), ctx->stream));
             auto kern = pearson_gemm_split16_kernel<T, NPROD, MODE, true>;
+            unsigned long long* diag = nullptr;
+            if (std::is_same<T, _Float16>::value && NPROD == 3 && MODE != CROSS && getenv("SEEKR_GEMM_DIAG") &&
+                atoi(getenv("SEEKR_GEMM_DIAG"))) {
+                // diagnostic build: stamps into the ctx workspace (8 + 8 x 65 536 words), read back by skr_gemm_diag_read
+                void* ws = nullptr;
+                SKR_TRY(skr_ctx_workspace(ctx, (size_t)(8 + 8 * 65536) * 8, &ws));
+                diag = (unsigned long long*)ws;
+                SKR_HIP(hipMemsetAsync(diag, 0, 64, ctx->stream));
+                kern = pearson_gemm_split16_kernel<T, NPROD, (MODE == CROSS ? PLAIN : MODE), true, true>;
+            }
             SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         2 * kStageBytes));
             // A resident workgroup owns its CU outright (8 waves x ~248 VGPRs, 128 KiB LDS): with RCCL traffic
@@ -311,13 +351,14 @@ int launch16(skr_ctx* ctx, const T* A, const T* B, const SplitOut& o, int64_t M,
             const int reserve = reserve_env >= 0 ? reserve_env : (ctx->nranks > 1 ? 8 : 0);
             const unsigned grid = (unsigned)std::max(8, ctx->num_cu - reserve);
             hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 2 * kStageBytes, ctx->stream, Ac, Bc, o.C, o.Ct, M, N, ktc, o.ldc,
-                               o.ldct, K, tiles_m, tiles_n, super_n, queues, slots / 8, kt, accumulate);
+                               o.ldct, K, tiles_m, tiles_n, super_n, queues, slots / 8, kt, accumulate, diag);
         } else {
             auto kern = pearson_gemm_split16_kernel<T, NPROD, MODE, false>;
             SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         2 * kStageBytes));
             hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(512), 2 * kStageBytes, ctx->stream, Ac, Bc, o.C, o.Ct, M, N, ktc,
-                               o.ldc, o.ldct, K, tiles_m, tiles_n, super_n, (uint32_t*)nullptr, (int64_t)0, kt, accumulate);
+                               o.ldc, o.ldct, K, tiles_m, tiles_n, super_n, (uint32_t*)nullptr, (int64_t)0, kt, accumulate,
+                               (unsigned long long*)nullptr);
         }
         SKR_HIP(hipGetLastError());
     }
@@ -354,4 +395,20 @@ int skr_launch_gemm_split(skr_ctx* ctx, int precision, const void* As, const voi
                                            "pearson_gemm_f16x3", chunk_tiles);
         default: return skr_set_error(SKR_ERR_INVALID, "not a split precision: %d", precision);
     }
+}
+
+// Diagnostic build only (SEEKR_GEMM_DIAG=1): copies the stamp records of the last contraction launch to the host.
+// out: [max_records][8] uint64 = {memtime t0, memrealtime t0, memtime k-loop start, memtime k-loop end, memtime end,
+// memrealtime end, tm<<32|tn, xcc<<32|workgroup}; *n_records = records written by the kernel.
+extern "C" int skr_gemm_diag_read(skr_ctx* ctx, unsigned long long* out, int64_t max_records, int64_t* n_records) {
+    SKR_REQUIRE(ctx && out && n_records && max_records >= 0, "NULL argument");
+    SKR_TRY(skr_activate(ctx));
+    SKR_REQUIRE(ctx->ws && ctx->ws_bytes >= (size_t)(8 + 8 * 65536) * 8, "no diagnostic launch has run");
+    SKR_HIP(hipStreamSynchronize(ctx->stream));
+    unsigned long long n = 0;
+    SKR_HIP(hipMemcpy(&n, ctx->ws, 8, hipMemcpyDeviceToHost));
+    *n_records = (int64_t)n;
+    const int64_t take = std::min<int64_t>(std::min<int64_t>((int64_t)n, 65536), max_records);
+    if (take > 0) SKR_HIP(hipMemcpy(out, (char*)ctx->ws + 64, (size_t)take * 64, hipMemcpyDeviceToHost));
+    return SKR_OK;
 }

@@ -1,0 +1,66 @@
+"""In-kernel anatomy of the split-fp16 contraction (diagnostic build, SEEKR_GEMM_DIAG=1): per tile, the
+shader cycles of the k loop and of the epilogue (s_memtime) and the in-kernel clock (delta s_memtime /
+delta s_memrealtime x 100 MHz), after >= 2 s of back-to-back launches on random data
+(MI355X_MICROARCH.md, DVFS give-back item 6).
+
+    python tools/gemm_diag.py [--rows 50000] [--mode self]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+from seekr_amd import _lib  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rows", type=int, default=50000)
+ap.add_argument("--cols", type=int, default=4096)
+ap.add_argument("--mode", default="self", choices=["self", "plain"])
+ap.add_argument("--data", default="counts", choices=["counts", "zeros", "ones"],
+                help="operand values: normalised-count-like (default), all zero, or all one (constant rows standardise to NaN -> use raw fill)")
+args = ap.parse_args()
+ctx = _lib.default_context()
+rng = np.random.default_rng(0)
+op = _lib.Operand(ctx, args.rows, args.cols, _lib.PREC_F16X3)
+for r0 in range(0, args.rows, 8192):
+    nr = min(8192, args.rows - r0)
+    x = np.log2(rng.binomial(1995, 1.0 / 4096, size=(nr, args.cols)).astype(np.float32) * np.float32(0.5) + 1.0)
+    if args.data == "zeros":
+        x[:] = 0
+    d = ctx.from_numpy(x.astype(np.float32))
+    # zeros: rows used as they are (row standardisation of a constant row is 0/0)
+    _lib.operand_fill(ctx, d, op=op.view(r0, nr), precision=_lib.PREC_F16X3, row_standardize=args.data == "counts")
+    d.free()
+b = op
+if args.mode == "plain":
+    b = op.view(0, args.rows)  # a distinct handle: PLAIN mode multiplies every tile
+r = ctx.empty(args.rows, args.rows)
+sym = args.mode == "self"
+t_end = time.time() + 2.0
+n = 0
+while time.time() < t_end:  # warm the chip up to its steady clock
+    _lib.pearson_gemm_op(ctx, op, b, r, symmetric=sym)
+    ctx.sync()
+    n += 1
+os.environ["SEEKR_GEMM_DIAG"] = "1"
+_lib.pearson_gemm_op(ctx, op, b, r, symmetric=sym)
+ctx.sync()
+os.environ.pop("SEEKR_GEMM_DIAG")
+rec = np.zeros((65536, 8), dtype=np.uint64)
+cnt = C.c_int64(0)
+_lib.check(_lib.lib().skr_gemm_diag_read(ctx._h, rec.ctypes.data_as(C.c_void_p), 65536, C.byref(cnt)))
+rec = rec[:min(cnt.value, 65536)].astype(np.float64)
+t0, rt0, k0, k1, t1, rt1 = (rec[:, i] for i in range(6))
+clock = (t1 - t0) / (rt1 - rt0) * 100e6 / 1e9
+print("%d warm-up launches; %d tile records" % (n, len(rec)))
+print("in-kernel clock: median %.3f GHz (5-95 %%: %.3f - %.3f)" % (np.median(clock), *np.percentile(clock, [5, 95])))
+for name, v in (("tile total", t1 - t0), ("prologue (slot + first stage)", k0 - t0), ("k loop", k1 - k0), ("epilogue + store drain", t1 - k1)):
+    print("%-30s median %8.0f cycles = %6.1f us   (5-95 %%: %.0f - %.0f)"
+          % (name, np.median(v), np.median(v) / np.median(clock) / 1e3, *np.percentile(v, [5, 95])))
+kt = (args.cols + 31) // 32
+mfma = kt * 2 * 96 * 16
+print("MFMA cycles per tile and SIMD (2 waves x 96 MFMA x 16 cycles x %d k tiles): %d = %.3f of the k loop, %.3f of the tile"
+      % (kt, mfma, mfma / np.median(k1 - k0), mfma / np.median(t1 - t0)))
