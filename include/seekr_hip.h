@@ -203,6 +203,10 @@ int skr_operand_fill(skr_ctx* ctx, const skr_mat* x, const skr_mat* center, cons
  * width (a receive buffer) with the kind and scale of `like`.                                    */
 int skr_operand_kind(const skr_operand* op, int* kind);
 int skr_operand_adopt_layout(skr_operand* op, const skr_operand* like);
+/* get (set = 0) or set (set != 0, from *value) the "rows are mostly one repeated value" flag that makes the
+ * split contraction restart its accumulators every 2 048 columns; skr_operand_fill computes it from the rows
+ * it sees, a multi-GPU caller all-reduces it so that every shard of a set carries the same value.            */
+int skr_operand_coherent(skr_operand* op, int set, int* value);
 /* r[row0 + i, col0 + j] = <a_i, b_j> / K on prepared operands (same meaning as skr_pearson_gemm) */
 int skr_pearson_gemm_op(skr_ctx* ctx, const skr_operand* a, const skr_operand* b, int symmetric, skr_mat* r,
                         int64_t row0, int64_t col0);

@@ -74,6 +74,7 @@ SIGNATURES = {
     "skr_operand_fill": (_int, [_p, _p, _p, _p, _int, C.c_float, _p, _int, _p, C.POINTER(_int)]),
     "skr_operand_kind": (_int, [_p, C.POINTER(_int)]),
     "skr_operand_adopt_layout": (_int, [_p, _p]),
+    "skr_operand_coherent": (_int, [_p, _int, C.POINTER(_int)]),
     "skr_pearson_gemm_op": (_int, [_p, _p, _p, _int, _p, _i64, _i64]),
     "skr_pearson_gemm_op_mirror": (_int, [_p, _p, _p, _p, _i64, _i64, _p, _i64, _i64]),
     "skr_threshold_zero_diag": (_int, [_p, _p, C.c_float, _i64]),
@@ -332,6 +333,18 @@ class Operand:
         k = _int(0)
         check(lib().skr_operand_kind(self._h, C.byref(k)))
         return k.value
+
+    @property
+    def coherent(self):
+        """True when the rows are mostly one repeated value (the contraction then restarts its accumulators more often)."""
+        v = _int(0)
+        check(lib().skr_operand_coherent(self._h, 0, C.byref(v)))
+        return bool(v.value)
+
+    @coherent.setter
+    def coherent(self, flag):
+        v = _int(1 if flag else 0)
+        check(lib().skr_operand_coherent(self._h, 1, C.byref(v)))
 
     def adopt_layout(self, like):
         """Tag this buffer (a receive buffer) with the storage kind of `like`."""

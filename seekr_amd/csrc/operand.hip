@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void operand_fill_block_kernel(FillArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t K = a.cols, Kp = a.kt * 32, groups = a.kt * 4;
     const bool vec = (K & 7) == 0;
-    bool any_nan = false, overflow = false, outlier = false;
+    bool any_nan = false, overflow = false, outlier = false, coherent = false;
     auto block_sum = [&](float v) -> float {
         v = wave_sum(v);
         if (lane == 0) red[wave] = v;
@@ -284,6 +284,19 @@ __global__ __launch_bounds__(256) void operand_fill_block_kernel(FillArgs a) {
             __syncthreads();
             zmax2 = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
             __syncthreads();
+            // share of the row held by its minimum (see operand_fill_reg_kernel); equal raw values give equal z
+            float vmin = INFINITY;
+            for (int64_t g = tid; g < groups; g += 256)
+                for (int64_t c = g * 8; c < std::min<int64_t>(K, g * 8 + 8); c++) vmin = fminf(vmin, val(c));
+            vmin = -wave_max(-vmin);
+            if (lane == 0) red[wave] = vmin;
+            __syncthreads();
+            vmin = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+            __syncthreads();
+            float same = 0.f;
+            for (int64_t g = tid; g < groups; g += 256)
+                for (int64_t c = g * 8; c < std::min<int64_t>(K, g * 8 + 8); c++) same += (float)(val(c) == vmin);
+            if (block_sum(same) >= 0.85f * (float)K) coherent = true;
         }
         float sq = 0.f;
         for (int64_t g = tid; g < groups; g += 256) {
@@ -323,6 +336,7 @@ __global__ __launch_bounds__(256) void operand_fill_block_kernel(FillArgs a) {
     if (any_nan) atomicOr(&a.flags[1], 1u);
     if (overflow) atomicOr(&a.flags[3], 1u);
     if (outlier) atomicOr(&a.flags[4], 1u);
+    if (coherent) atomicOr(&a.flags[5], 1u);
 }
 
 // Register-resident variant for K = VPL * 256 columns (k = 5: VPL 4, k = 6: VPL 16): a wave keeps
@@ -742,6 +756,16 @@ extern "C" int skr_operand_adopt_layout(skr_operand* op, const skr_operand* like
     op->precision = like->precision;
     op->coherent = like->coherent;
     op->diag_valid = false;
+    return SKR_OK;
+}
+
+/* The "rows are mostly one repeated value" flag of a prepared operand (skr_operand_fill sets it from this rank's
+ * rows): get it, or set it — shards multiplied against each other must agree on it, so a multi-GPU caller
+ * all-reduces the flag and sets the result on its shard and receive buffers. */
+extern "C" int skr_operand_coherent(skr_operand* op, int set, int* value) {
+    SKR_REQUIRE(op && value, "NULL argument");
+    if (set) op->coherent = *value != 0;
+    *value = op->coherent ? 1 : 0;
     return SKR_OK;
 }
 

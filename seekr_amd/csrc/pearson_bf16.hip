@@ -190,8 +190,9 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
     stage(0, 0);
     __syncthreads();
     if (DIAG) st[2] = __builtin_amdgcn_s_memtime();
+    const bool no_dma = DIAG && (diag[1] & 1);  // diagnostic only: k loop without its staging traffic (results meaningless)
     for (int64_t t = 0; t < kt; t++) {
-        if (t + 1 < kt) stage(cur ^ 1, t + 1);
+        if (t + 1 < kt && !no_dma) stage(cur ^ 1, t + 1);
         const char* base = smem + cur * kStageBytes;
         vec8<T> ahi[MT], alo[MT], bhi[NT], blo[NT];
 #pragma unroll
@@ -340,6 +341,7 @@ int launch16(skr_ctx* ctx, const T* A, const T* B, const SplitOut& o, int64_t M,
                 SKR_TRY(skr_ctx_workspace(ctx, (size_t)(8 + 8 * 65536) * 8, &ws));
                 diag = (unsigned long long*)ws;
                 SKR_HIP(hipMemsetAsync(diag, 0, 64, ctx->stream));
+                if (atoi(getenv("SEEKR_GEMM_DIAG")) == 2) SKR_HIP(hipMemsetAsync(diag + 1, 1, 1, ctx->stream));  // flags word = 1: no staging
                 kern = pearson_gemm_split16_kernel<T, NPROD, (MODE == CROSS ? PLAIN : MODE), true, true>;
             }
             SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

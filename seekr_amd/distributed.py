@@ -248,6 +248,13 @@ def sharded_normalize_prepare(engine, comm, x, n_total, log2="Log2.post", mean=T
             if not keep_counts:
                 raise NotImplementedError("a rank fell back to the float32 contraction; re-run with keep_counts=True")
             operand = engine.prepare_f32(x)
+    # "rows are mostly one repeated value" (skr_operand_coherent) decides how often the contraction restarts its
+    # accumulators: a block (g, h) must be treated the same whichever of its two ranks multiplies it, so the flag
+    # is made global (receive buffers adopt it from the local shard in sharded_pearson_*)
+    if comm.size > 1 and hasattr(operand, "coherent"):
+        flag = _any_rank(comm, operand.coherent)
+        if flag != operand.coherent:
+            operand.coherent = flag
     return center, scale, _any_rank(comm, has_nan), operand
 
 

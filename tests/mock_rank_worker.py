@@ -27,7 +27,17 @@ def main():
     packed = _lib.PackedSeqs.from_buffer(ctx, blob, offsets, "AGTC")
     x = _lib.count_per_kb(ctx, packed, k)
     engine = HipEngine(ctx)
-    if raw_mode:  # raw counts straight into Pearson: the shape that needs the fp32 kernel's dynamic range
+    coherent_mode = os.environ.get("MOCK_COHERENT_LAST_RANK") == "1"
+    if coherent_mode:
+        # only the LAST rank holds rows that are mostly one repeated value (tools/margin_probe.py's worst case):
+        # the flag must become global or a cross block would be accumulated differently by its two ranks
+        from coherent_case import coherent_matrix
+        full = coherent_matrix(n_total, x.cols, size)
+        x = ctx.from_numpy(full[lo:hi])
+        mean, std, has_nan, z = sharded_normalize_prepare(engine, comm, x, n_total, "Log2.none", False, False)
+        assert z.kind != 0 and z.coherent, "rank %d: coherent flag not global (kind %d)" % (rank, z.kind)
+        mean = std = ctx.zeros(1, x.cols)
+    elif raw_mode:  # raw counts straight into Pearson: the shape that needs the fp32 kernel's dynamic range
         mean, std, has_nan, z = sharded_normalize_prepare(engine, comm, x, n_total, "Log2.none", False, False)
         assert z.kind == 0, "every rank must have switched to the float32 layout"
         mean = std = ctx.zeros(1, x.cols)

@@ -67,3 +67,23 @@ def test_constructed_worst_case_stays_at_the_bar():
     truth = orc.pearson_f64_truth(x, x)
     err = np.abs(pearson(x, x) - truth)
     assert (err <= 2e-6 + 1e-5 * np.abs(truth)).all(), float((err / (2e-6 + 1e-5 * np.abs(truth))).max())
+
+
+def test_constructed_worst_case_k16384_through_the_block_fill_kernel():
+    """The same construction at K = 16 384 through operand_fill_block_kernel (the k = 7 kernel whenever the normalised
+    counts are kept without device float32 vectors): it must raise the "mostly one repeated value" flag like the
+    register kernels do, and the contraction then stays inside the bar (1.04 x the bar without the flag)."""
+    import numpy as np
+    from coherent_case import coherent_matrix
+    from oracle import seekr_oracle as orc
+    from seekr_amd import _lib
+    ctx = _lib.default_context()
+    x = coherent_matrix(96, 16384, 1)[48:]  # the degenerate half
+    d, keep = ctx.from_numpy(x), ctx.empty(48, 16384)
+    op, _ = _lib.operand_fill(ctx, d, precision=_lib.PREC_F16X3, y=keep)   # y given, no vectors -> block kernel
+    assert op.kind == 2 and op.coherent
+    r = ctx.empty(48, 48)
+    _lib.pearson_gemm_op(ctx, op, op, r, symmetric=True)
+    truth = orc.pearson_f64_truth(x, x)
+    err = np.abs(r.to_numpy() - truth)
+    assert (err <= 2e-6 + 1e-5 * np.abs(truth)).all(), float((err / (2e-6 + 1e-5 * np.abs(truth))).max())

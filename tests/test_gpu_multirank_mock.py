@@ -154,6 +154,35 @@ def test_every_rank_switches_when_one_needs_the_fp32_kernel(mock_lib, tmp_path):
     assert np.allclose(full, orc.pearson(x, x), rtol=1e-5, atol=2e-6)
 
 
+def test_coherent_flag_is_global(mock_lib, tmp_path):
+    """only the last rank holds rows that are mostly one repeated value.  Its flag (skr_operand_coherent)
+    is all-reduced, so every rank restarts the accumulators of every block every 2 048 columns; at K = 16 384 the
+    uncorrected accumulation of a cross block would sit at 1.04 x the bar (tools/margin_probe.py)."""
+    from coherent_case import coherent_matrix
+    from oracle import seekr_oracle as orc
+    size, n_total, cols = 2, 96, 16384
+    env = dict(os.environ, WORLD_SIZE=str(size), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), LOCAL_RANK="0",
+               SEEKR_RCCL_LIB=mock_lib, MOCK_RCCL_ASYNC="1", MOCK_COHERENT_LAST_RANK="1")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mock_rank_worker.py"), str(tmp_path), str(n_total), "600", "7"],
+                              env=dict(env, RANK=str(rank)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for rank in range(size)]
+    for rank, p in enumerate(procs):
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, "rank %d failed:\n%s" % (rank, out.decode()[-3000:])
+    parts = [np.load(str(tmp_path / ("rank%d.npz" % rank))) for rank in range(size)]
+    x = coherent_matrix(n_total, cols, size)
+    truth = orc.pearson_f64_truth(x, x)
+    bar = 2e-6 + 1e-5 * np.abs(truth)
+    full = np.concatenate([p["r"] for p in parts], axis=0)          # row-block layout
+    assert (np.abs(full - truth) <= bar).all(), float((np.abs(full - truth) / bar).max())
+    sym = np.zeros_like(full)
+    for p in parts:
+        for which, br, bc, nr, nc, gr, gc in p["blocks"]:
+            buf = p["r_row"] if which == 0 else p["r_col"]
+            sym[gr:gr + nr, gc:gc + nc] = buf[br:br + nr, bc:bc + nc]
+    assert (np.abs(sym - truth) <= bar).all(), float((np.abs(sym - truth) / bar).max())
+
+
 @pytest.mark.parametrize("n_total,size", [(6, 4), (6, 8), (3, 3), (17, 5)])
 def test_tiny_and_empty_shards(n_total, size, mock_lib, tmp_path):
     """Fewer rows than ranks (empty shards), one row per rank, odd splits: k = 2, i.e. 16 columns and the

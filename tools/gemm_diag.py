@@ -21,6 +21,7 @@ ap.add_argument("--cols", type=int, default=4096)
 ap.add_argument("--mode", default="self", choices=["self", "plain"])
 ap.add_argument("--data", default="counts", choices=["counts", "zeros", "ones"],
                 help="operand values: normalised-count-like (default), all zero, or all one (constant rows standardise to NaN -> use raw fill)")
+ap.add_argument("--no-dma", action="store_true", help="k loop without its LDS-DMA staging (timing experiment; r is garbage)")
 args = ap.parse_args()
 ctx = _lib.default_context()
 rng = np.random.default_rng(0)
@@ -45,7 +46,7 @@ while time.time() < t_end:  # warm the chip up to its steady clock
     _lib.pearson_gemm_op(ctx, op, b, r, symmetric=sym)
     ctx.sync()
     n += 1
-os.environ["SEEKR_GEMM_DIAG"] = "1"
+os.environ["SEEKR_GEMM_DIAG"] = "2" if args.no_dma else "1"
 _lib.pearson_gemm_op(ctx, op, b, r, symmetric=sym)
 ctx.sync()
 os.environ.pop("SEEKR_GEMM_DIAG")
