@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-symmetry", action="store_true",
                     help="compute both triangles of the self-comparison block instead of mirroring one")
+    ap.add_argument("--grouped-shifts", action="store_true",
+                    help="symmetric layout: post all half-ring shifts as one grouped exchange (one receive buffer per shift)")
     ap.add_argument("--layout", default="symmetric", choices=["symmetric", "rowblock"],
                     help="multi-GPU result layout (see module docstring); fp32 / --no-symmetry imply rowblock")
     return ap.parse_args()
@@ -190,16 +192,17 @@ def main():
     r = ctx.zeros(n_loc, n_total)
     r_col = ctx.zeros(n_total, n_loc) if (symmetric_layout and size > 1) else None  # mirrored blocks (h, g)
     max_shard = max(bounds[g + 1] - bounds[g] for g in range(size))
-    recv = [engine.empty_operand(max_shard, n_cols), engine.empty_operand(max_shard, n_cols)] if size > 1 else [None, None]
+    n_recv = max(2, size // 2) if args.grouped_shifts else 2
+    recv = [engine.empty_operand(max_shard, n_cols) for _ in range(n_recv)] if size > 1 else [None, None]
 
     def step():
         _lib.count_per_kb(ctx, packed, k, out=x)
         # column statistics (rank-chained), then ONE pass: normalised counts -> x, standardised rows -> z
         zz = sharded_normalize_prepare(engine, comm, x, n_total, "Log2.post", True, True, keep_counts=True, op=z)[3]
         if symmetric_layout:
-            sharded_pearson_symmetric(engine, comm, zz, bounds, r, r_col, recv)
+            sharded_pearson_symmetric(engine, comm, zz, bounds, r, r_col, recv, grouped=args.grouped_shifts)
         else:
-            sharded_pearson_rowblock(engine, comm, zz, bounds, r, recv)
+            sharded_pearson_rowblock(engine, comm, zz, bounds, r, recv[:2])
 
     for _ in range(args.warmup):
         step()

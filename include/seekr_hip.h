@@ -329,7 +329,8 @@ int skr_comm_barrier(skr_ctx* ctx);
 /* send rows [srow0, srow0+snrows) of `src` to `dst_rank` and receive rows into `dst` from
  * `src_rank` as one grouped RCCL operation on the ctx's communication stream; either side
  * may be skipped with rank < 0.  Completion is tracked per call: the returned ticket can be
- * waited on (once) by the compute stream with skr_comm_wait.                                */
+ * waited on (once) by the compute stream with skr_comm_wait.  ticket == NULL: fire and forget —
+ * the exchange is ordered against later exchanges (same stream), no event is kept for it.    */
 int skr_comm_sendrecv(skr_ctx* ctx, const skr_mat* src, int64_t srow0, int64_t snrows, int dst_rank,
                       skr_mat* dst, int64_t drow0, int64_t dnrows, int src_rank, int64_t* ticket);
 /* all-gather of row shards of unequal size: rank g contributes `shard` (bounds[g+1]-bounds[g]
@@ -338,6 +339,11 @@ int skr_comm_sendrecv(skr_ctx* ctx, const skr_mat* src, int64_t srow0, int64_t s
  * link per peer).  bounds: nranks+1 row offsets, bounds[0] == 0.                              */
 int skr_comm_allgather_rows(skr_ctx* ctx, const skr_mat* shard, skr_mat* full, const int64_t* bounds,
                             int64_t* ticket);
+/* n exchanges (arguments as skr_comm_sendrecv, one entry per exchange) as ONE grouped RCCL
+ * operation: transfers with different peers run on their own xGMI links at once; one ticket.   */
+int skr_comm_exchange(skr_ctx* ctx, int n, const skr_mat* const* src, const int64_t* srow0, const int64_t* snrows,
+                      const int* dst_rank, skr_mat* const* dst, const int64_t* drow0, const int64_t* dnrows,
+                      const int* src_rank, int64_t* ticket);
 int skr_comm_wait(skr_ctx* ctx, int64_t ticket);
 /* all-reduce of a few host doubles (op: 0 = sum, 1 = max, 2 = min)                          */
 int skr_comm_allreduce_f64(skr_ctx* ctx, double* values, int n, int op);

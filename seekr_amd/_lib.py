@@ -100,6 +100,7 @@ SIGNATURES = {
     "skr_comm_barrier": (_int, [_p]),
     "skr_comm_sendrecv": (_int, [_p, _p, _i64, _i64, _int, _p, _i64, _i64, _int, C.POINTER(_i64)]),
     "skr_comm_allgather_rows": (_int, [_p, _p, _p, C.POINTER(_i64), C.POINTER(_i64)]),
+    "skr_comm_exchange": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(_i64)]),
     "skr_comm_wait": (_int, [_p, _i64]),
     "skr_comm_allreduce_f64": (_int, [_p, C.POINTER(C.c_double), _int, _int]),
     "skr_gemm_diag_read": (_int, [_p, _p, _i64, C.POINTER(_i64)]),
@@ -669,10 +670,24 @@ def comm_init(ctx, nranks, rank, uid):
     check(lib().skr_comm_init(ctx._h, int(nranks), int(rank), uid))
 
 
-def comm_sendrecv(ctx, src, srow0, snrows, dst_rank, dst, drow0, dnrows, src_rank):
+def comm_sendrecv(ctx, src, srow0, snrows, dst_rank, dst, drow0, dnrows, src_rank, want_ticket=True):
+    """want_ticket=False: fire and forget (ordered on the communication stream only); returns None."""
     ticket = _i64(-1)
     check(lib().skr_comm_sendrecv(ctx._h, _h(src), int(srow0), int(snrows), int(dst_rank), _h(dst), int(drow0),
-                                  int(dnrows), int(src_rank), C.byref(ticket)))
+                                  int(dnrows), int(src_rank), C.byref(ticket) if want_ticket else None))
+    return ticket.value if want_ticket else None
+
+
+def comm_exchange(ctx, items):
+    """items: [(src, srow0, snrows, dst_rank, dst, drow0, dnrows, src_rank)] posted as ONE grouped RCCL operation
+    (transfers with different peers use their own xGMI links at once); returns one ticket."""
+    n = len(items)
+    mats_s = (_p * n)(*[_h(it[0]) for it in items])
+    mats_d = (_p * n)(*[_h(it[4]) for it in items])
+    i64 = lambda col: (C.c_int64 * n)(*[int(it[col]) for it in items])  # noqa: E731
+    i32 = lambda col: (C.c_int * n)(*[int(it[col]) for it in items])    # noqa: E731
+    ticket = _i64(-1)
+    check(lib().skr_comm_exchange(ctx._h, n, mats_s, i64(1), i64(2), i32(3), mats_d, i64(5), i64(6), i32(7), C.byref(ticket)))
     return ticket.value
 
 

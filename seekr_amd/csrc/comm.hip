@@ -28,9 +28,10 @@ RcclApi g_api;
 
 int load_rccl() {
     if (g_api.handle) return SKR_OK;
-    // SEEKR_RCCL_LIB: test hook — tests/mock_rccl stands in for RCCL so that several ranks can share the
-    // one GPU of a test box (RCCL refuses that); never set in production
-    const char* override_path = getenv("SEEKR_RCCL_LIB");
+    // SEEKR_RCCL_LIB: test hook, honoured only under SEEKR_TEST_HOOKS=1 — tests/mock_rccl stands in for RCCL so that
+    // several ranks can share the one GPU of a test box (RCCL refuses that); never set in production
+    const char* hooks = getenv("SEEKR_TEST_HOOKS");
+    const char* override_path = hooks && atoi(hooks) == 1 ? getenv("SEEKR_RCCL_LIB") : nullptr;
     const char* names[] = {override_path ? override_path : "librccl.so.1", "librccl.so.1", "librccl.so",
                            "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
@@ -64,6 +65,38 @@ int load_rccl() {
         if (r_ != ncclSuccess)                                                                  \
             return skr_set_error(SKR_ERR_COMM, "%s failed: %s", #call, g_api.GetErrorString(r_)); \
     } while (0)
+
+// completion event of what was just enqueued on comm_stream; *ticket (optional) identifies it for skr_comm_wait.
+// With ticket == NULL nothing is recorded: the exchange is ordered on comm_stream only (fire and forget).
+int issue_ticket(skr_ctx* ctx, int64_t* ticket) {
+    if (!ticket) return SKR_OK;
+    int slot;
+    if (!ctx->free_tickets.empty()) {
+        slot = ctx->free_tickets.back();
+        ctx->free_tickets.pop_back();
+    } else {
+        SKR_REQUIRE(ctx->tickets.size() < 65536, "more than 65 536 exchanges are waiting to be waited on");
+        ctx->tickets.emplace_back();
+        slot = (int)ctx->tickets.size() - 1;
+    }
+    skr_ctx::Ticket& t = ctx->tickets[slot];
+    if (!t.ev) SKR_HIP(hipEventCreateWithFlags(&t.ev, hipEventDisableTiming));
+    SKR_HIP(hipEventRecord(t.ev, ctx->comm_stream));
+    t.live = true;
+    t.gen++;
+    *ticket = ((int64_t)t.gen << 16) | slot;
+    return SKR_OK;
+}
+
+// the data being sent was produced on the compute stream: comm_stream waits for what is enqueued there now
+int comm_after_compute(skr_ctx* ctx) {
+    hipEvent_t ready;
+    SKR_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    SKR_HIP(hipEventRecord(ready, ctx->stream));
+    SKR_HIP(hipStreamWaitEvent(ctx->comm_stream, ready, 0));
+    SKR_HIP(hipEventDestroy(ready));
+    return SKR_OK;
+}
 
 int need_comm(skr_ctx* ctx) {
     SKR_REQUIRE(ctx, "ctx is NULL");
@@ -125,12 +158,7 @@ extern "C" int skr_comm_sendrecv(skr_ctx* ctx, const skr_mat* src, int64_t srow0
         SKR_REQUIRE(src_rank < ctx->nranks, "src_rank out of range");
     }
     ncclComm_t comm = (ncclComm_t)ctx->comm;
-    // the data being sent was produced on the compute stream
-    hipEvent_t ready;
-    SKR_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
-    SKR_HIP(hipEventRecord(ready, ctx->stream));
-    SKR_HIP(hipStreamWaitEvent(ctx->comm_stream, ready, 0));
-    SKR_HIP(hipEventDestroy(ready));
+    SKR_TRY(comm_after_compute(ctx));
     SKR_NCCL(g_api.GroupStart());
     if (do_send) {
         const size_t rb = (size_t)src->cols * src->elem();
@@ -143,12 +171,44 @@ extern "C" int skr_comm_sendrecv(skr_ctx* ctx, const skr_mat* src, int64_t srow0
                             ctx->comm_stream));
     }
     SKR_NCCL(g_api.GroupEnd());
-    hipEvent_t done;
-    SKR_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
-    SKR_HIP(hipEventRecord(done, ctx->comm_stream));
-    ctx->tickets.push_back(done);
-    if (ticket) *ticket = (int64_t)ctx->tickets.size() - 1;
-    return SKR_OK;
+    return issue_ticket(ctx, ticket);
+}
+
+// Several exchanges as ONE grouped RCCL operation: xGMI is point-to-point, so transfers to / from different peers
+// run on different links at once (the half-ring posts all its shifts this way when it has the receive buffers).
+extern "C" int skr_comm_exchange(skr_ctx* ctx, int n, const skr_mat* const* src, const int64_t* srow0, const int64_t* snrows,
+                                 const int* dst_rank, skr_mat* const* dst, const int64_t* drow0, const int64_t* dnrows,
+                                 const int* src_rank, int64_t* ticket) {
+    SKR_TRY(need_comm(ctx));
+    SKR_REQUIRE(n >= 0 && n <= 64 && (n == 0 || (src && srow0 && snrows && dst_rank && dst && drow0 && dnrows && src_rank)),
+                "bad exchange list");
+    for (int i = 0; i < n; i++) {
+        if (dst_rank[i] >= 0 && snrows[i] > 0) {
+            SKR_REQUIRE(src[i] && src[i]->ctx == ctx && srow0[i] >= 0 && srow0[i] + snrows[i] <= src[i]->rows &&
+                            dst_rank[i] < ctx->nranks, "exchange %d: bad send", i);
+        }
+        if (src_rank[i] >= 0 && dnrows[i] > 0) {
+            SKR_REQUIRE(dst[i] && dst[i]->ctx == ctx && drow0[i] >= 0 && drow0[i] + dnrows[i] <= dst[i]->rows &&
+                            src_rank[i] < ctx->nranks, "exchange %d: bad receive", i);
+        }
+    }
+    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    SKR_TRY(comm_after_compute(ctx));
+    SKR_NCCL(g_api.GroupStart());
+    for (int i = 0; i < n; i++) {
+        if (dst_rank[i] >= 0 && snrows[i] > 0) {
+            const size_t rb = (size_t)src[i]->cols * src[i]->elem();
+            SKR_NCCL(g_api.Send((const char*)src[i]->data + (size_t)srow0[i] * rb, (size_t)snrows[i] * rb, ncclUint8, dst_rank[i],
+                                comm, ctx->comm_stream));
+        }
+        if (src_rank[i] >= 0 && dnrows[i] > 0) {
+            const size_t rb = (size_t)dst[i]->cols * dst[i]->elem();
+            SKR_NCCL(g_api.Recv((char*)dst[i]->data + (size_t)drow0[i] * rb, (size_t)dnrows[i] * rb, ncclUint8, src_rank[i], comm,
+                                ctx->comm_stream));
+        }
+    }
+    SKR_NCCL(g_api.GroupEnd());
+    return issue_ticket(ctx, ticket);
 }
 
 // All-gather of row shards of unequal size: rank g owns rows [bounds[g], bounds[g+1]) of `full`.
@@ -167,11 +227,7 @@ extern "C" int skr_comm_allgather_rows(skr_ctx* ctx, const skr_mat* shard, skr_m
                 (long long)(bounds[me + 1] - bounds[me]));
     ncclComm_t comm = (ncclComm_t)ctx->comm;
     const size_t rb = (size_t)full->cols * full->elem();
-    hipEvent_t ready;
-    SKR_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
-    SKR_HIP(hipEventRecord(ready, ctx->stream));
-    SKR_HIP(hipStreamWaitEvent(ctx->comm_stream, ready, 0));
-    SKR_HIP(hipEventDestroy(ready));
+    SKR_TRY(comm_after_compute(ctx));
     if (shard->rows && shard->data != (char*)full->data + (size_t)bounds[me] * rb)
         SKR_HIP(hipMemcpyAsync((char*)full->data + (size_t)bounds[me] * rb, shard->data, (size_t)shard->rows * rb,
                                hipMemcpyDeviceToDevice, ctx->comm_stream));
@@ -185,21 +241,18 @@ extern "C" int skr_comm_allgather_rows(skr_ctx* ctx, const skr_mat* shard, skr_m
                                 ctx->comm_stream));
     }
     SKR_NCCL(g_api.GroupEnd());
-    hipEvent_t done;
-    SKR_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
-    SKR_HIP(hipEventRecord(done, ctx->comm_stream));
-    ctx->tickets.push_back(done);
-    if (ticket) *ticket = (int64_t)ctx->tickets.size() - 1;
-    return SKR_OK;
+    return issue_ticket(ctx, ticket);
 }
 
 extern "C" int skr_comm_wait(skr_ctx* ctx, int64_t ticket) {
     SKR_TRY(need_comm(ctx));
-    SKR_REQUIRE(ticket >= 0 && ticket < (int64_t)ctx->tickets.size() && ctx->tickets[ticket], "unknown ticket");
-    SKR_HIP(hipStreamWaitEvent(ctx->stream, ctx->tickets[ticket], 0));
-    // a ticket is waited on once: the dependency is now in the compute stream, release the event
-    (void)hipEventDestroy(ctx->tickets[ticket]);
-    ctx->tickets[ticket] = nullptr;
+    const int64_t slot = ticket & 0xFFFF;
+    SKR_REQUIRE(ticket >= 0 && slot < (int64_t)ctx->tickets.size() && ctx->tickets[slot].live &&
+                    (int64_t)ctx->tickets[slot].gen == (ticket >> 16), "unknown ticket (each ticket is waited on once)");
+    SKR_HIP(hipStreamWaitEvent(ctx->stream, ctx->tickets[slot].ev, 0));
+    // a ticket is waited on once: the dependency is now in the compute stream; the slot and its event are recycled
+    ctx->tickets[slot].live = false;
+    ctx->free_tickets.push_back((int)slot);
     return SKR_OK;
 }
 

@@ -32,7 +32,15 @@ struct skr_ctx {
     // RCCL (loaded lazily with dlopen; see comm.cpp)
     void* comm = nullptr;
     int nranks = 1, rank = 0;
-    std::vector<hipEvent_t> tickets;
+    // tickets: completion events of exchanges on comm_stream.  Slots are recycled (the events too), so a long-running
+    // loop neither leaks events nor grows the table; a ticket id carries the slot's generation.
+    struct Ticket {
+        hipEvent_t ev = nullptr;
+        uint32_t gen = 0;
+        bool live = false;
+    };
+    std::vector<Ticket> tickets;
+    std::vector<int> free_tickets;
 };
 
 struct skr_mat {

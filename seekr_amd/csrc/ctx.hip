@@ -75,7 +75,7 @@ extern "C" int skr_ctx_destroy(skr_ctx* ctx) {
         (void)hipEventDestroy(p.second);
     }
     for (auto& t : ctx->tickets)
-        if (t) (void)hipEventDestroy(t);
+        if (t.ev) (void)hipEventDestroy(t.ev);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);

@@ -118,9 +118,10 @@ class RcclComm:
     def __init__(self, ctx, rank, size):
         self.ctx, self.rank, self.size = ctx, rank, size
 
-    def send_vec(self, v, dst):
-        """Returns a ticket: the compute stream must wait on it before it overwrites `v`."""
-        return _lib.comm_sendrecv(self.ctx, v, 0, 1, dst, None, 0, 0, -1)
+    def send_vec(self, v, dst, want_ticket=True):
+        """Returns a ticket: the compute stream must wait on it before it overwrites `v`.  want_ticket=False: fire
+        and forget (no event kept; later exchanges on the communication stream are still ordered behind it)."""
+        return _lib.comm_sendrecv(self.ctx, v, 0, 1, dst, None, 0, 0, -1, want_ticket=want_ticket)
 
     def recv_vec(self, v, src):
         t = _lib.comm_sendrecv(self.ctx, None, 0, 0, -1, v, 0, 1, src)
@@ -132,6 +133,12 @@ class RcclComm:
     def shift(self, send, dst, recv, recv_rows, src):
         """send: an Operand (all rows go to dst); recv: an Operand buffer (rows [0, recv_rows) filled from src)."""
         return _lib.comm_sendrecv(self.ctx, send.as_matrix(), 0, send.rows, dst, recv.as_matrix(), 0, recv_rows, src)
+
+    def shift_all(self, shifts):
+        """shifts: [(send, dst, recv, recv_rows, src)] as ONE grouped exchange: every peer's link carries traffic at
+        once.  Returns one ticket for all of them."""
+        return _lib.comm_exchange(self.ctx, [(s.as_matrix(), 0, s.rows, dst, r.as_matrix(), 0, rows, src)
+                                             for s, dst, r, rows, src in shifts])
 
     def allgather_rows(self, shard, full, bounds):
         """shard: this rank's Operand; full: an Operand of bounds[-1] rows; returns a ticket."""
@@ -159,6 +166,13 @@ class SingleComm:
 
 
 # ------------------------------------------------------------------------------ steps -------
+def _send_vec(comm, v, dst, want_ticket):
+    try:
+        return comm.send_vec(v, dst, want_ticket=want_ticket)
+    except TypeError:  # a communicator without the option (the gloo one of the CPU tests)
+        return comm.send_vec(v, dst)
+
+
 def _chain_colsum(engine, comm, x, n_cols, center=None, center2=None, square=False):
     """Sequential float32 column sums over ALL ranks' rows in global row order; the finished
     sums end on every rank."""
@@ -169,12 +183,13 @@ def _chain_colsum(engine, comm, x, n_cols, center=None, center2=None, square=Fal
     if comm.size > 1:
         last = comm.size - 1
         if comm.rank < last:
-            comm.send_vec(acc, comm.rank + 1)
+            # no ticket: the receive below is ordered behind this send on the communication stream
+            _send_vec(comm, acc, comm.rank + 1, want_ticket=False)
             comm.recv_vec(acc, last)
         else:
             ticket = None
-            for g in range(last):
-                ticket = comm.send_vec(acc, g)
+            for g in range(last):  # one stream, in order: the last send's ticket covers them all
+                ticket = _send_vec(comm, acc, g, want_ticket=g == last - 1)
             # the caller goes on to rescale `acc` in place (finish) on the compute stream, while these
             # sends sit on the communication stream: without this wait the peers could read the
             # rescaled vector (caught by the asynchronous mode of tests/mock_rccl)
@@ -324,34 +339,48 @@ def owned_blocks(size, rank, bounds):
     return out
 
 
-def sharded_pearson_symmetric(engine, comm, z, bounds, r_row, r_col, recv_bufs):
+def sharded_pearson_symmetric(engine, comm, z, bounds, r_row, r_col, recv_bufs, grouped=False):
     """Self-comparison with every unordered pair of shards multiplied once (module docstring).
 
     `z`: this rank's prepared operand; `r_row` [n_g, N] and `r_col` [N, n_g]: float32 result
-    buffers (r_col may be None on one GPU); `recv_bufs`: two operand buffers of at least
-    max-shard rows.  Shift s sends our shard to rank-s and receives rank+s's; its GEMM overlaps
-    shift s+1.  Returns owned_blocks(size, rank, bounds)."""
+    buffers (r_col may be None on one GPU); `recv_bufs`: operand buffers of at least max-shard rows.
+    With two buffers shift s sends our shard to rank-s and receives rank+s's, its GEMM overlapping shift
+    s+1.  `grouped` (needs one receive buffer per shift): ALL shifts are posted up front as one grouped
+    exchange, so every peer's xGMI link carries traffic at once and no later shift can be exposed behind a
+    GEMM that finished early; the first cross block then waits for the whole group.
+    Returns owned_blocks(size, rank, bounds)."""
     size, rank = comm.size, comm.rank
     plan = half_ring_plan(size, rank, bounds)
     tickets = {}
     if hasattr(engine, "adopt_layout"):
         for buf in recv_bufs:
             engine.adopt_layout(buf, z)
+    can_group = hasattr(comm, "shift_all") and len(recv_bufs) >= len(plan) > 1
+    grouped = bool(grouped) and can_group
+    buf_of = (lambda i: recv_bufs[i]) if grouped else (lambda i: recv_bufs[i % 2])
 
     def post(i):
         s, peer = plan[i][0], plan[i][1]
-        tickets[i] = comm.shift(z, (rank - s) % size, recv_bufs[i % 2], bounds[peer + 1] - bounds[peer], peer)
+        tickets[i] = comm.shift(z, (rank - s) % size, buf_of(i), bounds[peer + 1] - bounds[peer], peer)
 
-    if plan:
+    group_ticket = None
+    if grouped:
+        group_ticket = comm.shift_all([(z, (rank - s) % size, buf_of(i), bounds[peer + 1] - bounds[peer], peer)
+                                       for i, (s, peer, *_rest) in enumerate(plan)])
+    elif plan:
         post(0)
     engine.gemm(z, z, r_row, bounds[rank], symmetric=True)
     for i, (_, peer, a0, an, b0, bn) in enumerate(plan):
-        comm.wait(tickets.pop(i))
-        if i + 1 < len(plan):
-            post(i + 1)
+        if grouped:
+            if i == 0:
+                comm.wait(group_ticket)
+        else:
+            comm.wait(tickets.pop(i))
+            if i + 1 < len(plan):
+                post(i + 1)
         if an and bn:
             a = z if an == engine.rows(z) else engine.view(z, a0, an)
-            b = engine.view(recv_bufs[i % 2], b0, bn)
+            b = engine.view(buf_of(i), b0, bn)
             p0 = bounds[peer] + b0
             engine.gemm_mirror(a, b, r_row, a0, p0, r_col, p0, a0)
     return owned_blocks(size, rank, bounds)

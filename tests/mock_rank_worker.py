@@ -44,9 +44,11 @@ def main():
     else:
         mean, std, has_nan, z = sharded_normalize_prepare(engine, comm, x, n_total, "Log2.post", True, True)
     max_shard = max(bounds[g + 1] - bounds[g] for g in range(size))
-    recv = [engine.empty_operand(max_shard, x.cols) for _ in range(2)]
+    grouped = os.environ.get("MOCK_GROUPED_SHIFTS") == "1"  # one receive buffer per shift, all shifts in one ncclGroup
+    recv = [engine.empty_operand(max_shard, x.cols) for _ in range(max(2, size // 2) if grouped else 2)]
     r_row, r_col = ctx.zeros(hi - lo, n_total), ctx.zeros(n_total, hi - lo)
-    blocks = sharded_pearson_symmetric(engine, comm, z, bounds, r_row, r_col, recv)
+    blocks = sharded_pearson_symmetric(engine, comm, z, bounds, r_row, r_col, recv, grouped=grouped)
+    recv = recv[:2]
     r = ctx.zeros(hi - lo, n_total)
     sharded_pearson_rowblock(engine, comm, z, bounds, r, recv)
     e = sharded_pearson_edges(engine, comm, z, bounds, 0.05, stripe_rows=128, upper_only=True)

@@ -66,11 +66,19 @@ def test_ranks_on_one_gpu_equal_single_gpu(size, asynchronous, mock_lib, single,
     check_ranks(size, asynchronous, mock_lib, single, tmp_path)
 
 
-def check_ranks(size, asynchronous, mock_lib, single, tmp_path):
+@pytest.mark.parametrize("size", [4, 5, 8])
+def test_all_shifts_posted_as_one_group(size, mock_lib, single, tmp_path):
+    """sharded_pearson_symmetric(grouped=True): every shift of the half ring in ONE ncclGroup (skr_comm_exchange), one
+    receive buffer per shift — all xGMI links at once on real hardware; here the asynchronous mock checks the data."""
+    check_ranks(size, 1, mock_lib, single, tmp_path, extra_env={"MOCK_GROUPED_SHIFTS": "1"})
+
+
+def check_ranks(size, asynchronous, mock_lib, single, tmp_path, extra_env=None):
     """asynchronous = 1: the mock enqueues its copies and waits on the communication stream like RCCL's
     kernels, so the product's event / ticket waits between the two streams are what keeps the data right."""
     env = dict(os.environ, WORLD_SIZE=str(size), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), LOCAL_RANK="0",
-               SEEKR_RCCL_LIB=mock_lib, MOCK_RCCL_ASYNC=str(asynchronous))
+               SEEKR_TEST_HOOKS="1", SEEKR_RCCL_LIB=mock_lib, MOCK_RCCL_ASYNC=str(asynchronous))
+    env.update(extra_env or {})
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mock_rank_worker.py"), str(tmp_path),
                                str(single["n_total"]), str(single["length"]), str(single["k"])],
                               env=dict(env, RANK=str(rank)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
@@ -115,7 +123,7 @@ def test_bench_under_torchrun_with_two_ranks(mock_lib):
     """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one process per
     rank), both ranks on device 0 over the mock transport: one JSON line from rank 0, whole-job value."""
     import json
-    env = dict(os.environ, SEEKR_RCCL_LIB=mock_lib, SEEKR_FORCE_DEVICE="0", MOCK_RCCL_ASYNC="1")
+    env = dict(os.environ, SEEKR_TEST_HOOKS="1", SEEKR_RCCL_LIB=mock_lib, SEEKR_FORCE_DEVICE="0", MOCK_RCCL_ASYNC="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--rows", "6000", "--length", "500"]
@@ -137,7 +145,7 @@ def test_every_rank_switches_when_one_needs_the_fp32_kernel(mock_lib, tmp_path):
     the pair's r is 1 to float32 accuracy (the split contraction alone would give 1 - 2.4e-4)."""
     size, n_total, length, k = 3, 700, 600, 6
     env = dict(os.environ, WORLD_SIZE=str(size), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), LOCAL_RANK="0",
-               SEEKR_RCCL_LIB=mock_lib, MOCK_RCCL_ASYNC="1", MOCK_RAW_HOMOPOLYMERS="1")
+               SEEKR_TEST_HOOKS="1", SEEKR_RCCL_LIB=mock_lib, MOCK_RCCL_ASYNC="1", MOCK_RAW_HOMOPOLYMERS="1")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mock_rank_worker.py"), str(tmp_path), str(n_total), str(length),
                                str(k)], env=dict(env, RANK=str(rank)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for rank in range(size)]
@@ -162,7 +170,7 @@ def test_coherent_flag_is_global(mock_lib, tmp_path):
     from oracle import seekr_oracle as orc
     size, n_total, cols = 2, 96, 16384
     env = dict(os.environ, WORLD_SIZE=str(size), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), LOCAL_RANK="0",
-               SEEKR_RCCL_LIB=mock_lib, MOCK_RCCL_ASYNC="1", MOCK_COHERENT_LAST_RANK="1")
+               SEEKR_TEST_HOOKS="1", SEEKR_RCCL_LIB=mock_lib, MOCK_RCCL_ASYNC="1", MOCK_COHERENT_LAST_RANK="1")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mock_rank_worker.py"), str(tmp_path), str(n_total), "600", "7"],
                               env=dict(env, RANK=str(rank)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for rank in range(size)]

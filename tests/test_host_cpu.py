@@ -1,6 +1,7 @@
 """CPU-side checks: the C-ABI library loads and exports every declared symbol, the product
 fails loudly without a GPU, and the host mirrors (Reader, CLI parsers) behave like the oracle."""
 import os
+import subprocess
 import re
 import sys
 
@@ -138,3 +139,15 @@ def test_header_is_plain_c_and_a_c_program_links(tmp_path):
     fa.write_text(">a\nACGTACGT\n>b\nTTTTGGGA\n")
     out = subprocess.run([exe, str(fa), "2", str(tmp_path / "c.npy"), str(tmp_path / "r.npy")], capture_output=True, text=True)
     assert out.returncode == 3 and "skr_ctx_create" in out.stderr  # 1 + |SKR_ERR_HIP|
+
+
+def test_test_hooks_are_off_without_the_opt_in():
+    """SEEKR_RCCL_LIB / SEEKR_FORCE_DEVICE are honoured only under SEEKR_TEST_HOOKS=1."""
+    code = ("import os; from seekr_amd import launch; os.environ['RANK']='1'; os.environ['LOCAL_RANK']='5';"
+            "print(launch.world()[2])")
+    env = dict(os.environ, SEEKR_FORCE_DEVICE="0", PYTHONPATH=ROOT)
+    env.pop("SEEKR_TEST_HOOKS", None)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.stdout.strip() == "5", out.stdout + out.stderr
+    out = subprocess.run([sys.executable, "-c", code], env=dict(env, SEEKR_TEST_HOOKS="1"), capture_output=True, text=True, timeout=120)
+    assert out.stdout.strip() == "0", out.stdout + out.stderr
