@@ -233,6 +233,12 @@ int skr_gather_f32(skr_ctx* ctx, const skr_mat* src, const int64_t* idx_host, in
 /* p[i,j] = float32(count(bg > r[i,j]) / total_len) (find_pval.py:158-164); sorted_bg: the
  * background values ascending with NaNs removed, total_len: len(fitres) including NaNs.    */
 int skr_empirical_pvalues(skr_ctx* ctx, const skr_mat* r, const skr_mat* sorted_bg, int64_t total_len, skr_mat* p);
+/* p[i,j] = float32(1 - dist(*params).cdf(r[i,j])), find_pval.py:118-133 with the scipy.stats distribution that
+ * find_dist fitted: dist_name one of cauchy, chi2, expon, exponpow, gamma, lognorm, norm, pareto, rayleigh,
+ * uniform (find_dist.py:96-98); params = shape parameter (where the distribution has one), loc, scale — the
+ * tuple find_dist returns.  Evaluated in float64 like scipy; other names: SKR_ERR_UNSUPPORTED.                */
+int skr_parametric_pvalues(skr_ctx* ctx, const skr_mat* r, const char* dist_name, const double* params, int n_params,
+                           skr_mat* p);
 
 /* The non-zero cells that kmer_leiden.py:94-96 leaves in a block of r, as an edge list and
  * without writing the zeros: cells of r[0:nrows, col_begin:col_end] with !(v < cutoff) (NaN

@@ -58,6 +58,30 @@ def empirical_pvalues(r, fitres):
     return p
 
 
+def parametric_pvalues(r, dist_name, params):
+    """Device matrix p = float32(1 - scipy.stats.<dist_name>(*params).cdf(r)) — find_pval's branch for a fitted
+    distribution (find_pval.py:118-133); `params` is the tuple find_dist returns (shapes..., loc, scale).
+    NotImplementedError for distributions outside find_dist's common10 list."""
+    ctx = r.ctx
+    vals = [float(v) for v in params]
+    arr = (C.c_double * max(1, len(vals)))(*vals)
+    p = ctx.empty(r.rows, r.cols)
+    _lib.check(_lib.lib().skr_parametric_pvalues(ctx._h, r._h, dist_name.encode(), arr, len(vals), p._h))
+    return p
+
+
+def pvalues_host(sim, fitres, bestfit=1):
+    """find_pval's p-value step for a host float32 `sim`: `fitres` is find_dist's output — a list of
+    (distribution name, deviance, parameters) (the `bestfit`-th entry is used, find_pval.py:116-121) or a 1-D array of
+    background similarities (:158-164).  Returns a host float32 matrix."""
+    sim = np.ascontiguousarray(sim, dtype=np.float32)
+    if isinstance(fitres, np.ndarray):
+        return empirical_pvalues_host(sim, fitres)
+    name, _, params = fitres[bestfit - 1]
+    ctx = _lib.default_context()
+    return parametric_pvalues(ctx.from_numpy(sim), name, params).to_numpy()
+
+
 def empirical_pvalues_host(sim, fitres):
     """find_pval's numpy-array branch for a host float32 `sim`; returns a host float32 matrix."""
     sim = np.ascontiguousarray(sim, dtype=np.float32)

@@ -41,6 +41,15 @@ struct skr_ctx {
     };
     std::vector<Ticket> tickets;
     std::vector<int> free_tickets;
+    // small device blocks (statistic vectors, a few KiB) handed back by skr_mat_free and reused by skr_mat_create:
+    // no hipFree / hipMalloc, so no host synchronisation per step.  `comm_done` orders the next user (compute stream)
+    // behind anything the communication stream may still read from the block.
+    struct SmallBlock {
+        void* p = nullptr;
+        size_t bytes = 0;
+        hipEvent_t comm_done = nullptr;
+    };
+    std::vector<SmallBlock> small_blocks;
 };
 
 struct skr_mat {

@@ -5,6 +5,7 @@
 // All three are streaming passes over r in HBM (HBM-bound); keeping them on the device avoids
 // moving an N x N matrix over PCIe just to reduce it.
 #include <algorithm>
+#include <cstring>
 
 #include "common.hpp"
 
@@ -244,6 +245,78 @@ unsigned grid_for(const skr_ctx* ctx, int64_t items) {
     return (unsigned)std::max<int64_t>(1, std::min<int64_t>((items + 255) / 256, (int64_t)ctx->num_cu * 8));
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Parametric p-values (find_pval.py:118-133): p[i,j] = 1 - dist(*params).cdf(sim[i,j]) for the scipy.stats
+// distribution find_dist fitted (find_dist.py:96-98, the `common10` list).  scipy evaluates the cdf of a float32
+// argument in float64, `1 - cdf` in float64, and the assignment into np.zeros_like(sim) rounds to float32: the
+// kernel does the same, one cell per thread.  params = shape parameters..., loc, scale as scipy orders them.
+// ---------------------------------------------------------------------------------------
+enum { DIST_CAUCHY = 0, DIST_CHI2, DIST_EXPON, DIST_EXPONPOW, DIST_GAMMA, DIST_LOGNORM, DIST_NORM, DIST_PARETO, DIST_RAYLEIGH,
+       DIST_UNIFORM, DIST_COUNT };
+
+// regularised lower incomplete gamma P(a, x), float64: series for x < a + 1, Lentz continued fraction for Q otherwise
+// (Abramowitz & Stegun 6.5.29 / 6.5.31; both converge to ~1e-16 within a few hundred terms for the shapes a fit returns)
+__device__ double gamma_p(double a, double x) {
+    if (!(x > 0.0)) return 0.0;
+    if (isinf(x)) return 1.0;
+    const double lg = lgamma(a);
+    if (x < a + 1.0) {
+        double ap = a, del = 1.0 / a, sum = del;
+        for (int n = 0; n < 2000; n++) {
+            ap += 1.0;
+            del *= x / ap;
+            sum += del;
+            if (fabs(del) < fabs(sum) * 1e-17) break;
+        }
+        return sum * exp(-x + a * log(x) - lg);
+    }
+    const double tiny = 1e-300;
+    double b = x + 1.0 - a, c = 1.0 / tiny, d = 1.0 / b, h = d;
+    for (int i = 1; i < 2000; i++) {
+        const double an = -(double)i * ((double)i - a);
+        b += 2.0;
+        d = an * d + b;
+        if (fabs(d) < tiny) d = tiny;
+        c = b + an / c;
+        if (fabs(c) < tiny) c = tiny;
+        d = 1.0 / d;
+        const double del = d * c;
+        h *= del;
+        if (fabs(del - 1.0) < 1e-16) break;
+    }
+    return 1.0 - exp(-x + a * log(x) - lg) * h;
+}
+
+struct DistParams {
+    int dist;
+    double shape, loc, scale;
+};
+
+__device__ __forceinline__ double dist_cdf(const DistParams& d, double x) {
+    const double z = (x - d.loc) / d.scale;
+    switch (d.dist) {
+        case DIST_CAUCHY: return 0.5 + atan(z) / 3.14159265358979323846;
+        case DIST_CHI2: return z > 0.0 ? gamma_p(0.5 * d.shape, 0.5 * z) : 0.0;
+        case DIST_EXPON: return z > 0.0 ? -expm1(-z) : 0.0;
+        case DIST_EXPONPOW: return z > 0.0 ? -expm1(-expm1(pow(z, d.shape))) : 0.0;
+        case DIST_GAMMA: return z > 0.0 ? gamma_p(d.shape, z) : 0.0;
+        case DIST_LOGNORM: return z > 0.0 ? 0.5 * erfc(-(log(z) / d.shape) * 0.70710678118654752440) : 0.0;
+        case DIST_NORM: return 0.5 * erfc(-z * 0.70710678118654752440);
+        case DIST_PARETO: return z >= 1.0 ? 1.0 - pow(z, -d.shape) : 0.0;
+        case DIST_RAYLEIGH: return z > 0.0 ? -expm1(-0.5 * z * z) : 0.0;
+        default: return z <= 0.0 ? 0.0 : (z >= 1.0 ? 1.0 : z);  // uniform
+    }
+}
+
+__global__ __launch_bounds__(256) void parametric_p_kernel(const float* __restrict__ r, int64_t cells, DistParams d,
+                                                           float* __restrict__ p) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += (int64_t)gridDim.x * blockDim.x) {
+        const double x = (double)r[i];
+        p[i] = x != x ? NAN : (float)(1.0 - dist_cdf(d, x));  // cdf(nan) is nan in scipy
+    }
+}
+
 }  // namespace
 
 extern "C" int skr_threshold_zero_diag(skr_ctx* ctx, skr_mat* r, float cutoff, int64_t diag_col0) {
@@ -375,6 +448,42 @@ extern "C" int skr_topk_rows(skr_ctx* ctx, const skr_mat* r, int64_t nrows, int6
     hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)std::min<int64_t>(nrows, (int64_t)ctx->num_cu * 16)), dim3(256), 0,
                        ctx->stream, (const float*)r->data, r->cols, nrows, col_begin, col_end, row_global0, col_global0, k,
                        (uint32_t*)out_idx->data, (float*)out_val->data);
+    SKR_HIP(hipGetLastError());
+    return SKR_OK;
+}
+
+extern "C" int skr_parametric_pvalues(skr_ctx* ctx, const skr_mat* r, const char* dist_name, const double* params, int n_params,
+                                      skr_mat* p) {
+    SKR_REQUIRE(ctx && r && dist_name && p, "NULL argument");
+    SKR_REQUIRE(r->ctx == ctx && p->ctx == ctx, "foreign ctx");
+    SKR_REQUIRE(r->dtype == SKR_F32 && p->dtype == SKR_F32, "float32 only");
+    SKR_REQUIRE(p->rows == r->rows && p->cols == r->cols, "p must have r's shape");
+    static const struct { const char* name; int code; int shapes; } kDists[] = {
+        {"cauchy", DIST_CAUCHY, 0}, {"chi2", DIST_CHI2, 1}, {"expon", DIST_EXPON, 0}, {"exponpow", DIST_EXPONPOW, 1},
+        {"gamma", DIST_GAMMA, 1}, {"lognorm", DIST_LOGNORM, 1}, {"norm", DIST_NORM, 0}, {"pareto", DIST_PARETO, 1},
+        {"rayleigh", DIST_RAYLEIGH, 0}, {"uniform", DIST_UNIFORM, 0}};
+    DistParams d{-1, 0.0, 0.0, 1.0};
+    for (const auto& k : kDists) {
+        if (strcmp(k.name, dist_name) != 0) continue;
+        // scipy: dist(*shapes, loc=0, scale=1); find_dist's fit returns all of them
+        SKR_REQUIRE(n_params >= k.shapes && n_params <= k.shapes + 2 && (n_params == 0 || params),
+                    "%s takes %d shape parameter(s) plus loc and scale, got %d values", dist_name, k.shapes, n_params);
+        d.dist = k.code;
+        if (k.shapes) d.shape = params[0];
+        if (n_params > k.shapes) d.loc = params[k.shapes];
+        if (n_params > k.shapes + 1) d.scale = params[k.shapes + 1];
+    }
+    if (d.dist < 0)
+        return skr_set_error(SKR_ERR_UNSUPPORTED,
+                             "distribution '%s' has no device cdf (available: cauchy, chi2, expon, exponpow, gamma, lognorm, "
+                             "norm, pareto, rayleigh, uniform — find_dist's common10 list)", dist_name);
+    SKR_REQUIRE(d.scale > 0.0, "scale must be positive");
+    SKR_TRY(skr_activate(ctx));
+    const int64_t cells = r->rows * r->cols;
+    if (cells == 0) return SKR_OK;
+    SkrProfScope prof(ctx, "parametric_pvalues");
+    hipLaunchKernelGGL(parametric_p_kernel, dim3(grid_for(ctx, cells)), dim3(256), 0, ctx->stream, (const float*)r->data, cells, d,
+                       (float*)p->data);
     SKR_HIP(hipGetLastError());
     return SKR_OK;
 }

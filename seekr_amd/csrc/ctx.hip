@@ -76,6 +76,10 @@ extern "C" int skr_ctx_destroy(skr_ctx* ctx) {
     }
     for (auto& t : ctx->tickets)
         if (t.ev) (void)hipEventDestroy(t.ev);
+    for (auto& b : ctx->small_blocks) {
+        if (b.comm_done) (void)hipEventDestroy(b.comm_done);
+        if (b.p) (void)hipFree(b.p);
+    }
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
@@ -184,6 +188,9 @@ extern "C" int skr_prof_names(skr_ctx* ctx, char* buf, int64_t cap) {
 }
 
 // ---------------------------------------------------------------- matrices --------------
+constexpr size_t kSmallBlockBytes = 256 << 10;  // statistic vectors: 16 KiB (k = 6) ... 256 KiB (k = 8, float32)
+constexpr size_t kSmallBlockCap = 64;
+
 extern "C" int skr_mat_create(skr_ctx* ctx, int64_t rows, int64_t cols, int dtype, skr_mat** out) {
     SKR_REQUIRE(ctx && out, "NULL argument");
     *out = nullptr;
@@ -197,6 +204,23 @@ extern "C" int skr_mat_create(skr_ctx* ctx, int64_t rows, int64_t cols, int dtyp
     m->dtype = dtype;
     size_t bytes = m->bytes();
     if (bytes == 0) bytes = 16;
+    if (bytes <= kSmallBlockBytes) {  // a recycled block of exactly this size (see skr_mat_free)
+        for (size_t i = 0; i < ctx->small_blocks.size(); i++) {
+            if (ctx->small_blocks[i].bytes != bytes) continue;
+            skr_ctx::SmallBlock b = ctx->small_blocks[i];
+            ctx->small_blocks.erase(ctx->small_blocks.begin() + (long)i);
+            // earlier uses on the compute stream are ordered by the stream itself; the communication stream by the event
+            hipError_t we = hipStreamWaitEvent(ctx->stream, b.comm_done, 0);
+            (void)hipEventDestroy(b.comm_done);
+            if (we != hipSuccess) {
+                (void)hipFree(b.p);
+                break;
+            }
+            m->data = b.p;
+            *out = m;
+            return SKR_OK;
+        }
+    }
     hipError_t e = hipMalloc(&m->data, bytes);
     if (e != hipSuccess) {
         delete m;
@@ -211,6 +235,20 @@ extern "C" int skr_mat_free(skr_mat* m) {
     if (!m) return SKR_OK;
     if (m->owner) {  // views own nothing: no synchronisation needed to drop them
         (void)hipSetDevice(m->ctx->device);
+        const size_t bytes = m->bytes() ? m->bytes() : 16;
+        if (m->data && bytes <= kSmallBlockBytes && m->ctx->small_blocks.size() < kSmallBlockCap) {
+            // keep the block for the next matrix of this size: no hipFree, hence no host synchronisation
+            skr_ctx::SmallBlock b;
+            b.p = m->data;
+            b.bytes = bytes;
+            if (hipEventCreateWithFlags(&b.comm_done, hipEventDisableTiming) == hipSuccess &&
+                hipEventRecord(b.comm_done, m->ctx->comm_stream) == hipSuccess) {
+                m->ctx->small_blocks.push_back(b);
+                delete m;
+                return SKR_OK;
+            }
+            if (b.comm_done) (void)hipEventDestroy(b.comm_done);
+        }
         (void)hipStreamSynchronize(m->ctx->stream);
         (void)hipStreamSynchronize(m->ctx->comm_stream);
         if (m->data) (void)hipFree(m->data);

@@ -9,36 +9,27 @@ BasicCounter, labelled CSV rows, `supply_basic_header`).
 HEADER_MARK = ">"
 
 
-def split_records(stripped_lines):
-    """(headers, sequences) from lines that have already been `str.strip()`ped.
-
-    Rules of fasta_reader.py:47-63, including its failure modes: an empty line fails on `line[0]`
-    (IndexError), a header that follows another header — anywhere but on the first line — trips the
-    assertion, sequences are upper-cased, and a header at the very end gets an empty sequence."""
-    headers, sequences, pieces = [], [], []
+def records(stripped_lines):
+    """The entries of the file in encounter order, as fasta_reader.py:47-63 builds them: a header line as it stands,
+    the sequence lines up to the next header joined and upper-cased.  For a well-formed file that is
+    [h0, s0, h1, s1, ...].  The reference's failure modes are kept: an empty line fails on `line[0]` (IndexError); a
+    header that follows another header — anywhere but on the first line — trips the assertion; a header at the very
+    end gets an empty sequence; and a file whose first line is NOT a header simply starts with a sequence entry
+    ([s0, h1, s1, ...]), which `get_headers` / `get_seqs` then slice as they slice everything (the reference does not
+    notice either)."""
+    entries, pieces = [], []
     for index, line in enumerate(stripped_lines):
-        first = line[0]
-        if first != HEADER_MARK:
+        if line[0] != HEADER_MARK:
             pieces.append(line)
             continue
         if pieces:
-            sequences.append("".join(pieces).upper())
+            entries.append("".join(pieces).upper())
             pieces = []
         elif index:
             raise AssertionError("There may be a header without a sequence at line {}.".format(index))
-        headers.append(line)
-    sequences.append("".join(pieces).upper())
-    return headers, sequences
-
-
-def interleave(headers, sequences):
-    """[h0, s0, h1, s1, ...] — the shape the reference keeps in `Reader.data`."""
-    out = []
-    for pair in zip(headers, sequences):
-        out.extend(pair)
-    if len(sequences) > len(headers):  # sequence lines without any header: the reference keeps them as one record
-        out.extend(sequences[len(headers):])
-    return out
+        entries.append(line)
+    entries.append("".join(pieces).upper())
+    return entries
 
 
 class Reader:
@@ -51,9 +42,8 @@ class Reader:
     def _load(self):
         with open(self.infasta) as fh:
             stripped = [raw.strip() for raw in fh]
-        headers, sequences = split_records(stripped)
-        self.data = interleave(headers, sequences)
-        return headers, sequences
+        self.data = records(stripped)
+        return self.data[0::2], self.data[1::2]
 
     def get_lines(self):
         self._load()

@@ -72,7 +72,15 @@ class BasicCounter:
         if infasta is not None:
             # kmer_counts.py:103-105 reads the file here; errors of the reader surface here too
             if self._two_bit:
-                self._packed = _lib.default_context().pack_fasta(infasta, alphabet)
+                try:
+                    self._packed = _lib.default_context().pack_fasta(infasta, alphabet)
+                except ValueError as e:
+                    # a file whose first line is not a header: the native reader refuses it, the reference slices its
+                    # entry list anyway (Reader.get_seqs then returns what stands at the odd positions).  Same result
+                    # here: the strings of the Python Reader are packed instead.
+                    if "does not start with a '>' header line" not in str(e):
+                        raise
+                    self._seqs = Reader(infasta).get_seqs()
             else:
                 self._seqs = Reader(infasta).get_seqs()
         self.outfile = outfile
@@ -136,7 +144,24 @@ class BasicCounter:
         if self._two_bit:
             packed = ctx.pack([seq], self.alphabet)
             n = _lib.count_u32(ctx, packed, self.k).to_numpy()[0]
-            vals = _lib.count_per_kb(ctx, packed, self.k, dtype=np.float64).to_numpy()[0]
+            if self.k <= 7:
+                vals = _lib.count_per_kb(ctx, packed, self.k, dtype=np.float64).to_numpy()[0]
+            else:
+                # the float64 flush exists for k <= 7; above that the (sparse) row is rebuilt from the integer counts:
+                # n sequential float64 additions of 1000/W, the reference's own arithmetic (kmer_counts.py:144-150)
+                windows = len(seq) - self.k + 1
+                if windows == 0:
+                    raise ZeroDivisionError("division by zero")
+                inc = 1000.0 / windows
+                vals = np.zeros(n.shape, dtype=np.float64)
+                hit = np.nonzero(n)[0]
+                top = int(n[hit].max()) if len(hit) else 0
+                partial = np.zeros(top + 1, dtype=np.float64)
+                acc = 0.0
+                for j in range(1, top + 1):
+                    acc += inc
+                    partial[j] = acc
+                vals[hit] = partial[n[hit]]
         else:
             n = _lib.count_generic(ctx, [seq], self.alphabet, self.k, np.uint32).to_numpy()[0]
             vals = _lib.count_generic(ctx, [seq], self.alphabet, self.k, np.float64).to_numpy()[0]

@@ -1,6 +1,8 @@
 """Consumers of the Pearson matrix against their numpy definitions in the
 reference: kmer_leiden.py:94-96, find_dist.py:163,169, find_pval.py:158-164.  Bit-exact: they
 are copies, comparisons and one correctly rounded division."""
+import os
+
 import numpy as np
 import pytest
 
@@ -149,3 +151,26 @@ def test_topk_rows_matches_stable_argsort(n, m, k, ctx):
     for i in range(10):
         cand = np.array([c for c in range(m) if c != 10 + i])
         assert np.array_equal(idx2[i], cand[np.argsort(-r[10 + i][cand], kind="stable")][:3])
+
+
+def test_parametric_pvalues_against_scipy_fixtures(ctx, golden_dir):
+    """find_pval.py:118-133: p = 1 - dist.cdf(sim) for find_dist's common10 distributions, fixtures from scipy
+    (tests/golden/make_golden_pvals.py).  scipy works in float64 and the store rounds to float32; the device does
+    the same with its own float64 atan / erfc / expm1 / pow / incomplete gamma, so the results agree to float32
+    rounding of values that differ by a few float64 ulps: |dp| <= 2e-6 p + 4e-16 (the absolute term is the float64
+    granularity of 1 - cdf where the cdf has reached 1)."""
+    from seekr_amd import consumers
+    g = np.load(os.path.join(golden_dir, "pvals_common10.npz"))
+    sim = g["sim"]
+    d = ctx.from_numpy(sim)
+    for i, (name, params) in enumerate(zip(g["names"], g["params"])):
+        want = g["p%d" % i]
+        got = consumers.parametric_pvalues(d, str(name), [float(v) for v in str(params).split(",")]).to_numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(want)), name
+        ok = np.abs(got - want) <= 2e-6 * np.abs(want) + 4e-16
+        assert (ok | np.isnan(want)).all(), (str(name), str(params), float(np.nanmax(np.abs(got - want) / (np.abs(want) + 1e-300))))
+    # the host helper takes find_dist's result list as it is
+    host = consumers.pvalues_host(sim, [("norm", 0.01, (0.01, 0.08))])
+    assert np.allclose(host, g["p0"], rtol=2e-6, atol=4e-16, equal_nan=True)
+    with pytest.raises(NotImplementedError):
+        consumers.parametric_pvalues(d, "weibull_min", (1.5, 0.0, 1.0))

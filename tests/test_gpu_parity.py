@@ -938,6 +938,37 @@ def test_matrices_beyond_4gib():
     assert out.returncode == 0 and "big offsets ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+def test_g8_file_whose_first_line_is_not_a_header(golden_dir, tmp_path):
+    """The native reader refuses such a file; BasicCounter then packs the strings of the Python Reader, which slices
+    the entry list exactly as the reference does: same `seqs`, same raw counts, bit for bit."""
+    g = json.load(open(os.path.join(golden_dir, "g8_headerless.json")))
+    path = str(tmp_path / "h.fa")
+    with open(path, "w") as fh:
+        fh.write(g["text"])
+    c = counter(k=2, mean=False, std=False, log2="Log2.none", infasta=path)
+    assert list(c.seqs) == g["counter_seqs"]
+    c.get_counts()
+    assert np.array_equal(bits(c.counts), np.array(g["raw_k2_bits"], dtype=np.uint32))
+
+
+@pytest.mark.parametrize("k", [8, 9])
+def test_occurrences_float64_row_at_k8_and_up(k):
+    """BasicCounter.occurrences on a float64 row for k >= 8 (the float64 flush exists for k <= 7 only):
+    the values are rebuilt on the host from the integer counts — n sequential float64 additions of 1000/W."""
+    from seekr_amd.kmer_counts import BasicCounter
+    rng = np.random.default_rng(k)
+    seq = "".join(rng.choice(list("ACGT"), size=3000)) + "A" * 40
+    c = BasicCounter(k=k, silent=True)
+    row = np.zeros(4 ** k, dtype=np.float64)
+    c.occurrences(row, seq)
+    n = orc.count_kmers_u32([seq], k)[0]
+    want = orc.per_kb_from_counts(n[None, :], [len(seq)], k, dtype=np.float64)[0]
+    assert np.array_equal(row, want)
+    row32 = np.zeros(4 ** k, dtype=np.float32)
+    c.occurrences(row32, seq)
+    assert np.array_equal(row32, want.astype(np.float32))
+
+
 def test_g7_alphabets_other_than_four_letters(golden_dir, tmp_path):
     """Alphabets of 1, 2, 5 and 20 letters and with a repeated letter (the general counting kernel) against the
     reference's output: raw counts and `occurrences` bit-exact, normalised matrices within the bar."""

@@ -289,3 +289,19 @@ def test_g7_alphabets_other_than_four_letters(golden_dir):
             post = orc.normalize(raw, True, True, "Log2.post")[0]
         np.testing.assert_array_equal(pre, g7[name + "_pre"])
         np.testing.assert_array_equal(post, g7[name + "_post"])
+
+
+def test_g8_file_whose_first_line_is_not_a_header(golden_dir, tmp_path):
+    """fasta_reader.py:47-63 keeps entries in encounter order and :70-78 slice them as they stand: the oracle and the
+    package's Reader must return the reference's (odd-looking) lists for such a file."""
+    import json
+    from seekr_amd.fasta_reader import Reader
+    g = json.load(open(os.path.join(golden_dir, "g8_headerless.json")))
+    path = str(tmp_path / "h.fa")
+    with open(path, "w") as fh:
+        fh.write(g["text"])
+    assert orc.read_fasta(path) == (g["headers"], g["seqs"])
+    assert Reader(path).get_lines() == g["lines"] and Reader(path).get_headers() == g["headers"]
+    assert Reader(path).get_seqs() == g["seqs"] == g["counter_seqs"]
+    raw = orc.raw_counts(g["seqs"], 2)
+    assert np.array_equal(raw.view(np.uint32), np.array(g["raw_k2_bits"], dtype=np.uint32))
