@@ -253,6 +253,17 @@ int skr_edges(skr_ctx* ctx, const skr_mat* r, int64_t nrows, int64_t col_begin, 
               int64_t row_global0, int64_t col_global0, float cutoff, int upper_only, skr_mat* out_rows,
               skr_mat* out_cols, skr_mat* out_vals, int64_t* count);
 
+/* The edge list of the block r = a b^T / K WITHOUT writing the block: the contraction's epilogue applies
+ * kmer_leiden.py:94-96 (kept iff !(v < cutoff), v != 0, off the global diagonal; upper_only: column > row) and
+ * appends the survivors; they are then sorted by (row, column) — np.nonzero order — into out_rows / out_cols /
+ * out_vals (U32, U32, F32; global indices = row_global0 + i, col_global0 + j).  Same values, bit for bit, as
+ * skr_pearson_gemm_op followed by skr_edges.  *count = cells found; if it exceeds the outputs' capacity nothing is
+ * written to them and the caller calls again with larger outputs.  `scratch` (float32, at least [a.rows, b.rows]) is
+ * needed only for rows of more than 4 096 columns (2 048 for operands flagged by skr_operand_coherent): the earlier
+ * k chunks leave their partial sums there.  Split-precision operands only (SKR_ERR_UNSUPPORTED otherwise).          */
+int skr_pearson_gemm_edges(skr_ctx* ctx, const skr_operand* a, const skr_operand* b, skr_mat* scratch, int64_t row_global0,
+                           int64_t col_global0, float cutoff, int upper_only, skr_mat* out_rows, skr_mat* out_cols,
+                           skr_mat* out_vals, int64_t* count);
 /* Per-row top-k of the block r[0:nrows, col_begin:col_end]: out_idx[i, t] / out_val[i, t] = global
  * column and value of the t-th largest cell of row i (descending, ties to the smaller column,
  * NaN last: np.argsort(-row, kind="stable")[:k]), the row's own diagonal cell (global column ==

@@ -83,6 +83,7 @@ SIGNATURES = {
     "skr_empirical_pvalues": (_int, [_p, _p, _p, _i64, _p]),
     "skr_parametric_pvalues": (_int, [_p, _p, C.c_char_p, C.POINTER(C.c_double), _int, _p]),
     "skr_edges": (_int, [_p, _p, _i64, _i64, _i64, _i64, _i64, C.c_float, _int, _p, _p, _p, C.POINTER(_i64)]),
+    "skr_pearson_gemm_edges": (_int, [_p, _p, _p, _p, _i64, _i64, C.c_float, _int, _p, _p, _p, C.POINTER(_i64)]),
     "skr_topk_rows": (_int, [_p, _p, _i64, _i64, _i64, _i64, _i64, _int, _p, _p]),
     "skr_mat_save_npy": (_int, [_p, _p, _int, C.c_char_p]),
     "skr_mat_save_csv": (_int, [_p, _p, _int, _int, C.c_char_p]),

@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libseekr_hip.so")
 SOURCES = ["ctx.hip", "pack.hip", "count.hip", "normalize.hip", "pearson.hip", "pearson_bf16.hip", "operand.hip",
-           "consumers.hip", "comm.hip", "io.hip", "csv_read.hip", "host_api.hip"]
+           "consumers.hip", "fused_edges.hip", "comm.hip", "io.hip", "csv_read.hip", "host_api.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
           "-I" + os.path.join(HERE, "..", "include")]

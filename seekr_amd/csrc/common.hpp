@@ -117,6 +117,19 @@ int skr_launch_gemm_f64(skr_ctx* ctx, const double* A, const double* B, double* 
 int skr_launch_gemm_split(skr_ctx* ctx, int precision, const void* As, const void* Bs, float* C, int64_t M, int64_t N,
                           int64_t kt, int64_t ldc, float kdiv, int mode, float* Ct, int64_t ldct, int chunk_tiles = 128);
 
+// Where the EDGES mode of the split contraction appends the cells that survive a threshold (pearson_bf16.hip).
+struct SkrEdgeSink {
+    unsigned long long* keys;   // row << 32 | column (global indices)
+    float* vals;
+    unsigned long long* count;  // cells found (may exceed cap: then the list is incomplete and the caller retries)
+    unsigned long long cap;
+    int64_t row_global0, col_global0;
+    float cutoff;
+    int upper;
+};
+int skr_launch_gemm_edges(skr_ctx* ctx, int precision, const void* As, const void* Bs, float* C, int64_t M, int64_t N,
+                          int64_t kt, int64_t ldc, float kdiv, int chunk_tiles, const SkrEdgeSink& sink);
+
 // A Pearson operand prepared for the matrix cores.  Storage is kt*32 float-sized words per row
 // (kt = ceil(cols/32)) in both layouts: zero-padded float32, or split-interleaved 16-bit halves
 // (per 32-wide k tile: 32 hi then 32 lo = one 128-byte line).

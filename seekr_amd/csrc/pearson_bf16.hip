@@ -34,7 +34,13 @@ namespace {
 constexpr int TM = 256, TN = 256;
 constexpr int kRowBytes = 128;                       // one k tile of one row: 32 hi + 32 lo bf16
 constexpr int kStageBytes = (TM + TN) * kRowBytes;   // 64 KiB
-enum { PLAIN = 0, SELF = 1, CROSS = 2 };
+enum { PLAIN = 0, SELF = 1, CROSS = 2, EDGES = 3 };
+
+// EDGES mode: the epilogue does not store the tile; cells that kmer_leiden.py:94-96 would leave non-zero
+// (`ld_sim[ld_sim < cutoff] = 0; np.fill_diagonal(ld_sim, 0)`: kept iff !(v < cutoff), v != 0, off the diagonal; with
+// `upper` only column > row) are appended to a list — one ballot per accumulator register, one atomic per wave and
+// register that holds a hit — in no particular order; the host sorts the list by (row, column).
+using EdgeSink = SkrEdgeSink;  // common.hpp
 template <typename T>
 using vec8 = T __attribute__((ext_vector_type(8)));
 
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
     const T* __restrict__ A, const T* __restrict__ B, float* __restrict__ C, float* __restrict__ Ct,
     int64_t M, int64_t N, int64_t kt, int64_t ldc, int64_t ldct, float kdiv, int64_t tiles_m, int64_t tiles_n,
     int64_t super_n, uint32_t* __restrict__ queues, int64_t slots_per_queue, int64_t pitch_tiles, int accumulate,
-    unsigned long long* __restrict__ diag) {
+    unsigned long long* __restrict__ diag, const EdgeSink es) {
     constexpr int WN = 4, MT = 8, NT = 4, PP = 4;  // 8 waves as 2 x 4, wave tile 128 x 64
     constexpr bool SYM = MODE == SELF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -218,6 +224,72 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
         cur ^= 1;
     }
     if (DIAG) st[3] = __builtin_amdgcn_s_memtime();
+    if (MODE == EDGES) {
+        // pass 1 marks this lane's surviving cells (128 bits), one atomic per wave reserves room for all of them,
+        // pass 2 writes them (a list in no particular order: the host sorts it).  One atomic per wave and TILE: with one
+        // per accumulator register a dense block (a few % of the cells kept) spent 250 us per tile in dependent atomics.
+        // Cheap first: a cell can only survive if !(acc < cutoff x K) — exact when K x scale^2 is a power of two —
+        // so the exact test (global indices, diagonal, block edge) runs for the few candidates only.
+        const float thr = rk != 0.f && !accumulate ? es.cutoff * kdiv : -INFINITY;
+        auto cell = [&](int mt, int nt, int e, float& w, unsigned long long& key) -> bool {
+            const int64_t n = col_base + wn * 64 + nt * 16 + (lane & 15);
+            const int64_t m = row_base + wm * 128 + mt * 16 + 4 * q + e;
+            const bool inside = m < M && n < N;
+            w = rk != 0.f ? acc[mt][nt][e] * rk : acc[mt][nt][e] / kdiv;
+            if (accumulate && inside) w = C[(size_t)m * ldc + n] + w;  // earlier k chunks left their sum in C
+            const int64_t grow = es.row_global0 + m, gcol = es.col_global0 + n;
+            key = ((unsigned long long)grow << 32) | (unsigned long long)gcol;
+            return inside && !(w < es.cutoff) && w != 0.f && (es.upper ? gcol > grow : gcol != grow);
+        };
+        uint32_t bits[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    if (!(acc[mt][nt][e] < thr)) {  // NaN passes, as it does in numpy's `ld_sim < cutoff`
+                        float w;
+                        unsigned long long key;
+                        const int idx = (mt * NT + nt) * 4 + e;
+                        if (cell(mt, nt, e, w, key)) bits[idx >> 5] |= 1u << (idx & 31);
+                    }
+                }
+        const uint32_t mine = __popc(bits[0]) + __popc(bits[1]) + __popc(bits[2]) + __popc(bits[3]);
+        uint32_t incl = mine;  // inclusive scan over the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        const uint32_t total = __shfl(incl, 63, 64);
+        if (total) {  // wave-uniform
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(es.count, (unsigned long long)total);
+            base = __shfl(base, 0, 64);
+            unsigned long long pos = base + (incl - mine);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int idx = (mt * NT + nt) * 4 + e;
+                        if (bits[idx >> 5] & (1u << (idx & 31))) {
+                            float w;
+                            unsigned long long key;
+                            (void)cell(mt, nt, e, w, key);
+                            if (pos < es.cap) {
+                                es.keys[pos] = key;
+                                es.vals[pos] = w;
+                            }
+                            pos++;
+                        }
+                    }
+        }
+        if (!PERSIST) return;
+        continue;
+    }
     const bool mirror = MODE == CROSS || (SYM && tm != tn);
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
@@ -309,13 +381,54 @@ struct SplitOut {
     int64_t ldct;
 };
 
+// one launch over `ktc` k tiles starting at the operands' current tile (pitch: `kt_pitch` tiles per row)
 template <typename T, int NPROD, int MODE>
-int launch16(skr_ctx* ctx, const T* A, const T* B, const SplitOut& o, int64_t M, int64_t N, int64_t kt, float K,
-             const char* name, int64_t chunk_tiles) {
+int launch_chunk(skr_ctx* ctx, const T* Ac, const T* Bc, const SplitOut& o, int64_t M, int64_t N, int64_t ktc, int64_t kt_pitch,
+                 float K, int accumulate, const EdgeSink& es) {
     const int64_t tiles_m = (M + TM - 1) / TM, tiles_n = (N + TN - 1) / TN;
     const int64_t super_m = (tiles_m + 15) / 16, super_n = (tiles_n + 15) / 16;
     const int64_t slots = super_m * super_n * 256;
     const bool persist = !(getenv("SEEKR_GEMM_PERSIST") && atoi(getenv("SEEKR_GEMM_PERSIST")) == 0);  // A/B knob
+    if (persist && slots > ctx->num_cu) {
+        uint32_t* queues = ctx->d_flags + 8;  // eight counters, zeroed per launch
+        SKR_HIP(hipMemsetAsync(queues, 0, 8 * sizeof(uint32_t), ctx->stream));
+        auto kern = pearson_gemm_split16_kernel<T, NPROD, MODE, true>;
+        unsigned long long* diag = nullptr;
+        if (std::is_same<T, _Float16>::value && NPROD == 3 && (MODE == PLAIN || MODE == SELF) && getenv("SEEKR_GEMM_DIAG") &&
+            atoi(getenv("SEEKR_GEMM_DIAG"))) {
+            // diagnostic build: stamps into the ctx workspace (8 + 8 x 65 536 words), read back by skr_gemm_diag_read
+            void* ws = nullptr;
+            SKR_TRY(skr_ctx_workspace(ctx, (size_t)(8 + 8 * 65536) * 8, &ws));
+            diag = (unsigned long long*)ws;
+            SKR_HIP(hipMemsetAsync(diag, 0, 64, ctx->stream));
+            if (atoi(getenv("SEEKR_GEMM_DIAG")) == 2) SKR_HIP(hipMemsetAsync(diag + 1, 1, 1, ctx->stream));  // flags word = 1: no staging
+            kern = pearson_gemm_split16_kernel<T, NPROD, (MODE == SELF ? SELF : PLAIN), true, true>;
+        }
+        SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    2 * kStageBytes));
+        // A resident workgroup owns its CU outright (8 waves x ~248 VGPRs, 128 KiB LDS): with RCCL traffic
+        // in flight on the communication stream a few CUs are left free, or the send/recv kernels of
+        // shift s+1 could not start before this launch ends and the overlap of §5 would be lost.
+        static const int reserve_env = getenv("SEEKR_GEMM_RESERVE_CUS") ? atoi(getenv("SEEKR_GEMM_RESERVE_CUS")) : -1;
+        const int reserve = reserve_env >= 0 ? reserve_env : (ctx->nranks > 1 ? 8 : 0);
+        const unsigned grid = (unsigned)std::max(8, ctx->num_cu - reserve);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 2 * kStageBytes, ctx->stream, Ac, Bc, o.C, o.Ct, M, N, ktc, o.ldc, o.ldct, K,
+                           tiles_m, tiles_n, super_n, queues, slots / 8, kt_pitch, accumulate, diag, es);
+    } else {
+        auto kern = pearson_gemm_split16_kernel<T, NPROD, MODE, false>;
+        SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    2 * kStageBytes));
+        hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(512), 2 * kStageBytes, ctx->stream, Ac, Bc, o.C, o.Ct, M, N, ktc, o.ldc,
+                           o.ldct, K, tiles_m, tiles_n, super_n, (uint32_t*)nullptr, (int64_t)0, kt_pitch, accumulate,
+                           (unsigned long long*)nullptr, es);
+    }
+    SKR_HIP(hipGetLastError());
+    return SKR_OK;
+}
+
+template <typename T, int NPROD, int MODE>
+int launch16(skr_ctx* ctx, const T* A, const T* B, const SplitOut& o, int64_t M, int64_t N, int64_t kt, float K,
+             const char* name, int64_t chunk_tiles, const EdgeSink* sink = nullptr) {
     // One float32 accumulator per cell is restarted every 4 096 columns: the MFMA adder truncates each
     // add at the accumulator's unit (~0.25 ulp lost per add, measured; `chunk_tiles` = 64, i.e. every 2 048 columns, for
     // operands whose rows are mostly one repeated value: tools/margin_probe.py), a bias that grows with the number
@@ -323,54 +436,28 @@ int launch16(skr_ctx* ctx, const T* A, const T* B, const SplitOut& o, int64_t M,
     // 16 384 in one go.  Later chunks add their partial result to C in the epilogue (rounded float32 adds).
     static const int64_t env_chunk = getenv("SEEKR_GEMM_CHUNK_TILES") ? std::max(1, atoi(getenv("SEEKR_GEMM_CHUNK_TILES"))) : 0;  // A/B knob
     const int64_t kChunkTiles = env_chunk ? env_chunk : chunk_tiles;
+    const EdgeSink es = sink ? *sink : EdgeSink{};
     SkrProfScope prof(ctx, name);
     for (int64_t t0 = 0; t0 < kt; t0 += kChunkTiles) {
         const int64_t ktc = std::min(kChunkTiles, kt - t0);
         const T* Ac = A + t0 * 64;
         const T* Bc = B + t0 * 64;
         const int accumulate = t0 > 0;
-        if (persist && slots > ctx->num_cu) {
-            uint32_t* queues = ctx->d_flags + 8;  // eight counters, zeroed per launch
-            SKR_HIP(hipMemsetAsync(queues, 0, 8 * sizeof(uint32_t), ctx->stream));
-            auto kern = pearson_gemm_split16_kernel<T, NPROD, MODE, true>;
-            unsigned long long* diag = nullptr;
-            if (std::is_same<T, _Float16>::value && NPROD == 3 && MODE != CROSS && getenv("SEEKR_GEMM_DIAG") &&
-                atoi(getenv("SEEKR_GEMM_DIAG"))) {
-                // diagnostic build: stamps into the ctx workspace (8 + 8 x 65 536 words), read back by skr_gemm_diag_read
-                void* ws = nullptr;
-                SKR_TRY(skr_ctx_workspace(ctx, (size_t)(8 + 8 * 65536) * 8, &ws));
-                diag = (unsigned long long*)ws;
-                SKR_HIP(hipMemsetAsync(diag, 0, 64, ctx->stream));
-                if (atoi(getenv("SEEKR_GEMM_DIAG")) == 2) SKR_HIP(hipMemsetAsync(diag + 1, 1, 1, ctx->stream));  // flags word = 1: no staging
-                kern = pearson_gemm_split16_kernel<T, NPROD, (MODE == CROSS ? PLAIN : MODE), true, true>;
-            }
-            SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        2 * kStageBytes));
-            // A resident workgroup owns its CU outright (8 waves x ~248 VGPRs, 128 KiB LDS): with RCCL traffic
-            // in flight on the communication stream a few CUs are left free, or the send/recv kernels of
-            // shift s+1 could not start before this launch ends and the overlap of §5 would be lost.
-            static const int reserve_env = getenv("SEEKR_GEMM_RESERVE_CUS") ? atoi(getenv("SEEKR_GEMM_RESERVE_CUS")) : -1;
-            const int reserve = reserve_env >= 0 ? reserve_env : (ctx->nranks > 1 ? 8 : 0);
-            const unsigned grid = (unsigned)std::max(8, ctx->num_cu - reserve);
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 2 * kStageBytes, ctx->stream, Ac, Bc, o.C, o.Ct, M, N, ktc, o.ldc,
-                               o.ldct, K, tiles_m, tiles_n, super_n, queues, slots / 8, kt, accumulate, diag);
+        if (MODE == EDGES && t0 + kChunkTiles < kt) {
+            // not the last k chunk: its partial sums go to C like a plain block; only the last chunk thresholds
+            SKR_TRY((launch_chunk<T, NPROD, PLAIN>(ctx, Ac, Bc, o, M, N, ktc, kt, K, accumulate, es)));
         } else {
-            auto kern = pearson_gemm_split16_kernel<T, NPROD, MODE, false>;
-            SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        2 * kStageBytes));
-            hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(512), 2 * kStageBytes, ctx->stream, Ac, Bc, o.C, o.Ct, M, N, ktc,
-                               o.ldc, o.ldct, K, tiles_m, tiles_n, super_n, (uint32_t*)nullptr, (int64_t)0, kt, accumulate,
-                               (unsigned long long*)nullptr);
+            SKR_TRY((launch_chunk<T, NPROD, MODE>(ctx, Ac, Bc, o, M, N, ktc, kt, K, accumulate, es)));
         }
-        SKR_HIP(hipGetLastError());
     }
     return SKR_OK;
 }
 
 template <typename T, int NPROD>
 int gemm_split(skr_ctx* ctx, const T* As, const T* Bs, const SplitOut& o, int64_t M, int64_t N, int64_t kt, float K,
-               int mode, const char* name, int64_t chunk_tiles) {
+               int mode, const char* name, int64_t chunk_tiles, const EdgeSink* sink = nullptr) {
     switch (mode) {
+        case EDGES: return launch16<T, NPROD, EDGES>(ctx, As, Bs, o, M, N, kt, K, name, chunk_tiles, sink);
         case SELF: return launch16<T, NPROD, SELF>(ctx, As, Bs, o, M, N, kt, K, name, chunk_tiles);
         case CROSS: return launch16<T, NPROD, CROSS>(ctx, As, Bs, o, M, N, kt, K, name, chunk_tiles);
         default: return launch16<T, NPROD, PLAIN>(ctx, As, Bs, o, M, N, kt, K, name, chunk_tiles);
@@ -395,6 +482,25 @@ int skr_launch_gemm_split(skr_ctx* ctx, int precision, const void* As, const voi
         case SKR_PREC_F16X3:
             return gemm_split<_Float16, 3>(ctx, (const _Float16*)As, (const _Float16*)Bs, o, M, N, kt, K, mode,
                                            "pearson_gemm_f16x3", chunk_tiles);
+        default: return skr_set_error(SKR_ERR_INVALID, "not a split precision: %d", precision);
+    }
+}
+
+// As skr_launch_gemm_split in PLAIN geometry, but the epilogue thresholds instead of storing (EDGES mode).  C is only
+// touched when the rows have more than one k chunk: the earlier chunks leave their partial sums there.
+int skr_launch_gemm_edges(skr_ctx* ctx, int precision, const void* As, const void* Bs, float* C, int64_t M, int64_t N,
+                          int64_t kt, int64_t ldc, float K, int chunk_tiles, const SkrEdgeSink& sink) {
+    SplitOut o{C, ldc, nullptr, 0};
+    switch (precision) {
+        case SKR_PREC_BF16X3:
+            return gemm_split<__bf16, 3>(ctx, (const __bf16*)As, (const __bf16*)Bs, o, M, N, kt, K, EDGES, "pearson_gemm_bf16x3",
+                                         chunk_tiles, &sink);
+        case SKR_PREC_BF16X4:
+            return gemm_split<__bf16, 4>(ctx, (const __bf16*)As, (const __bf16*)Bs, o, M, N, kt, K, EDGES, "pearson_gemm_bf16x4",
+                                         chunk_tiles, &sink);
+        case SKR_PREC_F16X3:
+            return gemm_split<_Float16, 3>(ctx, (const _Float16*)As, (const _Float16*)Bs, o, M, N, kt, K, EDGES,
+                                           "pearson_gemm_f16x3", chunk_tiles, &sink);
         default: return skr_set_error(SKR_ERR_INVALID, "not a split precision: %d", precision);
     }
 }

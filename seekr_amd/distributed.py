@@ -108,6 +108,12 @@ class HipEngine:
     def empty_block(self, rows, cols):
         return self.ctx.empty(rows, cols)
 
+    def fused_edges(self, operand):
+        """A consumers.FusedEdges for split-precision operands (threshold inside the contraction's epilogue: no stripe of
+        r is written), None for float32-layout ones (two-step path)."""
+        from seekr_amd import consumers
+        return consumers.FusedEdges(self.ctx) if operand.kind != 0 else None
+
     def edges(self, r, cutoff, nrows, col_begin, col_end, row_global0, upper_only):
         from seekr_amd import consumers
         return consumers.edges(r, cutoff, nrows=nrows, col_begin=col_begin, col_end=col_end, row_global0=row_global0,
@@ -413,7 +419,7 @@ def stripes_of_rank(n_total, stripe_rows, size, rank):
     return out
 
 
-def sharded_pearson_edges(engine, comm, z, bounds, cutoff, stripe_rows=8192, upper_only=True, full=None):
+def sharded_pearson_edges(engine, comm, z, bounds, cutoff, stripe_rows=8192, upper_only=True, full=None, fuse="auto"):
     """The edge list kmer_leiden builds from r (kmer_leiden.py:91-96: r < cutoff -> 0, zero diagonal,
     non-zero cells are edges) for a row-sharded set, without ever holding an N x N matrix: the
     operands are all-gathered once, then every rank produces and reduces its own row stripes of r
@@ -423,15 +429,28 @@ def sharded_pearson_edges(engine, comm, z, bounds, cutoff, stripe_rows=8192, upp
     n_total = bounds[-1]
     full = allgather_operand(engine, comm, z, bounds, full)
     stripe_rows = max(1, min(int(stripe_rows), n_total))
-    buf = engine.empty_block(stripe_rows, n_total)
+    fused = engine.fused_edges(full) if fuse and hasattr(engine, "fused_edges") else None
+    buf = None
     out = ([], [], [])
+    seen_cells = seen_edges = 0
     for s0, s1 in stripes_of_rank(n_total, stripe_rows, comm.size, comm.rank):
         c0 = s0 if upper_only else 0
         a = engine.view(full, s0, s1 - s0)
         b = engine.view(full, c0, n_total - c0) if c0 else full
-        engine.gemm(a, b, buf, c0)
-        part = engine.edges(buf, cutoff, s1 - s0, c0, n_total, s0, upper_only)
+        # "auto": fused while the list stays sparse (consumers.FUSE_MAX_DENSITY), else through the stripe buffer
+        use_fused = fused is not None and (fuse is True or seen_edges <= 1e-3 * max(seen_cells, 1))
+        if use_fused:
+            part = fused.block(a, b, cutoff, row_global0=s0, col_global0=c0, upper_only=upper_only)
+        else:
+            if buf is None:
+                buf = engine.empty_block(stripe_rows, n_total)
+            engine.gemm(a, b, buf, c0)
+            part = engine.edges(buf, cutoff, s1 - s0, c0, n_total, s0, upper_only)
+        seen_cells += (s1 - s0) * (n_total - c0)
+        seen_edges += len(part[2])
         for acc, p in zip(out, part):
             acc.append(p)
+    if fused:
+        fused.free()
     return tuple(np.concatenate(p) if p else np.empty(0, dtype=d)
                  for p, d in zip(out, (np.uint32, np.uint32, np.float32)))

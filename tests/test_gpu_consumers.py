@@ -174,3 +174,32 @@ def test_parametric_pvalues_against_scipy_fixtures(ctx, golden_dir):
     assert np.allclose(host, g["p0"], rtol=2e-6, atol=4e-16, equal_nan=True)
     with pytest.raises(NotImplementedError):
         consumers.parametric_pvalues(d, "weibull_min", (1.5, 0.0, 1.0))
+
+
+@pytest.mark.parametrize("shape", [(700, 4096, 0.05, True), (1300, 4096, -0.01, False), (530, 16384, 0.04, True),
+                                   (300, 1024, 0.0, False)])
+def test_threshold_fused_into_the_contraction_equals_the_two_step_path(shape, ctx):
+    """skr_pearson_gemm_edges (EDGES mode of the split contraction: the epilogue thresholds, nothing is stored, the
+    list is sorted on the device) against skr_pearson_gemm_op + skr_edges: identical rows, columns and values, bit for
+    bit — stripes, offsets, upper / full, k = 7 rows (four k chunks: the first three leave partial sums in the scratch
+    block), a constant row (NaN cells are edges, as in numpy) and a buffer that is too small at first."""
+    from seekr_amd import _lib, consumers
+    n, cols, cutoff, upper = shape
+    rng = np.random.default_rng(n)
+    x = (rng.binomial(40, 0.06, size=(n, cols)) * np.float32(0.5)).astype(np.float32)
+    x[5] = x[3]            # r = 1 exactly off the diagonal
+    x[7] = 2.5             # constant row: NaN row and column
+    z, _ = _lib.operand_fill(ctx, ctx.from_numpy(x), precision=_lib.PREC_F16X3)
+    assert z.kind == 2
+    for stripe in (n, 257):
+        two = consumers.pearson_edges(z, cutoff, stripe_rows=stripe, upper_only=upper, fuse=False)
+        one = consumers.pearson_edges(z, cutoff, stripe_rows=stripe, upper_only=upper, fuse=True)
+        assert len(two[2]) > 50
+        for a, b in zip(one, two):
+            assert a.dtype == b.dtype and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    fe = consumers.FusedEdges(ctx, capacity=16)  # far too small: the call repeats itself with room
+    got = fe.block(z, z, cutoff, upper_only=upper)
+    want = consumers.pearson_edges(z, cutoff, stripe_rows=n, upper_only=upper, fuse=False)
+    for a, b in zip(got, want):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    fe.free()
