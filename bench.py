@@ -258,7 +258,7 @@ def main():
     gemm_key = {"fp32": "pearson_gemm_f32_kernel", "bf16x3": "split16_kernelIDF16bLi3", "bf16x4": "split16_kernelIDF16bLi4",
                 "f16x3": "split16_kernelIDF16_Li3"}[args.precision]
     gemm_traffic = pmc_traffic(gemm_key) if default_shape else None
-    count_traffic = pmc_traffic("count_kmers_kernel<0") if default_shape else None  # <0, ...>: the float32, non-Log2.pre instantiation
+    count_traffic = pmc_traffic("count_rows_kernel<0") if default_shape else None  # <0, ...>: the float32, non-Log2.pre instantiation
     roofline = {"kernel": gemm_name, "bound": "mfma", "achieved": round(achieved_tf, 2), "peak": peak_tf,
                 "unit": "TFLOP/s", "frac": round(achieved_tf / peak_tf, 4),
                 "traffic": round(gemm_traffic["bytes"] / 1e9, 2) if gemm_traffic else None,

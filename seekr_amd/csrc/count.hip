@@ -473,6 +473,11 @@ int launch_rows(skr_ctx* ctx, const skr_seqs* s, int k, void* out) {
         int per_cu = 0;
         SKR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds));
         per_cu = std::max(1, std::min(per_cu, 2048 / threads));
+        // Row streams in flight chip-wide: every wave (k <= 6) writes its own 16 KiB row.  12 per CU (3 072 rows, a 50 MB
+        // window) wrote 6-10 % faster than the 19 the LDS allows, most clearly right after a kernel that left the caches
+        // dirty (tools/count_bench.py --pre gemm: 0.155 vs 0.170 ms at 50 000 x 2 kb) — the HBM prefers fewer streams.
+        per_cu = std::min(per_cu, 768 / threads);  // 12 waves per CU: 12 rows (k <= 6) or 3 rows of 64 KiB (k = 7) in flight
+        if (getenv("SEEKR_COUNT_PERCU")) per_cu = std::min(per_cu, atoi(getenv("SEEKR_COUNT_PERCU")));  // A/B knob
         // persistent, statically strided items: every workgroup must be resident from the start
         *grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(items, (int64_t)ctx->num_cu * per_cu));
         return SKR_OK;
@@ -550,10 +555,12 @@ int launch_count(skr_ctx* ctx, const skr_seqs* s, int k, void* out, const char* 
         return SKR_OK;
     }
     if (s->n < 1) return SKR_OK;
-    if (OUT != OUT_F64) {
+    const bool legacy = getenv("SEEKR_COUNT_LEGACY") && atoi(getenv("SEEKR_COUNT_LEGACY")) &&
+                        s->max_len - k + 1 <= 65535;  // A/B knob (tools/count_bench.py): the round-1 kernel
+    if (OUT != OUT_F64 && !legacy) {
         SkrProfScope prof(ctx, name);
         // k <= 6: one wave per sequence (8 KiB of bins at k = 6); k = 7: 32 KiB of bins shared by four waves
-        const int wps = k <= 6 ? 1 : 4;
+        const int wps = getenv("SEEKR_COUNT_WPS") ? atoi(getenv("SEEKR_COUNT_WPS")) : (k <= 6 ? 1 : 4);  // A/B knob
         constexpr int O = OUT == OUT_F64 ? OUT_F32 : OUT;  // (never instantiated for float64)
         return wps == 1 ? launch_rows<O, 1>(ctx, s, k, out) : launch_rows<O, 4>(ctx, s, k, out);
     }

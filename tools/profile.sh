@@ -1,12 +1,12 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence kept under profiles/: run ON THE GPU BOX from the repo root,
-#   gpurun -- 'bash tools/profile.sh r1_f16x3 f16x3'
+#   gpurun -- 'bash tools/profile.sh r2_f16x3 f16x3'
 # 1. kernel trace + stats of the default bench command (per-kernel average durations);
 # 2. PMC passes, each in its own run with --kernel-trace only (never with sys/hip/hsa traces),
 #    summarised per kernel by tools/pmc_summary.py.  Every pass runs under `timeout`: a counter
 #    set the hardware cannot schedule aborts the program and leaves rocprofv3 waiting forever.
 set -u
-TAG=${1:-r1_f16x3}
+TAG=${1:-r2_f16x3}
 PREC=${2:-f16x3}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
