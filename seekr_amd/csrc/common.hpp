@@ -21,6 +21,11 @@ struct skr_ctx {
     // workspaces owned by the ctx and grown on demand
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    // pinned host staging for small index tables uploaded asynchronously (skr_ctx_pinned): `pin_done` marks the end
+    // of the last copy out of it, so the next user waits for that copy only, never for the stream
+    void* h_pin = nullptr;
+    size_t h_pin_bytes = 0;
+    hipEvent_t pin_done = nullptr;
     // profiling
     bool prof = false;
     struct ProfRec {
@@ -109,6 +114,10 @@ struct SkrProfScope {
 };
 
 int skr_ctx_workspace(skr_ctx* ctx, size_t bytes, void** out);
+// pinned host buffer of at least `bytes`, free to be overwritten (the previous asynchronous copy out of it has
+// finished); after enqueueing a copy from it on ctx->stream call skr_ctx_pinned_used
+int skr_ctx_pinned(skr_ctx* ctx, size_t bytes, void** out);
+int skr_ctx_pinned_used(skr_ctx* ctx);
 // GEMM launchers (pearson.hip, pearson_bf16.hip), used by operand.hip
 int skr_launch_gemm_f32(skr_ctx* ctx, const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kp,
                         int64_t lda, int64_t ldb, int64_t ldc, int64_t K, int symmetric);

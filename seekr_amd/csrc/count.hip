@@ -23,7 +23,8 @@
 //
 // Long sequences (more than 8 192 windows) are cut into tiles of 8 192 windows (the k-1 bases of halo
 // are simply the next packed words) that are counted like sequences into a scratch matrix of uint32
-// partial histograms; reduce_tiles_kernel sums a sequence's tiles and converts.  A chromosome-sized
+// partial histograms; reduce_tiles_kernel sums a sequence's tiles (chunks of 32 in parallel) and convert_long_kernel
+// writes the row.  A chromosome-sized
 // sequence thus spreads over the whole chip instead of serialising on one CU.
 //
 // count_kmers_kernel (the round-1 kernel: one 256-thread workgroup per sequence, uint32 bins) is kept
@@ -440,19 +441,34 @@ __global__ __launch_bounds__(WPS * 64) void count_rows_kernel(const CountArgs a)
     }
 }
 
-// Sum of a long sequence's tile histograms -> its output row (same per-kb arithmetic as the flush above).
+// Sum of a long sequence's tile histograms, in two steps so that a single chromosome-sized sequence still fills the
+// chip: (1) workgroup (bin block, sequence, chunk of 32 tiles) adds its tiles and atomically adds the result to the
+// sequence's uint32 sum row; (2) the sum row becomes the output row (same per-kb arithmetic as the flush above).
+constexpr int kReduceChunk = 32;
+__global__ __launch_bounds__(256) void reduce_tiles_kernel(const uint32_t* __restrict__ partial, const int64_t* __restrict__ tile_begin,
+                                                           int k, uint32_t* __restrict__ sums) {
+    const uint32_t nbins = 1u << (2 * k);
+    const int64_t ls = blockIdx.y;
+    const int64_t t0 = tile_begin[ls] + (int64_t)blockIdx.z * kReduceChunk;
+    const int64_t t1 = std::min<int64_t>(tile_begin[ls + 1], t0 + kReduceChunk);
+    if (t0 >= t1) return;
+    for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < nbins; b += gridDim.x * 256) {
+        uint32_t n = 0;
+#pragma unroll 8
+        for (int64_t t = t0; t < t1; t++) n += partial[(size_t)t * nbins + b];
+        if (n) atomicAdd(&sums[(size_t)ls * nbins + b], n);
+    }
+}
+
 template <int OUT>
-__global__ __launch_bounds__(256) void reduce_tiles_kernel(const uint32_t* __restrict__ partial, const int64_t* __restrict__ long_seq,
-                                                           const int64_t* __restrict__ tile_begin, const int64_t* __restrict__ len,
-                                                           int k, void* __restrict__ out) {
+__global__ __launch_bounds__(256) void convert_long_kernel(const uint32_t* __restrict__ sums, const int64_t* __restrict__ long_seq,
+                                                           const int64_t* __restrict__ len, int k, void* __restrict__ out) {
     const uint32_t nbins = 1u << (2 * k);
     const int64_t ls = blockIdx.y;
     const int64_t seq = long_seq[ls];
-    const int64_t t0 = tile_begin[ls], t1 = tile_begin[ls + 1];
     const double inc = 1000.0 / (double)(len[seq] - k + 1);
     for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < nbins; b += gridDim.x * 256) {
-        uint32_t n = 0;
-        for (int64_t t = t0; t < t1; t++) n += partial[(size_t)t * nbins + b];
+        const uint32_t n = sums[(size_t)ls * nbins + b];
         if (OUT == OUT_U32) {
             reinterpret_cast<uint32_t*>(out)[(size_t)seq * nbins + b] = n;
         } else {
@@ -492,37 +508,51 @@ int launch_rows(skr_ctx* ctx, const skr_seqs* s, int k, void* out) {
 
     // ---- long sequences: tiles of kItemWindows windows -> uint32 partial histograms -> reduce + convert
     std::vector<int64_t> long_seq, tile_begin{0}, item_seq, item_word0;
+    int64_t max_tiles_of_one = 0;
     auto run_batch = [&]() -> int {
         const int64_t n_long = (int64_t)long_seq.size(), n_tiles = (int64_t)item_seq.size();
         if (n_long == 0) return SKR_OK;
-        const size_t idx_bytes = (size_t)(2 * n_tiles + 2 * n_long + 1) * sizeof(int64_t);
-        const size_t part_off = (idx_bytes + 255) & ~(size_t)255;
+        // index tables: one pinned staging buffer, one asynchronous copy
+        const size_t n_idx = (size_t)(2 * n_tiles + 2 * n_long + 1);
+        const size_t sums_off = (n_idx * sizeof(int64_t) + 255) & ~(size_t)255;
+        const size_t part_off = (sums_off + (size_t)n_long * nbins * 4 + 255) & ~(size_t)255;
         void* ws = nullptr;
         SKR_TRY(skr_ctx_workspace(ctx, part_off + (size_t)n_tiles * nbins * 4, &ws));
+        void* pin = nullptr;
+        SKR_TRY(skr_ctx_pinned(ctx, n_idx * sizeof(int64_t), &pin));
+        int64_t* h = reinterpret_cast<int64_t*>(pin);
+        memcpy(h, item_seq.data(), (size_t)n_tiles * 8);
+        memcpy(h + n_tiles, item_word0.data(), (size_t)n_tiles * 8);
+        memcpy(h + 2 * n_tiles, long_seq.data(), (size_t)n_long * 8);
+        memcpy(h + 2 * n_tiles + n_long, tile_begin.data(), (size_t)(n_long + 1) * 8);
         int64_t* d_item_seq = reinterpret_cast<int64_t*>(ws);
         int64_t* d_item_word0 = d_item_seq + n_tiles;
         int64_t* d_long_seq = d_item_word0 + n_tiles;
         int64_t* d_tile_begin = d_long_seq + n_long;
+        uint32_t* d_sums = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ws) + sums_off);
         uint32_t* d_partial = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ws) + part_off);
-        SKR_HIP(hipMemcpyAsync(d_item_seq, item_seq.data(), (size_t)n_tiles * 8, hipMemcpyHostToDevice, ctx->stream));
-        SKR_HIP(hipMemcpyAsync(d_item_word0, item_word0.data(), (size_t)n_tiles * 8, hipMemcpyHostToDevice, ctx->stream));
-        SKR_HIP(hipMemcpyAsync(d_long_seq, long_seq.data(), (size_t)n_long * 8, hipMemcpyHostToDevice, ctx->stream));
-        SKR_HIP(hipMemcpyAsync(d_tile_begin, tile_begin.data(), (size_t)(n_long + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        SKR_HIP(hipMemcpyAsync(d_item_seq, h, n_idx * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+        SKR_TRY(skr_ctx_pinned_used(ctx));
+        SKR_HIP(hipMemsetAsync(d_sums, 0, (size_t)n_long * nbins * 4, ctx->stream));
         CountArgs t{s->d_packed, s->d_word_off, s->d_len, s->d_mask, s->d_mask_off, d_item_seq, d_item_word0, n_tiles, d_partial, k};
         auto tkern = count_rows_kernel<OUT_U32, 4, true>;
         unsigned tgrid = 1;
         SKR_TRY(grid_for_kernel(reinterpret_cast<const void*>(tkern), 256, n_tiles, &tgrid));
         hipLaunchKernelGGL(tkern, dim3(tgrid), dim3(256), lds, ctx->stream, t);
         SKR_HIP(hipGetLastError());
-        const dim3 rgrid((unsigned)std::min<uint32_t>((nbins + 255) / 256, 64), (unsigned)n_long);
-        hipLaunchKernelGGL(reduce_tiles_kernel<OUT>, rgrid, dim3(256), 0, ctx->stream, d_partial, d_long_seq, d_tile_begin, s->d_len, k,
-                           out);
+        const unsigned bx = (unsigned)std::min<uint32_t>((nbins + 255) / 256, 64);
+        const unsigned chunks = (unsigned)std::min<int64_t>(65535, (max_tiles_of_one + kReduceChunk - 1) / kReduceChunk);
+        hipLaunchKernelGGL(reduce_tiles_kernel, dim3(bx, (unsigned)n_long, std::max(1u, chunks)), dim3(256), 0, ctx->stream, d_partial,
+                           d_tile_begin, k, d_sums);
         SKR_HIP(hipGetLastError());
-        SKR_HIP(hipStreamSynchronize(ctx->stream));  // the host vectors above are the source of the async copies
+        hipLaunchKernelGGL(convert_long_kernel<OUT>, dim3(bx, (unsigned)n_long), dim3(256), 0, ctx->stream, d_sums, d_long_seq,
+                           s->d_len, k, out);
+        SKR_HIP(hipGetLastError());
         long_seq.clear();
         item_seq.clear();
         item_word0.clear();
         tile_begin.assign(1, 0);
+        max_tiles_of_one = 0;
         return SKR_OK;
     };
     const int64_t batch_tiles = std::max<int64_t>(1, ((int64_t)1 << 31) / ((int64_t)nbins * 4));  // ~2 GB of partial histograms
@@ -533,6 +563,7 @@ int launch_rows(skr_ctx* ctx, const skr_seqs* s, int k, void* out) {
         if (!item_seq.empty() && (int64_t)item_seq.size() + tiles > batch_tiles) SKR_TRY(run_batch());
         if ((int64_t)long_seq.size() >= 65535) SKR_TRY(run_batch());  // gridDim.y limit
         long_seq.push_back(i);
+        max_tiles_of_one = std::max(max_tiles_of_one, tiles);
         for (int64_t t = 0; t < tiles; t++) {
             item_seq.push_back(i);
             item_word0.push_back(t * (kItemWindows / 16));

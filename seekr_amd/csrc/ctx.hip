@@ -81,6 +81,8 @@ extern "C" int skr_ctx_destroy(skr_ctx* ctx) {
         if (b.p) (void)hipFree(b.p);
     }
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    if (ctx->pin_done) (void)hipEventDestroy(ctx->pin_done);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -113,6 +115,26 @@ int skr_ctx_workspace(skr_ctx* ctx, size_t bytes, void** out) {
         ctx->ws_bytes = want;
     }
     *out = ctx->ws;
+    return SKR_OK;
+}
+
+int skr_ctx_pinned(skr_ctx* ctx, size_t bytes, void** out) {
+    if (ctx->pin_done) SKR_HIP(hipEventSynchronize(ctx->pin_done));
+    if (bytes > ctx->h_pin_bytes) {
+        if (ctx->h_pin) SKR_HIP(hipHostFree(ctx->h_pin));
+        ctx->h_pin = nullptr;
+        ctx->h_pin_bytes = 0;
+        const size_t want = (bytes + 65535) & ~(size_t)65535;
+        SKR_HIP(hipHostMalloc(&ctx->h_pin, want, hipHostMallocDefault));
+        ctx->h_pin_bytes = want;
+    }
+    *out = ctx->h_pin;
+    return SKR_OK;
+}
+
+int skr_ctx_pinned_used(skr_ctx* ctx) {
+    if (!ctx->pin_done) SKR_HIP(hipEventCreateWithFlags(&ctx->pin_done, hipEventDisableTiming));
+    SKR_HIP(hipEventRecord(ctx->pin_done, ctx->stream));
     return SKR_OK;
 }
 
