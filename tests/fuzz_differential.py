@@ -19,6 +19,9 @@ def random_seq(k):
         L = int(rng.choice([0, 1, k - 2, k, k + 1, 15, 16, 17, 31, 32, 33, 47, 48, 49]))
     elif kind == 1:
         L = int(rng.choice([2047, 2048, 2049, 2048 + k - 1, 4095, 4096, 4097, 4111, 6000]))
+    elif kind == 2 and rng.integers(0, 3) == 0:
+        # around the 8 192-window tiles of the long-sequence path (count.hip: kItemWindows)
+        L = int(rng.choice([8190, 8191 + k - 1, 8192 + k - 1, 8192 + k, 16383 + k, 16384 + k - 1, 16384 + k, 20011, 40000]))
     else:
         L = int(rng.integers(k, 3000))
     L = max(L, 0)
