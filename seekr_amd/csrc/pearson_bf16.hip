@@ -197,8 +197,9 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
     __syncthreads();
     if (DIAG) st[2] = __builtin_amdgcn_s_memtime();
     const bool no_dma = DIAG && (diag[1] & 1);  // diagnostic only: k loop without its staging traffic (results meaningless)
+    const bool same_tile = DIAG && (diag[1] & 2);  // diagnostic only: every stage re-loads k tile 0 (served by the nearest cache)
     for (int64_t t = 0; t < kt; t++) {
-        if (t + 1 < kt && !no_dma) stage(cur ^ 1, t + 1);
+        if (t + 1 < kt && !no_dma) stage(cur ^ 1, same_tile ? 0 : t + 1);
         const char* base = smem + cur * kStageBytes;
         vec8<T> ahi[MT], alo[MT], bhi[NT], blo[NT];
 #pragma unroll
