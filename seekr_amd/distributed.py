@@ -140,6 +140,11 @@ class RcclComm:
         """send: an Operand (all rows go to dst); recv: an Operand buffer (rows [0, recv_rows) filled from src)."""
         return _lib.comm_sendrecv(self.ctx, send.as_matrix(), 0, send.rows, dst, recv.as_matrix(), 0, recv_rows, src)
 
+    def shift_part(self, send, srow0, snrows, dst, recv, drow0, dnrows, src):
+        """A row range of a shift: rows [srow0, srow0+snrows) of `send` go to dst, rows [drow0, drow0+dnrows) of `recv`
+        come from src (the sender splits ITS shard the way the receiver expects: both sides use the sender's row count)."""
+        return _lib.comm_sendrecv(self.ctx, send.as_matrix(), srow0, snrows, dst, recv.as_matrix(), drow0, dnrows, src)
+
     def shift_all(self, shifts):
         """shifts: [(send, dst, recv, recv_rows, src)] as ONE grouped exchange: every peer's link carries traffic at
         once.  Returns one ticket for all of them."""
@@ -345,16 +350,18 @@ def owned_blocks(size, rank, bounds):
     return out
 
 
-def sharded_pearson_symmetric(engine, comm, z, bounds, r_row, r_col, recv_bufs, grouped=False):
+def sharded_pearson_symmetric(engine, comm, z, bounds, r_row, r_col, recv_bufs, grouped=False, split_first=True):
     """Self-comparison with every unordered pair of shards multiplied once (module docstring).
 
     `z`: this rank's prepared operand; `r_row` [n_g, N] and `r_col` [N, n_g]: float32 result
     buffers (r_col may be None on one GPU); `recv_bufs`: operand buffers of at least max-shard rows.
     With two buffers shift s sends our shard to rank-s and receives rank+s's, its GEMM overlapping shift
-    s+1.  `grouped` (needs one receive buffer per shift): ALL shifts are posted up front as one grouped
-    exchange, so every peer's xGMI link carries traffic at once and no later shift can be exposed behind a
-    GEMM that finished early; the first cross block then waits for the whole group.
-    Returns owned_blocks(size, rank, bounds)."""
+    s+1.  `split_first`: the FIRST shift — the only one with nothing but the small own triangle to hide behind
+    (rehearsal at 200 000 rows on 8 ranks: 8.2 ms of transfer behind 2.9 ms of work) — travels as two halves, and
+    the first cross block is multiplied half by half, so the wait shrinks to half a transfer.  `grouped` (needs one
+    receive buffer per shift): ALL shifts are posted up front as one grouped exchange, so every peer's xGMI link
+    carries traffic at once and no later shift can be exposed behind a GEMM that finished early; the first cross
+    block then waits for the whole group.  Returns owned_blocks(size, rank, bounds)."""
     size, rank = comm.size, comm.rank
     plan = half_ring_plan(size, rank, bounds)
     tickets = {}
@@ -365,18 +372,43 @@ def sharded_pearson_symmetric(engine, comm, z, bounds, r_row, r_col, recv_bufs, 
     grouped = bool(grouped) and can_group
     buf_of = (lambda i: recv_bufs[i]) if grouped else (lambda i: recv_bufs[i % 2])
 
+    def n_of(g):
+        return bounds[g + 1] - bounds[g]
+
     def post(i):
         s, peer = plan[i][0], plan[i][1]
-        tickets[i] = comm.shift(z, (rank - s) % size, buf_of(i), bounds[peer + 1] - bounds[peer], peer)
+        tickets[i] = comm.shift(z, (rank - s) % size, buf_of(i), n_of(peer), peer)
 
+    # halves of the first shift: every rank splits ITS shard at n_g // 2, so sender and receiver agree; only when the
+    # first cross block uses both shards whole (always, except the distance-P/2 pair of an even P, i.e. P = 2)
+    # The decision must be the same on every rank (a rank's send is half of its left neighbour's receive), so it rests on
+    # global facts only: P >= 3 (the distance-1 pair then uses both shards whole on every rank) and no shard below 2 rows.
+    halves = None
+    if (split_first and not grouped and size >= 3 and plan and hasattr(comm, "shift_part")
+            and min(n_of(g) for g in range(size)) >= 2):
+        s, peer = plan[0][0], plan[0][1]
+        dst = (rank - s) % size
+        own_h, peer_h = n_of(rank) // 2, n_of(peer) // 2
+        halves = [(0, peer_h, comm.shift_part(z, 0, own_h, dst, buf_of(0), 0, peer_h, peer)),
+                  (peer_h, n_of(peer) - peer_h,
+                   comm.shift_part(z, own_h, n_of(rank) - own_h, dst, buf_of(0), peer_h, n_of(peer) - peer_h, peer))]
     group_ticket = None
     if grouped:
-        group_ticket = comm.shift_all([(z, (rank - s) % size, buf_of(i), bounds[peer + 1] - bounds[peer], peer)
+        group_ticket = comm.shift_all([(z, (rank - s) % size, buf_of(i), n_of(peer), peer)
                                        for i, (s, peer, *_rest) in enumerate(plan)])
-    elif plan:
+    elif plan and halves is None:
         post(0)
     engine.gemm(z, z, r_row, bounds[rank], symmetric=True)
     for i, (_, peer, a0, an, b0, bn) in enumerate(plan):
+        if i == 0 and halves is not None:
+            p0 = bounds[peer]
+            for j, (h0, hn, ticket) in enumerate(halves):
+                comm.wait(ticket)
+                if j == len(halves) - 1 and len(plan) > 1:
+                    post(1)
+                if hn:
+                    engine.gemm_mirror(z, engine.view(buf_of(0), h0, hn), r_row, 0, p0 + h0, r_col, p0 + h0, 0)
+            continue
         if grouped:
             if i == 0:
                 comm.wait(group_ticket)

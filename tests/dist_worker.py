@@ -132,6 +132,16 @@ class GlooComm:
         self._pending[self._next] = works
         return self._next
 
+    def shift_part(self, send, srow0, snrows, dst, recv, drow0, dnrows, src):
+        works = []
+        if snrows:
+            works.append(self.dist.isend(self.torch.from_numpy(np.ascontiguousarray(send[srow0:srow0 + snrows])), dst))
+        if dnrows:
+            works.append(self.dist.irecv(self.torch.from_numpy(recv[drow0:drow0 + dnrows]), src))
+        self._next += 1
+        self._pending[self._next] = works
+        return self._next
+
     def allgather_rows(self, shard, full, bounds):
         full[bounds[self.rank]:bounds[self.rank + 1]] = shard
         works = []
