@@ -142,6 +142,12 @@ int skr_count_generic(skr_ctx* ctx, const char* bases, const int64_t* offsets, i
  * `acc` from rank to rank.                                                                   */
 int skr_colsum_seq(skr_ctx* ctx, const skr_mat* x, const skr_mat* center, const skr_mat* center2,
                    int square, skr_mat* acc);
+/* skr_colsum_seq's first pass (no centre) that also returns the column minima of the raw matrix: colmin is
+ * float32 [4, cols], the minimum over its four rows is the column's (NaN where the column holds one).  Float32
+ * rounding is monotone, so min_i z[i,j] = z(min_i x[i,j]) for scale >= 0 and skr_min_nan over `colmin` gives the
+ * Log2.post shift of kmer_counts.py:208 without a pass over the matrix.  The column count must be a multiple of 16
+ * (SKR_ERR_UNSUPPORTED otherwise: use skr_colsum_seq + skr_min_nan on x).                                          */
+int skr_colsum_seq_colmin(skr_ctx* ctx, const skr_mat* x, skr_mat* acc, skr_mat* colmin);
 /* v[j] = fl32(v[j] / fl32(n));  if take_sqrt: v[j] = sqrt_rn(that)  (np.mean / np.std tail) */
 int skr_vec_finish(skr_ctx* ctx, skr_mat* v, int64_t n, int take_sqrt);
 /* NaN-propagating minimum (np.min, kmer_counts.py:208) of z = (x - center) / scale over the

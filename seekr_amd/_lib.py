@@ -57,6 +57,7 @@ SIGNATURES = {
     "skr_count_u32": (_int, [_p, _p, _int, _p]),
     "skr_count_per_kb": (_int, [_p, _p, _int, _int, _p]),
     "skr_colsum_seq": (_int, [_p, _p, _p, _p, _int, _p]),
+    "skr_colsum_seq_colmin": (_int, [_p, _p, _p, _p]),
     "skr_vec_finish": (_int, [_p, _p, _i64, _int]),
     "skr_min_nan": (_int, [_p, _p, _p, _p, C.POINTER(C.c_float), C.POINTER(_int)]),
     "skr_apply": (_int, [_p, _p, _int, _p, _p, _int, C.c_float, _p, C.POINTER(_int)]),
@@ -485,6 +486,12 @@ def count_generic(ctx, seqs, alphabet, k, dtype=np.float32, log2_pre=False):
 
 def colsum_seq(ctx, x, acc, center=None, center2=None, square=False):
     check(lib().skr_colsum_seq(ctx._h, x._h, _h(center), _h(center2), 1 if square else 0, acc._h))
+    return acc
+
+
+def colsum_seq_colmin(ctx, x, acc, colmin):
+    """First pass of the column sums that also leaves the raw column minima in `colmin` [4, cols]."""
+    check(lib().skr_colsum_seq_colmin(ctx._h, x._h, acc._h, colmin._h))
     return acc
 
 

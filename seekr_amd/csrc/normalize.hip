@@ -53,11 +53,16 @@ __device__ __forceinline__ float div_scale(float x, const void* vec, int64_t col
 //     (not HBM latency), so the walker carries no staging work: one barrier per tile is all that
 //     stands between two tiles of its chain.
 // ---------------------------------------------------------------------------------------
-template <int CK, bool SQUARE, bool VEC>
+// MINOUT (first pass only: no centre, no square): the staging waves also keep the minimum of the raw values of their
+// columns (a thread always loads the same four columns) and each of the four waves writes its minima as one row of
+// `colmin` [4, cols] (NaN where it met a NaN).  Rounding is monotone, so the minimum of the NORMALISED matrix over a
+// column is the normalised minimum of the raw column (for scale >= 0): the Log2.post shift |min z| (kmer_counts.py:208)
+// then needs a scan of these four rows instead of a pass over the matrix.
+template <int CK, bool SQUARE, bool VEC, bool MINOUT = false>
 __global__ __launch_bounds__(kWgThreads) void colsum_seq_kernel(const float* __restrict__ x, int64_t rows,
                                                               int64_t cols, const void* __restrict__ center,
                                                               const float* __restrict__ center2,
-                                                              float* __restrict__ acc) {
+                                                              float* __restrict__ acc, float* __restrict__ colmin = nullptr) {
     // column-major tile so that the walker fetches 4 consecutive rows of its column with one
     // ds_read_b128; +4 floats of padding per column keep the 16 walker lanes on distinct banks
     __shared__ __attribute__((aligned(16))) float tile[2][kColsPerWG][kTileRows + 4];
@@ -142,6 +147,8 @@ __global__ __launch_bounds__(kWgThreads) void colsum_seq_kernel(const float* __r
             if (col0 + lane_c4 + j < cols) c2[j] = center2[col0 + lane_c4 + j];
     }
 
+    float4 mn = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+    bool saw_nan[4] = {false, false, false, false};
     auto load_tile = [&](int64_t row_base, float4 (&regs)[kLoads]) {
         if (VEC) {
 #pragma unroll
@@ -149,6 +156,19 @@ __global__ __launch_bounds__(kWgThreads) void colsum_seq_kernel(const float* __r
                 int64_t r = row_base + s * kRowsPerPass + lane_r;
                 r = r < rows ? r : rows - 1;
                 regs[s] = *reinterpret_cast<const float4*>(x + (size_t)r * cols + col0 + lane_c4);
+            }
+            if (MINOUT) {  // rows past the end re-read the last row: real values, harmless for a minimum
+#pragma unroll
+                for (int s = 0; s < kLoads; s++) {
+                    mn.x = fminf(mn.x, regs[s].x);
+                    mn.y = fminf(mn.y, regs[s].y);
+                    mn.z = fminf(mn.z, regs[s].z);
+                    mn.w = fminf(mn.w, regs[s].w);
+                    saw_nan[0] |= regs[s].x != regs[s].x;
+                    saw_nan[1] |= regs[s].y != regs[s].y;
+                    saw_nan[2] |= regs[s].z != regs[s].z;
+                    saw_nan[3] |= regs[s].w != regs[s].w;
+                }
             }
         } else {  // ragged strip / odd column count: element-wise, guarded (small matrices only)
 #pragma unroll
@@ -206,6 +226,25 @@ __global__ __launch_bounds__(kWgThreads) void colsum_seq_kernel(const float* __r
             store_tile(d & 1, ring[d]);     // kDepth is even, so d & 1 == t & 1; waits only for this tile's (oldest) loads
             __syncthreads();
             load_tile((t0 + d + kDepth) * kTileRows, ring[d]);
+        }
+    }
+    if (MINOUT && VEC) {
+        // lanes with the same lane % kLanesPerRow hold the same four columns: fold them inside the wave
+        float m[4] = {mn.x, mn.y, mn.z, mn.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float v = saw_nan[j] ? NAN : m[j];
+            for (int off = kLanesPerRow; off < 64; off <<= 1) {
+                const float o = __shfl_xor(v, off, 64);
+                v = (v != v || o != o) ? NAN : fminf(v, o);
+            }
+            m[j] = v;
+        }
+        const int swave = tid >> 6;  // 0..3: the row of colmin this staging wave owns
+        if ((tid & 63) < kLanesPerRow) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (col0 + lane_c4 + j < cols) colmin[(size_t)swave * cols + col0 + lane_c4 + j] = m[j];
         }
     }
 }
@@ -425,6 +464,28 @@ extern "C" int skr_colsum_seq(skr_ctx* ctx, const skr_mat* x, const skr_mat* cen
     return SKR_OK;
 }
 
+// First pass of the column statistics with the column minima of the raw matrix as a by-product (see MINOUT above).
+// colmin: float32 [4, cols]; min over its four rows = the column's minimum (NaN if the column holds a NaN).
+extern "C" int skr_colsum_seq_colmin(skr_ctx* ctx, const skr_mat* x, skr_mat* acc, skr_mat* colmin) {
+    SKR_REQUIRE(ctx, "ctx is NULL");
+    SKR_TRY(check_f32(ctx, x, "x"));
+    SKR_TRY(check_f32(ctx, acc, "acc"));
+    SKR_TRY(check_f32(ctx, colmin, "colmin"));
+    SKR_REQUIRE(acc->rows * acc->cols == x->cols, "acc must hold one float per column");
+    SKR_REQUIRE(colmin->rows == 4 && colmin->cols == x->cols, "colmin must be [4, %lld]", (long long)x->cols);
+    if (x->cols % kColsPerWG != 0 || x->rows == 0)
+        return skr_set_error(SKR_ERR_UNSUPPORTED, "column minima ride on the vector path: the column count must be a multiple of %d",
+                             kColsPerWG);
+    SKR_TRY(skr_activate(ctx));
+    const unsigned grid = (unsigned)(x->cols / kColsPerWG);
+    SkrProfScope prof(ctx, "colsum_seq");
+    hipLaunchKernelGGL((colsum_seq_kernel<C_NONE, false, true, true>), dim3(grid), dim3(kWgThreads), 0, ctx->stream,
+                       (const float*)x->data, x->rows, x->cols, (const void*)nullptr, (const float*)nullptr, (float*)acc->data,
+                       (float*)colmin->data);
+    SKR_HIP(hipGetLastError());
+    return SKR_OK;
+}
+
 extern "C" int skr_vec_finish(skr_ctx* ctx, skr_mat* v, int64_t n, int take_sqrt) {
     SKR_REQUIRE(ctx, "ctx is NULL");
     SKR_TRY(check_f32(ctx, v, "v"));
@@ -491,10 +552,23 @@ extern "C" int skr_normalize(skr_ctx* ctx, skr_mat* x, int log2_mode, int mean_m
     if (log2_mode == SKR_LOG2_PRE) SKR_TRY(skr_apply(ctx, x, 1, nullptr, nullptr, 0, 0.f, x, nullptr));
     // centre (:165-169): the matrix itself stays raw; the transform is replayed by later passes
     const skr_mat* center = nullptr;
+    // Log2.post with a mean computed here and a scale that is computed (>= 0) or absent: the first pass brings the raw
+    // column minima along and the minimum of z is looked for among their normalised values (skr_colsum_seq_colmin)
+    skr_mat* colmin = nullptr;
+    const bool want_colmin = log2_mode == SKR_LOG2_POST && mean_mode == 1 && std_mode != 2 && x->cols % kColsPerWG == 0 && n > 0;
     if (mean_mode == 1) {
         SKR_TRY(check_f32(ctx, mean_out, "mean_out"));
         SKR_TRY(skr_mat_fill_zero(mean_out));
-        SKR_TRY(skr_colsum_seq(ctx, x, nullptr, nullptr, 0, mean_out));
+        if (want_colmin) {
+            SKR_TRY(skr_mat_create(ctx, 4, x->cols, SKR_F32, &colmin));
+            const int rc = skr_colsum_seq_colmin(ctx, x, mean_out, colmin);
+            if (rc != SKR_OK) {
+                skr_mat_free(colmin);
+                return rc;
+            }
+        } else {
+            SKR_TRY(skr_colsum_seq(ctx, x, nullptr, nullptr, 0, mean_out));
+        }
         SKR_TRY(skr_vec_finish(ctx, mean_out, n, 0));
         center = mean_out;
     } else if (mean_mode == 2) {
@@ -513,6 +587,7 @@ extern "C" int skr_normalize(skr_ctx* ctx, skr_mat* x, int log2_mode, int mean_m
         if (rc == SKR_OK) rc = skr_colsum_seq(ctx, x, center, mprime, 1, std_out);
         if (rc == SKR_OK) rc = skr_vec_finish(ctx, std_out, n, 1);
         skr_mat_free(mprime);
+        if (rc != SKR_OK && colmin) skr_mat_free(colmin);
         SKR_TRY(rc);
         scale = std_out;
     } else if (std_mode == 2) {
@@ -521,9 +596,13 @@ extern "C" int skr_normalize(skr_ctx* ctx, skr_mat* x, int log2_mode, int mean_m
     float shift = 0.f;
     if (log2_mode == SKR_LOG2_POST) {
         float mn = 0.f;
-        SKR_TRY(skr_min_nan(ctx, x, center, scale, &mn, nullptr));
+        const int rc = skr_min_nan(ctx, colmin ? colmin : x, center, scale, &mn, nullptr);
+        if (colmin) skr_mat_free(colmin);
+        colmin = nullptr;
+        SKR_TRY(rc);
         shift = fabsf(mn);  // NaN stays NaN (np.abs(np.min(...)), :208)
     }
+    if (colmin) skr_mat_free(colmin);
     int nan_after_scale = 0;
     if (center || scale || log2_mode == SKR_LOG2_POST)
         SKR_TRY(skr_apply(ctx, x, 0, center, scale, log2_mode == SKR_LOG2_POST, shift, x,

@@ -62,8 +62,16 @@ class HipEngine:
     def view(self, x, row0, nrows):
         return x.view(row0, nrows)
 
-    def colsum(self, x, acc, center=None, center2=None, square=False):
-        _lib.colsum_seq(self.ctx, x, acc, center, center2, square)
+    def colsum(self, x, acc, center=None, center2=None, square=False, colmin=None):
+        if colmin is not None:
+            _lib.colsum_seq_colmin(self.ctx, x, acc, colmin)
+        else:
+            _lib.colsum_seq(self.ctx, x, acc, center, center2, square)
+
+    def colmin_buffer(self, x):
+        """A [4, cols] buffer for the raw column minima the first column-sum pass can produce on the way (None when
+        the column count does not allow it: then the Log2.post minimum is scanned from the matrix)."""
+        return self.ctx.empty(4, x.cols) if x.cols % 16 == 0 and x.rows > 0 else None
 
     def finish(self, v, n, take_sqrt=False):
         _lib.vec_finish(self.ctx, v, n, take_sqrt)
@@ -184,13 +192,16 @@ def _send_vec(comm, v, dst, want_ticket):
         return comm.send_vec(v, dst)
 
 
-def _chain_colsum(engine, comm, x, n_cols, center=None, center2=None, square=False):
+def _chain_colsum(engine, comm, x, n_cols, center=None, center2=None, square=False, colmin=None):
     """Sequential float32 column sums over ALL ranks' rows in global row order; the finished
-    sums end on every rank."""
+    sums end on every rank.  `colmin` (first pass only): also filled with this rank's raw column minima."""
     acc = engine.zeros_vec(n_cols)
     if comm.size > 1 and comm.rank > 0:
         comm.recv_vec(acc, comm.rank - 1)
-    engine.colsum(x, acc, center, center2, square)
+    if colmin is not None:
+        engine.colsum(x, acc, colmin=colmin)
+    else:
+        engine.colsum(x, acc, center, center2, square)
     if comm.size > 1:
         last = comm.size - 1
         if comm.rank < last:
@@ -216,8 +227,15 @@ def sharded_stats(engine, comm, x, n_total, log2="Log2.post", mean=True, std=Tru
     vector to use.  Returns (center, scale, post, shift) for the elementwise tail."""
     n_cols = engine.cols(x)
     center = None
+    # Log2.post needs min z over the whole matrix.  When the mean is computed here anyway, the first column-sum pass
+    # brings the raw column minima along, and (rounding being monotone, the scale a computed std >= 0 or absent) the
+    # minimum of z is found among the normalised column minima: 4 x cols cells instead of a pass over the matrix.
+    colmin = None
+    if (log2 == "Log2.post" and mean is True and (std is True or std is False or std is None)
+            and hasattr(engine, "colmin_buffer")):
+        colmin = engine.colmin_buffer(x)
     if mean is True:
-        center = _chain_colsum(engine, comm, x, n_cols)
+        center = _chain_colsum(engine, comm, x, n_cols, colmin=colmin)
         engine.finish(center, n_total)
     elif mean is not False:
         center = mean
@@ -232,7 +250,7 @@ def sharded_stats(engine, comm, x, n_total, log2="Log2.post", mean=True, std=Tru
     shift = 0.0
     post = log2 == "Log2.post"
     if post:
-        local_min, local_nan = engine.min_nan(x, center, scale)
+        local_min, local_nan = engine.min_nan(colmin if colmin is not None else x, center, scale)
         if comm.size > 1:
             flag = comm.allreduce([1.0 if local_nan else 0.0], "max")[0]
             gmin = comm.allreduce([float(local_min) if not local_nan else 0.0], "min")[0]
