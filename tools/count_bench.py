@@ -65,9 +65,9 @@ def main():
         other = ctx.empty(125000, 4096)
         PRE["op"] = lambda: _lib.check(_lib.lib().skr_mat_fill_zero(other._h))
     elif args.pre == "gemm":
-        xs = np.random.default_rng(0).normal(size=(16384, 4096)).astype(np.float32)
+        xs = np.random.default_rng(0).normal(size=(int(os.environ.get('PRE_GEMM_ROWS', '16384')), 4096)).astype(np.float32)
         zop, _ = _lib.operand_fill(ctx, ctx.from_numpy(xs), precision=_lib.PREC_F16X3)
-        rbuf = ctx.empty(16384, 16384)
+        rbuf = ctx.empty(xs.shape[0], xs.shape[0])
         PRE["op"] = lambda: _lib.pearson_gemm_op(ctx, zop, zop, rbuf, symmetric=True)
     res = time_variants(ctx, packed, args.k, out, variants, args.rounds)
     # calibration of this box: a plain fill of the same matrix (hipMemsetAsync), timed by the host around a sync
