@@ -299,7 +299,7 @@ __global__ __launch_bounds__(WPS * 64) void count_rows_kernel(const CountArgs a)
     }
 
     for (int64_t it = blockIdx.x; it < a.n_items; it += gridDim.x) {
-        prefetch(it + gridDim.x);  // in flight during the counting
+        if (it + gridDim.x < a.n_items) prefetch(it + gridDim.x);  // in flight during the counting (persistent grids only)
         const int64_t Wtot = L - k + 1;  // windows, counting every character (kmer_counts.py:143-144)
         const int64_t Wi = windows_of(L, w0);
         const bool skip = !TILES && Wtot > kItemWindows;
@@ -502,6 +502,14 @@ int launch_rows(skr_ctx* ctx, const skr_seqs* s, int k, void* out) {
     unsigned grid = 1;
     auto kern = count_rows_kernel<OUT, WPS, false>;
     SKR_TRY(grid_for_kernel(reinterpret_cast<const void*>(kern), WPS * 64, s->n, &grid));
+    // One wave per sequence (k <= 6): NOT persistent — one workgroup per sequence, dispatched by the hardware in order, as
+    // many resident as the LDS allows (19 per CU at k = 6).  The rows being written then form a compact front that
+    // moves through the matrix, which is what the HBM writes fastest (tools/micro/store_pattern.hip); a persistent
+    // grid whose waves stride through the sequences drifts apart.  Measured behind a contraction, 50 000 x 2 kb:
+    // 0.146 ms against 0.165 for the persistent grid of 12 waves per CU (which needs the cap: 19 are slower still),
+    // k = 5: 0.100 vs 0.108.  Four waves per sequence (k = 7) measure the same either way and stay persistent.
+    const bool persistent = WPS > 1 || (getenv("SEEKR_COUNT_PERSIST") && atoi(getenv("SEEKR_COUNT_PERSIST")));  // A/B knob
+    if (!persistent) grid = (unsigned)std::min<int64_t>(s->n, 0x7fffffff);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WPS * 64), lds, ctx->stream, a);
     SKR_HIP(hipGetLastError());
     if (s->max_len - k + 1 <= kItemWindows) return SKR_OK;
