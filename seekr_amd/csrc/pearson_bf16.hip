@@ -291,7 +291,7 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
         if (!PERSIST) return;
         continue;
     }
-    const bool mirror = MODE == CROSS || (SYM && tm != tn);
+    const bool mirror = (MODE == CROSS || (SYM && tm != tn)) && !(DIAG && (diag[1] & 4));  // DIAG flag 4: timing without the mirror stores
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
@@ -402,7 +402,10 @@ int launch_chunk(skr_ctx* ctx, const T* Ac, const T* Bc, const SplitOut& o, int6
             SKR_TRY(skr_ctx_workspace(ctx, (size_t)(8 + 8 * 65536) * 8, &ws));
             diag = (unsigned long long*)ws;
             SKR_HIP(hipMemsetAsync(diag, 0, 64, ctx->stream));
-            if (atoi(getenv("SEEKR_GEMM_DIAG")) == 2) SKR_HIP(hipMemsetAsync(diag + 1, 1, 1, ctx->stream));  // flags word = 1: no staging
+            // diagnostic experiments (results meaningless): 2 = k loop without staging, 3 = every stage re-loads k tile 0,
+            // 4 = self mode without the mirror stores
+            const int dmode = atoi(getenv("SEEKR_GEMM_DIAG"));
+            if (dmode >= 2 && dmode <= 4) SKR_HIP(hipMemsetAsync(diag + 1, dmode == 2 ? 1 : (dmode == 3 ? 2 : 4), 1, ctx->stream));
             kern = pearson_gemm_split16_kernel<T, NPROD, (MODE == SELF ? SELF : PLAIN), true, true>;
         }
         SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

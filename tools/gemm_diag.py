@@ -23,6 +23,7 @@ ap.add_argument("--data", default="counts", choices=["counts", "zeros", "ones"],
                 help="operand values: normalised-count-like (default), all zero, or all one (constant rows standardise to NaN -> use raw fill)")
 ap.add_argument("--no-dma", action="store_true", help="k loop without its LDS-DMA staging (timing experiment; r is garbage)")
 ap.add_argument("--same-tile", action="store_true", help="every stage re-loads k tile 0: the staging traffic stays, its source is the nearest cache (timing experiment; r is garbage)")
+ap.add_argument("--no-mirror", action="store_true", help="self mode without the mirror stores (timing experiment; the lower triangle stays unwritten)")
 args = ap.parse_args()
 ctx = _lib.default_context()
 rng = np.random.default_rng(0)
@@ -47,7 +48,7 @@ while time.time() < t_end:  # warm the chip up to its steady clock
     _lib.pearson_gemm_op(ctx, op, b, r, symmetric=sym)
     ctx.sync()
     n += 1
-os.environ["SEEKR_GEMM_DIAG"] = "2" if args.no_dma else ("3" if args.same_tile else "1")
+os.environ["SEEKR_GEMM_DIAG"] = "2" if args.no_dma else ("3" if args.same_tile else ("4" if args.no_mirror else "1"))
 _lib.pearson_gemm_op(ctx, op, b, r, symmetric=sym)
 ctx.sync()
 os.environ.pop("SEEKR_GEMM_DIAG")
