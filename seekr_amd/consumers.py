@@ -130,26 +130,31 @@ class FusedEdges:
                          self.ctx.empty(self.cap, 1, np.float32))
         return self._out
 
-    def block(self, a, b, cutoff, row_global0=0, col_global0=0, upper_only=False):
-        """(rows, cols, vals) of the block a b^T / K, global indices, np.nonzero order."""
+    def block(self, a, b, cutoff, row_global0=0, col_global0=0, upper_only=False, scratch=None, retry=True):
+        """(rows, cols, vals) of the block a b^T / K, global indices, np.nonzero order.  `scratch`: a float32 matrix of at
+        least [a.rows, b.rows] for rows of more than 4 096 columns (allocated and kept here when not given).  The list
+        buffers start at 2e-3 entries per cell; a block with more edges is run again with room (retry=True) or reported
+        as None (retry=False: the caller has a cheaper way for lists that dense)."""
         ctx = self.ctx
         chunk_cols = 2048 if (a.coherent or b.coherent) else 4096
-        scratch = None
-        if a.cols > chunk_cols:
+        if a.cols > chunk_cols and scratch is None:
             if self._scratch is None or self._scratch.rows < a.rows or self._scratch.cols < b.rows:
                 if self._scratch is not None:
                     self._scratch.free()
                 self._scratch = ctx.empty(a.rows, b.rows)
             scratch = self._scratch
+        self.cap = max(self.cap, min(int(2e-3 * a.rows * b.rows) + 1024, 1 << 30))
         while True:
             o_r, o_c, o_v = self._buffers()
             count = C.c_int64(0)
-            _lib.check(_lib.lib().skr_pearson_gemm_edges(ctx._h, a._h, b._h, _lib._h(scratch), int(row_global0), int(col_global0),
-                                                         C.c_float(cutoff), 1 if upper_only else 0, o_r._h, o_c._h, o_v._h,
-                                                         C.byref(count)))
+            _lib.check(_lib.lib().skr_pearson_gemm_edges(ctx._h, a._h, b._h, _lib._h(scratch) if a.cols > chunk_cols else None,
+                                                         int(row_global0), int(col_global0), C.c_float(cutoff),
+                                                         1 if upper_only else 0, o_r._h, o_c._h, o_v._h, C.byref(count)))
             n = count.value
             if n <= self.cap:
                 break
+            if not retry:
+                return None
             self.cap = int(n * 1.25) + 1024  # more edges than the buffers hold: once more with room
         if n == 0:
             return np.empty(0, np.uint32), np.empty(0, np.uint32), np.empty(0, np.float32)
@@ -206,9 +211,16 @@ def pearson_edges(z, cutoff, stripe_rows=8192, upper_only=True, engine_gemm=None
         a = z.view(s0, rows)
         b = z.view(c0, n - c0) if c0 else z
         use_fused = fused is not None and (fuse is True or seen_edges <= FUSE_MAX_DENSITY * max(seen_cells, 1))
+        part = None
         if use_fused:
-            part = fused.block(a, b, cutoff, row_global0=s0, col_global0=c0, upper_only=upper_only)
-        else:
+            if z.cols > 2048 and buf is None:
+                buf = ctx.empty(stripe_rows, n)  # k = 7: the earlier k chunks need a block to leave their sums in
+            part = fused.block(a, b, cutoff, row_global0=s0, col_global0=c0, upper_only=upper_only, scratch=buf,
+                               retry=fuse is True)
+            if part is None:  # denser than the list buffers: through the stripe buffer from here on
+                fused.free()
+                fused = None
+        if part is None:
             if buf is None:
                 buf = ctx.empty(stripe_rows, n)
             _lib.pearson_gemm_op(ctx, a, b, buf, symmetric=False, row0=0, col0=c0)

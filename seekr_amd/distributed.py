@@ -489,9 +489,16 @@ def sharded_pearson_edges(engine, comm, z, bounds, cutoff, stripe_rows=8192, upp
         b = engine.view(full, c0, n_total - c0) if c0 else full
         # "auto": fused while the list stays sparse (consumers.FUSE_MAX_DENSITY), else through the stripe buffer
         use_fused = fused is not None and (fuse is True or seen_edges <= 1e-3 * max(seen_cells, 1))
+        part = None
         if use_fused:
-            part = fused.block(a, b, cutoff, row_global0=s0, col_global0=c0, upper_only=upper_only)
-        else:
+            if engine.cols(full) > 2048 and buf is None:
+                buf = engine.empty_block(stripe_rows, n_total)  # k = 7: the earlier k chunks leave their sums here
+            part = fused.block(a, b, cutoff, row_global0=s0, col_global0=c0, upper_only=upper_only, scratch=buf,
+                               retry=fuse is True)
+            if part is None:  # denser than the list buffers: through the stripe buffer from here on
+                fused.free()
+                fused = None
+        if part is None:
             if buf is None:
                 buf = engine.empty_block(stripe_rows, n_total)
             engine.gemm(a, b, buf, c0)
