@@ -224,6 +224,12 @@ def main():
     for name in ctx.prof_names():
         ms, cnt = ctx.prof_query(name)
         kern[name] = {"ms_total": ms, "launches": cnt}
+    # prof_query matches by prefix ("colsum_seq" also collects "colsum_seq_sq"): make the entries exclusive
+    for name in sorted(kern, key=len):
+        for longer in kern:
+            if longer != name and longer.startswith(name):
+                kern[name]["ms_total"] -= kern[longer]["ms_total"]
+                kern[name]["launches"] -= kern[longer]["launches"]
     gemm_name = {"fp32": "pearson_gemm_f32", "bf16x3": "pearson_gemm_bf16x3", "bf16x4": "pearson_gemm_bf16x4",
                  "f16x3": "pearson_gemm_f16x3"}[args.precision]
     gemm = kern.get(gemm_name, {"ms_total": 0.0, "launches": 0})
