@@ -58,7 +58,10 @@ __device__ __forceinline__ bool row_needs_fp32(float zmax2, float K) {
     // ITS unit — measured on two identical rows with max z^2 = 0.77 K at k = 7: r = 1 - 2.4e-5, i.e.
     // ~0.25 ulp lost per add (the MFMA adder truncates), where the gradual growth of an ordinary
     // r ~ 1 pair costs half of that and everything else far less.
-    return zmax2 * 16.f >= K;
+    // Below 1 024 columns a row meets the energy rule all the time (|z| >= 2 at k = 3) and does not need it: the loss is
+    // at most one unit of the largest partial sum per MFMA add, 3 K / 32 adds in all — <= 2.9e-6 of an r ~ 1 at
+    // K = 256, and half of that at most for an r ~ 0 whose partial sums climbed to K / 2 on the way.
+    return K >= 1024.f && zmax2 * 16.f >= K;
 }
 
 struct FillArgs {
@@ -612,12 +615,15 @@ extern "C" int skr_operand_create(skr_ctx* ctx, int64_t rows, int64_t cols, int 
     op->cols = cols;
     op->kt = (cols + 31) / 32;
     op->precision = precision;
-    // The split error averages out like 1/sqrt(K): at K >= 1024 (k >= 5) it is inside the parity bar
-    // (|dr| <= 2e-6 + 1e-5 |r|); below that the exact-product fp32 MFMA is used, where it is cheap.
-    // ... and above 16 384 columns (k >= 8) one float32 accumulator per cell over the whole of K drifts
+    // bf16 halves: the split error averages out like 1/sqrt(K): at K >= 1024 (k >= 5) it is inside the parity bar
+    // (|dr| <= 2e-6 + 1e-5 |r|); below that the exact-product fp32 MFMA is used.  fp16 halves keep 22 bits of z, so
+    // the dropped lo*lo term is bounded by 2^-21 sum|z_i z_j| / K <= 5e-7 whatever K is: the split kernel is used
+    // from 64 columns (k = 3) up, where it is faster than the fp32 one (k = 4, 50 000 rows: 6.9 -> 3.2 ms).
+    // Above 16 384 columns (k >= 8) one float32 accumulator per cell over the whole of K drifts
     // past the bar (1e-5 at K = 65 536 measured), so those shapes also take the fp32 kernel, whose
     // accumulation is blocked.
-    if (precision == SKR_PREC_FP32 || cols < 1024 || cols > 16384) op->kind = 0;
+    const int64_t split_min = precision == SKR_PREC_F16X3 ? 64 : 1024;
+    if (precision == SKR_PREC_FP32 || cols < split_min || cols > 16384) op->kind = 0;
     else op->kind = precision == SKR_PREC_F16X3 ? 2 : 1;
     // fp16 halves: rows are stored times a power of two chosen so that sqrt(K) — the largest value a
     // row-standardised row can hold — lands just below 2^15.  The lo half of a small z then stays a

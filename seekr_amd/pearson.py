@@ -11,8 +11,8 @@ float32 inputs run on the matrix cores in the arithmetic named by `SEEKR_PRECISI
                     short sequences): up to ~2e-6 off the diagonal, 1e-5 on it
   bf16x4            bf16x3 + lo*lo, ~25 % slower than bf16x3, same 16-bit residual
   fp32              f32-input MFMA, blocked accumulation: 5e-7 on smooth data, ~6x slower
-(tools/adversarial.py prints the errors of all four on worst-case inputs; below 1024 columns
-every choice uses the fp32 kernel).  Anything else (float64, integers, DataFrames read from
+(tools/adversarial.py prints the errors of all four on worst-case inputs; the bf16 choices use
+the fp32 kernel below 1024 columns, f16x3 below 64).  Anything else (float64, integers, DataFrames read from
 CSV) is promoted to float64 like numpy does and runs on the f64 MFMA.
 """
 import os

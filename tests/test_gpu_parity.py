@@ -789,7 +789,7 @@ def test_pearson_split_bf16_vs_oracle(prec, shape, L, ctx):
     truth = orc.pearson_f64_truth(a, b)
     assert np.allclose(got, ref, rtol=RTOL, atol=ATOL_R), np.abs(got - ref).max()
     err = np.abs(got - truth)
-    if k >= 1024:  # the split path proper (K < 1024 is routed to the fp32 MFMA kernel)
+    if k >= 1024:  # the split path proper (bf16 halves below 1 024 columns, fp16 halves below 64: fp32 MFMA kernel)
         assert err.max() < (6e-6 if prec == "bf16x3" else 2.5e-6), err.max()  # error vs float64 truth, on r ~ 1 pairs
     else:
         assert err.max() < 1.5e-6, err.max()
@@ -805,6 +805,36 @@ def test_pearson_split_bf16_vs_oracle(prec, shape, L, ctx):
     # order the hi*lo and lo*hi cross terms enter the float32 accumulator
     assert np.array_equal(np.triu(full), np.triu(rs))
     assert np.allclose(full, rs, rtol=1e-6, atol=2e-7)
+
+
+@pytest.mark.parametrize("K", [64, 256])
+def test_split_fp16_from_64_columns_up(K, L, ctx):
+    """k = 3 and k = 4 profiles (64 / 256 columns) run on the split-fp16 kernel too: its operands carry 22 bits, so the
+    error is bounded by ~2^-21 sum|z_i z_j| / K whatever K is — no averaging over columns is needed, unlike bf16 halves,
+    which keep the fp32 kernel below 1 024 columns.  Worst case for a split: few-valued rows and near copies (r ~ 1)."""
+    rng = np.random.default_rng(K)
+    n = 700
+    few = rng.choice([0.0, 1.0, 2.0, 7.0], (n, K), p=[0.6, 0.25, 0.1, 0.05]).astype(np.float32)
+    few[1::2] = few[0::2]
+    for i in range(1, n, 2):
+        few[i, rng.integers(0, K, 2)] = rng.integers(0, 8, 2)
+    smooth = rng.gamma(2.0, 1.0, size=(n, K)).astype(np.float32)
+    onehot = np.zeros((n, K), np.float32)   # homopolymers: the whole row in one column (|z| = sqrt(K - 1) there)
+    onehot[np.arange(n), rng.integers(0, 4, n)] = rng.integers(1, 50, n)
+    onehot[n // 2:] += (rng.random((n - n // 2, K)) < 0.1) * np.float32(0.25)
+    for x in (few, smooth, onehot):
+        dev = ctx.from_numpy(x)
+        op, _ = L.operand_fill(ctx, dev, precision=L.PREC_F16X3)
+        assert op.kind == 2
+        op_b, _ = L.operand_fill(ctx, dev, precision=L.PREC_BF16X3)
+        assert op_b.kind == 0
+        truth = orc.pearson_f64_truth(x, x)
+        got = L.pearson(ctx, dev, dev, True, L.PREC_F16X3).to_numpy().astype(np.float64)
+        err, bar = np.abs(got - truth), ATOL_R + RTOL * np.abs(truth)
+        assert (err / bar).max() < 0.5, (err / bar).max()
+        assert np.array_equal(got, got.T)
+    tiny, _ = L.operand_fill(ctx, ctx.from_numpy(smooth[:, :16].copy()), precision=L.PREC_F16X3)
+    assert tiny.kind == 0   # k <= 2: one padded k tile, nothing to gain
 
 
 def test_split_fp16_small_values_and_range(L, ctx):
