@@ -18,6 +18,8 @@ struct skr_ctx {
     // small device scratch: [0] encoded min, [1] nan flag, [2] error flag, ...
     uint32_t* d_flags = nullptr;
     uint32_t* h_flags = nullptr;  // pinned mirror
+    double* d_recip = nullptr;    // float64 reciprocals of a scale vector (skr_operand_fill), grown on demand
+    size_t d_recip_len = 0;
     // workspaces owned by the ctx and grown on demand
     void* ws = nullptr;
     size_t ws_bytes = 0;
@@ -165,3 +167,7 @@ __device__ __forceinline__ float skr_log2_cr(float x) { return (float)log2((doub
 // Log2.post is the last step (no statistics are taken of its output), so the <= 1 ulp float32
 // log2 is enough there and an order of magnitude cheaper than the float64 evaluation.
 __device__ __forceinline__ float skr_log2_fast(float x) { return log2f(x); }
+// log2(u + 1) of Log2.post.  The float32 sum u + 1 is zero or at least 2^-24 in magnitude — never subnormal — so the
+// scaling log2f wraps around v_log_f32 for subnormal arguments can never act: the bare instruction returns the same
+// bits (five instructions fewer per cell in kernels that are bound by their instruction count).
+__device__ __forceinline__ float skr_log2_of_sum1(float u) { return __builtin_amdgcn_logf(__fadd_rn(u, 1.0f)); }

@@ -84,6 +84,7 @@ extern "C" int skr_ctx_destroy(skr_ctx* ctx) {
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->pin_done) (void)hipEventDestroy(ctx->pin_done);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
+    if (ctx->d_recip) (void)hipFree(ctx->d_recip);
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);

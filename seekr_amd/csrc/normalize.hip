@@ -292,9 +292,7 @@ __global__ __launch_bounds__(256) void elementwise_kernel(const float* __restric
         if (v != v) any_nan = true;
         if (MIN) vmin = fminf(vmin, v);
         if (POST) {
-            v = __fadd_rn(v, shift);
-            v = __fadd_rn(v, 1.0f);
-            v = skr_log2_fast(v);
+            v = skr_log2_of_sum1(__fadd_rn(v, shift));
         }
         return v;
     };

@@ -17,19 +17,48 @@ namespace {
 // fuzzer; alphabet of 7 letters, 90 % of the columns structurally zero).  So fp16 halves are rounded down or up
 // by a hash of the COLUMN: the residuals of a repeated value come with both signs, the truncation errors cancel
 // like noise, and hi + lo still carries the value to 2^-21 relative.  (bf16 halves keep round-to-nearest.)
-extern "C" __device__ _Float16 __ocml_cvtrtn_f16_f32(float);
-extern "C" __device__ _Float16 __ocml_cvtrtp_f16_f32(float);
+//
+// Directed rounding without the device library's two software conversions (round-down AND round-up evaluated for
+// every cell, ~30 instructions; the fill is bound by its VALU instructions, not by HBM): RU(z) = -RD(-z), so the sign
+// of z is flipped where the hash says "up", the value converted to nearest, stepped one bit pattern towards -inf if
+// that overshot, and the sign flipped back — the same fp16 value as __ocml_cvtrtp / __ocml_cvtrtn bit for bit.
+__device__ __forceinline__ uint32_t split_flip(int64_t col) {  // 0x80000000 where the hi half is rounded UP
+    return ((uint32_t)col * 0x9E3779B1u) & 0x80000000u;
+}
+__device__ __forceinline__ _Float16 split_hi_f16(float zs, uint32_t flip) {
+    const float u = __uint_as_float(__float_as_uint(zs) ^ flip);
+    const _Float16 h = (_Float16)u;  // to nearest; NaN stays NaN
+    uint16_t bits = __builtin_bit_cast(uint16_t, h);
+    // towards -inf: a positive value that overshot goes one pattern down, a negative one (or -0) one pattern up
+    const uint16_t stepped = (int16_t)bits < 0 ? (uint16_t)(bits + 1) : (uint16_t)(bits - 1);
+    bits = (float)h > u ? stepped : bits;
+    return __builtin_bit_cast(_Float16, (uint16_t)(bits ^ (uint16_t)(flip >> 16)));
+}
 template <typename T>
 __device__ __forceinline__ T split_hi(float zs, int64_t col) {
     return (T)zs;  // hardware convert: RNE, NaN stays NaN
 }
 template <>
 __device__ __forceinline__ _Float16 split_hi<_Float16>(float zs, int64_t col) {
-    // directed conversions of the device library (a rounding-mode switch around v_cvt_f16_f32): +0.15 ms on the
-    // 50 000 x 4 096 fill; a hand-written neighbour step (branches) cost +0.5 ms, a biased RNE convert +0.23 ms
-    const bool up = (((uint32_t)col * 0x9E3779B1u) >> 31) != 0;
-    return up ? __ocml_cvtrtp_f16_f32(zs) : __ocml_cvtrtn_f16_f32(zs);
+    return split_hi_f16(zs, split_flip(col));
 }
+// ... and with the direction of the cell known to the caller (the register kernel keeps one bit per cell of its lane)
+template <typename T>
+__device__ __forceinline__ T split_hi_flip(float zs, uint32_t flip) {
+    return (T)zs;
+}
+template <>
+__device__ __forceinline__ _Float16 split_hi_flip<_Float16>(float zs, uint32_t flip) {
+    return split_hi_f16(zs, flip);
+}
+
+// x / d for float32 x and d, rounded exactly as the IEEE division rounds it, from r = RN64(1 / d): the product
+// RN64(x * r) is within 2^-52 (relative) of x / d, and a quotient of two float32 numbers that is not itself a float32
+// number is at least 2^-49 (relative) away from every point where the float32 rounding changes (x - m d is a nonzero
+// multiple of the last of the 49 bits of m d for a 25-bit midpoint m), so the float64 product rounds to float32 the
+// way the exact quotient does.  Zero, infinite and NaN divisors behave as in x / d (r = inf, 0, NaN).  Three
+// instructions instead of the ten of v_div_scale / v_rcp / 4 fma / v_div_fmas / v_div_fixup.
+__device__ __forceinline__ float div_by_recip(float x, double r) { return (float)((double)x * r); }
 
 template <typename T>
 using vec8 = T __attribute__((ext_vector_type(8)));
@@ -69,6 +98,7 @@ struct FillArgs {
     int64_t rows, cols, kt;
     const void* center;  // ck: 0 none, 1 f32, 2 f64
     const void* scale;
+    const double* scale_recip;  // 1 / scale in float64 (register kernels with a float32 scale vector: div_by_recip)
     int ck, sk, post, row_standardize;
     float shift;
     float* y;  // optional normalised-count output (may alias x)
@@ -89,9 +119,7 @@ __device__ __forceinline__ float fill_tail(const FillArgs& a, float v, int64_t c
     else if (a.sk == 2) v = (float)((double)v / reinterpret_cast<const double*>(a.scale)[c]);
     if (v != v) any_nan = true;
     if (a.post) {
-        v = __fadd_rn(v, a.shift);
-        v = __fadd_rn(v, 1.0f);
-        v = skr_log2_fast(v);
+        v = skr_log2_of_sum1(__fadd_rn(v, a.shift));
     }
     return v;
 }
@@ -358,11 +386,13 @@ using vec4h = T __attribute__((ext_vector_type(4)));
 // RW = waves that share a row (1: a wave per row; 4: the workgroup's four waves take 4^7 columns
 // together, wave w owning the 256-column pieces w, w + 4, ... and the row sums crossing the waves
 // through 16 bytes of LDS and one barrier each).
-template <typename T, int VPL, int MODE, int RW>
-__global__ __launch_bounds__(256) void operand_fill_reg_kernel(FillArgs a) {
+template <typename T, int VPL, int MODE, int RW, bool HASY>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VPL == 16 ? 2 : 4))) void operand_fill_reg_kernel(FillArgs a) {
     __shared__ float red[7][4];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    // the wave index through readfirstlane: the compiler then KNOWS the row index is wave-uniform and keeps every row
+    // base in scalar registers (derived from threadIdx it is 'divergent', and all addresses become 64-bit VGPR pairs)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), waves = blockDim.x >> 6;
     constexpr int64_t K = (int64_t)VPL * 256 * RW;
     bool any_nan = false, overflow = false, outlier = false, coherent = false;
     // sum / max over the row; `slot` separates the reductions of one row so that one barrier each is enough
@@ -381,35 +411,74 @@ __global__ __launch_bounds__(256) void operand_fill_reg_kernel(FillArgs a) {
         return fmaxf(fmaxf(red[slot][0], red[slot][1]), fmaxf(red[slot][2], red[slot][3]));
     };
     const int64_t r_first = RW == 1 ? (int64_t)blockIdx.x * waves + wave : (int64_t)blockIdx.x;
-    const int64_t r_step = RW == 1 ? (int64_t)gridDim.x * waves : (int64_t)gridDim.x;
     const int piece0 = RW == 1 ? 0 : wave;  // first 256-column piece of this wave
-    for (int64_t r = r_first; r < a.rows; r += r_step) {
+    // rounding direction of the hi half of each of this lane's VPL * 4 cells, one bit per cell (the same for every row)
+    uint32_t dir[(VPL * 4 + 31) / 32] = {};
+    if (sizeof(T) == 2) {
+#pragma unroll
+        for (int i = 0; i < VPL; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                dir[(i * 4 + j) >> 5] |= (split_flip((int64_t)(i * RW + piece0) * 256 + lane * 4 + j) >> 31) << ((i * 4 + j) & 31);
+    }
+    // launched with exactly one row per wave (RW == 1) or per workgroup (RW == 4), see launch_fill: no row loop
+    const int64_t r = r_first;
+    if (r < a.rows) {
         const float* xr = a.x + (size_t)r * K;
         float4 v[VPL];
 #pragma unroll
         for (int i = 0; i < VPL; i++) v[i] = *reinterpret_cast<const float4*>(xr + (i * RW + piece0) * 256 + lane * 4);
         float s = 0.f;
+        if (MODE >= 1) {
+            // Column vectors (mean, and 1 / std in float64) four 256-column pieces at a time, the next four in flight while
+            // these are used: left to the scheduler all 16 pieces are hoisted to the top (64 + 128 registers on top of
+            // the row) and the kernel drops to one wave per SIMD.
+            constexpr int G = VPL < 4 ? VPL : 4, NG = VPL / G;
+            int nan_seen = 0;
+            float4 mv[2][G];
+            double2 rv[2][G][2];
+            auto load_group = [&](int g, int slot) {
 #pragma unroll
-        for (int i = 0; i < VPL; i++) {
-            const int64_t c = (i * RW + piece0) * 256 + lane * 4;
-            if (MODE >= 1) {
-                const float4 m = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.center) + c);
-                const float4 d = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.scale) + c);
-                v[i].x = __fdiv_rn(__fsub_rn(v[i].x, m.x), d.x);
-                v[i].y = __fdiv_rn(__fsub_rn(v[i].y, m.y), d.y);
-                v[i].z = __fdiv_rn(__fsub_rn(v[i].z, m.z), d.z);
-                v[i].w = __fdiv_rn(__fsub_rn(v[i].w, m.w), d.w);
-                any_nan |= (v[i].x != v[i].x) | (v[i].y != v[i].y) | (v[i].z != v[i].z) | (v[i].w != v[i].w);
-                if (MODE == 2) {
-                    v[i].x = skr_log2_fast(__fadd_rn(__fadd_rn(v[i].x, a.shift), 1.0f));
-                    v[i].y = skr_log2_fast(__fadd_rn(__fadd_rn(v[i].y, a.shift), 1.0f));
-                    v[i].z = skr_log2_fast(__fadd_rn(__fadd_rn(v[i].z, a.shift), 1.0f));
-                    v[i].w = skr_log2_fast(__fadd_rn(__fadd_rn(v[i].w, a.shift), 1.0f));
+                for (int q = 0; q < G; q++) {
+                    const int64_t c = ((g * G + q) * RW + piece0) * 256 + lane * 4;
+                    mv[slot][q] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.center) + c);
+                    rv[slot][q][0] = *reinterpret_cast<const double2*>(a.scale_recip + c);
+                    rv[slot][q][1] = *reinterpret_cast<const double2*>(a.scale_recip + c + 2);
                 }
-                if (a.y) *reinterpret_cast<float4*>(a.y + (size_t)r * K + c) = v[i];
+            };
+            load_group(0, 0);
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                if (g + 1 < NG) load_group(g + 1, (g + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < G; q++) {
+                    const int i = g * G + q;
+                    const int64_t c = (i * RW + piece0) * 256 + lane * 4;
+                    const float4 m = mv[g & 1][q];
+                    v[i].x = div_by_recip(__fsub_rn(v[i].x, m.x), rv[g & 1][q][0].x);
+                    v[i].y = div_by_recip(__fsub_rn(v[i].y, m.y), rv[g & 1][q][0].y);
+                    v[i].z = div_by_recip(__fsub_rn(v[i].z, m.z), rv[g & 1][q][1].x);
+                    v[i].w = div_by_recip(__fsub_rn(v[i].w, m.w), rv[g & 1][q][1].y);
+                    nan_seen |= (int)((v[i].x != v[i].x) | (v[i].y != v[i].y) | (v[i].z != v[i].z) | (v[i].w != v[i].w));
+                    if (MODE == 2) {
+                        v[i].x = skr_log2_of_sum1(__fadd_rn(v[i].x, a.shift));
+                        v[i].y = skr_log2_of_sum1(__fadd_rn(v[i].y, a.shift));
+                        v[i].z = skr_log2_of_sum1(__fadd_rn(v[i].z, a.shift));
+                        v[i].w = skr_log2_of_sum1(__fadd_rn(v[i].w, a.shift));
+                    }
+                    // (HASY is a template flag: a run-time test of a.y here splits the loop body into 16 basic blocks)
+                    if (HASY) *reinterpret_cast<float4*>(a.y + (size_t)r * K + c) = v[i];
+                }
+                // the NaN tests of this group are finished HERE: as one long OR the optimiser pairs cells of different
+                // groups into single unordered compares and keeps all 4 * VPL values from before the log2 alive for them
+                asm volatile("" : "+v"(nan_seen));
+                __builtin_amdgcn_sched_barrier(0);
             }
-            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            any_nan |= nan_seen != 0;
         }
+#pragma unroll
+        for (int i = 0; i < VPL; i++) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         if (a.row_standardize) {  // statistics in the order pearson.py:35-38 computes them
             const float kf = (float)K;
             const float mean = row_sum(s, 0) / kf;
@@ -427,9 +496,12 @@ __global__ __launch_bounds__(256) void operand_fill_reg_kernel(FillArgs a) {
                 s += (dx * dx + dy * dy) + (dz * dz + dw * dw);
             }
             const float sd = sqrtf(row_sum(s, 2) / kf);
+            const double rsd = 1.0 / (double)sd;  // once per row; the 4 * VPL quotients below cost 3 instructions each
 #pragma unroll
             for (int i = 0; i < VPL; i++) {
-                v[i].x /= sd; v[i].y /= sd; v[i].z /= sd; v[i].w /= sd;
+                v[i].x = div_by_recip(v[i].x, rsd); v[i].y = div_by_recip(v[i].y, rsd);
+                v[i].z = div_by_recip(v[i].z, rsd); v[i].w = div_by_recip(v[i].w, rsd);
+                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // float64 temporaries of four pieces at a time
             }
         }
         float sq = 0.f;
@@ -439,11 +511,15 @@ __global__ __launch_bounds__(256) void operand_fill_reg_kernel(FillArgs a) {
         sq = row_sum(sq, 3);
         if (lane == 0 && (RW == 1 || wave == 0)) a.diag[r] = sq / (float)K;
         if (sizeof(T) != 4) {
-            float zmax2 = 0.f;
+            // largest |z| of the row (NaN cells do not count): its square is the largest z^2, and times the operand's
+            // power-of-two scale it is the largest value the fp16 halves have to hold
+            float zmax = 0.f;
 #pragma unroll
             for (int i = 0; i < VPL; i++)
-                zmax2 = fmaxf(fmaxf(zmax2, fmaxf(v[i].x * v[i].x, v[i].y * v[i].y)), fmaxf(v[i].z * v[i].z, v[i].w * v[i].w));
-            if (row_needs_fp32(row_max(zmax2, 4), (float)K)) outlier = true;
+                zmax = fmaxf(fmaxf(zmax, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
+            zmax = row_max(zmax, 4);
+            if (row_needs_fp32(zmax * zmax, (float)K)) outlier = true;
+            if (zmax * a.out_scale > 65504.f) overflow = true;
             // Share of the row held by one repeated value — for count data its minimum, the empty bins.  Near-copies
             // of such a row have only positive products, small ones added to a sum that is already large, and the
             // truncating accumulate then loses up to an ulp of the sum per add (tools/margin_probe.py: the bar is
@@ -469,14 +545,14 @@ __global__ __launch_bounds__(256) void operand_fill_reg_kernel(FillArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const float zs = z[j] * a.out_scale;
-                    if (fabsf(zs) > 65504.f) overflow = true;
-                    const T hh = split_hi<T>(zs, c + j);
+                    const T hh = split_hi_flip<T>(zs, (dir[(i * 4 + j) >> 5] << (31 - ((i * 4 + j) & 31))) & 0x80000000u);
                     hi[j] = hh;
                     lo[j] = (T)(zs - (float)hh);
                 }
                 T* dst = reinterpret_cast<T*>(a.out) + ((size_t)r * a.kt + (c >> 5)) * 64 + (c & 31);
                 *reinterpret_cast<vec4h<T>*>(dst) = hi;
                 *reinterpret_cast<vec4h<T>*>(dst + 32) = lo;
+                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -518,12 +594,18 @@ int check_pair(const skr_ctx* ctx, const skr_mat* a, const skr_mat* b) {
     return SKR_OK;
 }
 
+__global__ void recip64_kernel(const float* __restrict__ v, double* __restrict__ r, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) r[i] = 1.0 / (double)v[i];
+}
+
 bool is_f32_precision(int p) {
     return p == SKR_PREC_FP32 || p == SKR_PREC_BF16X3 || p == SKR_PREC_BF16X4 || p == SKR_PREC_F16X3;
 }
 
 // launches the fill kernel that suits the row width and the operand's storage kind
-int launch_fill(skr_ctx* ctx, const skr_operand* op, const FillArgs& a) {
+int launch_fill(skr_ctx* ctx, const skr_operand* op, const FillArgs& a_in) {
+    const FillArgs& a = a_in;
     const size_t row_floats = (size_t)((a.cols + 3) & ~(int64_t)3);
     const bool wide = row_floats * 4 > 150 * 1024;  // k >= 8: the row does not fit the LDS
     const int waves = (int)std::max<size_t>(1, std::min<size_t>(4, (64 * 1024) / (row_floats * 4)));
@@ -537,20 +619,36 @@ int launch_fill(skr_ctx* ctx, const skr_operand* op, const FillArgs& a) {
     if (a.ck == 0 && a.sk == 0 && !a.post && !a.y) reg_mode = 0;
     else if (a.ck == 1 && a.sk == 1) reg_mode = a.post ? 2 : 1;
     if ((a.cols == 16384 || a.cols == 4096 || a.cols == 1024) && reg_mode >= 0) {
+        FillArgs a = a_in;
+        if (reg_mode >= 1) {  // float64 reciprocals of the scale vector: a quotient then costs 3 instructions (div_by_recip)
+            if (ctx->d_recip_len < (size_t)a.cols) {
+                if (ctx->d_recip) SKR_HIP(hipFree(ctx->d_recip));
+                ctx->d_recip = nullptr;
+                ctx->d_recip_len = 0;
+                SKR_HIP(hipMalloc((void**)&ctx->d_recip, (size_t)a.cols * sizeof(double)));
+                ctx->d_recip_len = (size_t)a.cols;
+            }
+            hipLaunchKernelGGL(recip64_kernel, dim3((unsigned)((a.cols + 255) / 256)), dim3(256), 0, ctx->stream,
+                               reinterpret_cast<const float*>(a.scale), ctx->d_recip, a.cols);
+            a.scale_recip = ctx->d_recip;
+        }
         const int64_t rows_per_wg = a.cols == 16384 ? 1 : 4;
-        // A wave per row (k <= 6): one workgroup per four rows, dispatched in order — the rows being read and written form
-        // a compact front (0.69 -> 0.63 ms at 50 000 x 4 096 against a persistent grid of 5 workgroups per CU; the same
-        // effect as in the counting kernel).  Four waves per row (k = 7) measure 5 % better persistent.
-        const bool persistent = a.cols == 16384 || (getenv("SEEKR_FILL_PERSIST") && atoi(getenv("SEEKR_FILL_PERSIST")));  // A/B knob
+        // One row per wave (k <= 6: four rows per workgroup) or per workgroup (k = 7), the workgroups dispatched in order:
+        // the rows being read and written form a compact front (0.69 -> 0.63 ms at 50 000 x 4 096 against a persistent
+        // grid of 5 workgroups per CU; the same effect as in the counting kernel), and with exactly one row per wave the
+        // kernel has no row loop for the compiler to pipeline across — a persistent k = 7 variant prefetched the next
+        // row into registers this row needs and spilled (2.27 instead of 1.17 ms at 30 000 x 16 384).
         const int64_t all_wgs = (a.rows + rows_per_wg - 1) / rows_per_wg;
-        const unsigned rgrid = (unsigned)std::max<int64_t>(
-            1, persistent ? std::min<int64_t>(all_wgs, (int64_t)ctx->num_cu * 5) : std::min<int64_t>(all_wgs, 0x7fffffff));
+        SKR_REQUIRE(all_wgs <= 0x7fffffff, "too many rows for one fill launch (%lld)", (long long)a.rows);
+        const unsigned rgrid = (unsigned)std::max<int64_t>(1, all_wgs);
         SkrProfScope prof(ctx, "operand_fill");
 #define LAUNCH_REG2(T, V, RW)                                                                                              \
     do {                                                                                                                   \
-        if (reg_mode == 0) hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 0, RW>), dim3(rgrid), dim3(256), 0, ctx->stream, a);      \
-        else if (reg_mode == 1) hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 1, RW>), dim3(rgrid), dim3(256), 0, ctx->stream, a); \
-        else hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 2, RW>), dim3(rgrid), dim3(256), 0, ctx->stream, a);                    \
+        if (reg_mode == 0) hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 0, RW, false>), dim3(rgrid), dim3(256), 0, ctx->stream, a);      \
+        else if (reg_mode == 1 && a.y) hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 1, RW, true>), dim3(rgrid), dim3(256), 0, ctx->stream, a); \
+        else if (reg_mode == 1) hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 1, RW, false>), dim3(rgrid), dim3(256), 0, ctx->stream, a); \
+        else if (a.y) hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 2, RW, true>), dim3(rgrid), dim3(256), 0, ctx->stream, a);             \
+        else hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 2, RW, false>), dim3(rgrid), dim3(256), 0, ctx->stream, a);                    \
     } while (0)
 #define LAUNCH_REG(T)                                  \
     do {                                               \
@@ -700,6 +798,7 @@ extern "C" int skr_operand_fill(skr_ctx* ctx, const skr_mat* x, const skr_mat* c
     SKR_TRY(vec_kind(scale, x->cols, "scale", &a.sk));
     a.center = center ? center->data : nullptr;
     a.scale = scale ? scale->data : nullptr;
+    a.scale_recip = nullptr;
     a.post = post != 0;
     a.shift = shift;
     a.row_standardize = row_standardize != 0;
