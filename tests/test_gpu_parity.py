@@ -551,6 +551,46 @@ def test_operand_fill_equals_separate_kernels(cols, L, ctx):
     assert has_nan and np.isnan(y.to_numpy()[:, 3]).all()
 
 
+@pytest.mark.parametrize("cols", [1024, 4096])
+def test_fill_quotients_are_the_ieee_quotients(cols, L, ctx):
+    """The register fill kernels divide by multiplying with a float64 reciprocal (operand.hip: div_by_recip) — claimed to
+    be THE correctly rounded float32 quotient for every pair of float32 numbers.  Held against numpy's float32 division
+    over the whole exponent range: subnormal, huge, zero, infinite and NaN numerators and divisors, exact quotients,
+    quotients next to a rounding boundary (x = q d rounded, q a float plus half an ulp), signed zeros."""
+    rng = np.random.default_rng(cols)
+    rows = 600
+
+    def wild(shape):
+        v = (rng.choice([-1.0, 1.0], shape) * np.exp2(rng.uniform(-149, 127, shape)) * rng.uniform(1, 2, shape))
+        v = v.astype(np.float32)
+        special = rng.random(shape)
+        v[special < 0.01] = 0.0
+        v[(special >= 0.01) & (special < 0.015)] = -0.0
+        v[(special >= 0.015) & (special < 0.02)] = np.inf
+        v[(special >= 0.02) & (special < 0.025)] = -np.inf
+        v[(special >= 0.025) & (special < 0.03)] = np.nan
+        return v
+
+    s = wild((cols,))
+    x = wild((rows, cols))
+    with np.errstate(all="ignore"):
+        # a third of the rows: moderate magnitudes (the pipeline's range), half of those built next to rounding boundaries
+        d = np.where(np.isfinite(s) & (s != 0), s, np.float32(3.0)).astype(np.float64)
+        q = rng.uniform(-64, 64, (rows // 3, cols)).astype(np.float32).astype(np.float64)
+        q[::2] += np.spacing(q[::2].astype(np.float32)).astype(np.float64) * 0.5   # midpoints between two floats
+        x[: rows // 3] = (q * d).astype(np.float32)
+        want = x / s                                                              # numpy float32 division: IEEE
+    zero = np.zeros((1, cols), np.float32)
+    y = ctx.empty(rows, cols)
+    L.operand_fill(ctx, ctx.from_numpy(x), precision=L.PREC_FP32, center=ctx.from_numpy(zero),
+                   scale=ctx.from_numpy(s.reshape(1, -1)), y=y, row_standardize=False)
+    got = y.to_numpy()
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(got), nan)
+    assert np.array_equal(got.view(np.uint32)[~nan], want.view(np.uint32)[~nan])
+    assert nan.mean() > 0.005 and (np.abs(want[~nan]) < 1.2e-38).mean() > 0.05   # NaNs and subnormal / zero quotients occurred
+
+
 # ------------------------------------------------------------------ k = 7 (config 5 geometry)
 def test_k7_pipeline_16384_columns(L, ctx):
     """k=7: 64 KiB LDS histogram per sequence, 16 384 columns through normalisation, the operand
