@@ -180,8 +180,8 @@ int skr_row_standardize(skr_ctx* ctx, const skr_mat* x, skr_mat* z);
 int skr_pearson_gemm(skr_ctx* ctx, const skr_mat* a, const skr_mat* b, int precision, int symmetric,
                      skr_mat* r, int64_t row0, int64_t col0);
 /* Prepared operands.  A skr_operand holds rows in the layout the chosen contraction consumes
- * (split-interleaved 16-bit halves for the split precisions at cols >= 1024, zero-padded
- * float32 otherwise), so that standardised rows are produced once, exchanged between GPUs as
+ * (split-interleaved 16-bit halves for the split precisions — fp16 halves from 64 columns,
+ * bf16 halves from 1024, both up to 16 384 — zero-padded float32 otherwise), so that standardised rows are produced once, exchanged between GPUs as
  * they are, and multiplied any number of times.                                              */
 typedef struct skr_operand skr_operand;
 int skr_operand_create(skr_ctx* ctx, int64_t rows, int64_t cols, int precision, skr_operand** out);
