@@ -517,7 +517,7 @@ def test_cfg2_full_size_properties(L, ctx):
 
 
 # ------------------------------------------------------------------ fused operand preparation
-@pytest.mark.parametrize("cols", [16, 100, 1024, 4096])
+@pytest.mark.parametrize("cols", [16, 100, 1024, 4096, 16384])
 def test_operand_fill_equals_separate_kernels(cols, L, ctx):
     """skr_operand_fill (normalisation tail + row standardisation + operand layout in one pass)
     must give the normalised counts of skr_apply bit for bit and the r of the unfused path."""
@@ -542,6 +542,12 @@ def test_operand_fill_equals_separate_kernels(cols, L, ctx):
             L.pearson_gemm_op(ctx, op, op, r, symmetric=True)
             want = L.pearson(ctx, ref_y, ref_y, precision=L.PRECISIONS[prec]).to_numpy()
             assert np.array_equal(r.to_numpy(), want)
+            # the same operand when the caller does not ask for the normalised counts (y = NULL: own kernel instances)
+            op2, _ = L.operand_fill(ctx, ctx.from_numpy(x), precision=L.PRECISIONS[prec], center=dmean, scale=dstd,
+                                    post=post, shift=shift, y=None, row_standardize=True)
+            r2 = ctx.empty(257, 257)
+            L.pearson_gemm_op(ctx, op2, op2, r2, symmetric=True)
+            assert np.array_equal(r2.to_numpy(), want)
             assert np.allclose(want, orc.pearson(ref_y.to_numpy(), ref_y.to_numpy()), rtol=RTOL, atol=ATOL_R)
     # NaN reporting: a zero-variance column divides 0 by 0
     x[:, 3] = 1.0
