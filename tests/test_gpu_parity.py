@@ -597,6 +597,40 @@ def test_fill_quotients_are_the_ieee_quotients(cols, L, ctx):
     assert nan.mean() > 0.005 and (np.abs(want[~nan]) < 1.2e-38).mean() > 0.05   # NaNs and subnormal / zero quotients occurred
 
 
+@pytest.mark.parametrize("cols", [256, 4096, 16384])
+def test_split_halves_against_a_numpy_restatement(cols, L, ctx):
+    """The stored fp16 halves, bit for bit: hi = z x scale rounded DOWN or UP by the hash of the column (operand.hip:
+    split_hi_f16 — one conversion and a step, not the device library's directed conversions), lo = fp16(z x scale - hi).
+    Restated with numpy's float16 conversion and nextafter; the three widths take the three fill kernels (wave-private
+    LDS rows, one row per wave in registers, four waves per row)."""
+    rng = np.random.default_rng(cols)
+    rows = 64
+    scale = np.float32(2.0 ** np.floor(np.log2(32768.0 / np.sqrt(cols))))
+    x = (rng.standard_normal((rows, cols)) * rng.choice([1e-9, 1e-6, 1e-3, 0.3, 3.0], (rows, 1))).astype(np.float32)
+    x[:, ::7] = np.float32(0.75)                      # a repeated value: both directions must occur for it
+    x[3, :5] = [0.0, -0.0, 6e-8 / scale, -6e-8 / scale, 1.0 / 3.0]   # zeros, half the smallest fp16 subnormal, a repeating fraction
+    op, _ = L.operand_fill(ctx, ctx.from_numpy(x), precision=L.PREC_F16X3, row_standardize=False)
+    assert op.kind == 2
+    kt = (cols + 31) // 32
+    got = op.as_matrix().to_numpy().view(np.uint16).reshape(rows, kt, 2, 32)
+    zs = x * scale
+    col = np.arange(cols, dtype=np.uint64)
+    up = (((col * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)) >> np.uint64(31)).astype(bool)[None, :]
+    with np.errstate(all="ignore"):
+        h = zs.astype(np.float16)
+        back = h.astype(np.float32)
+        h_up = np.where(back < zs, np.nextafter(h, np.float16(np.inf)), h)
+        h_dn = np.where(back > zs, np.nextafter(h, np.float16(-np.inf)), h)
+        hi = np.where(up, h_up, h_dn).astype(np.float16)
+        lo = (zs - hi.astype(np.float32)).astype(np.float16)
+    want_hi = hi.view(np.uint16).reshape(rows, kt, 32)
+    want_lo = lo.view(np.uint16).reshape(rows, kt, 32)
+    # signed zeros: RD(+0) = +0, RU(-0) = -0 and an exact value keeps its sign — numpy's nextafter path never runs there
+    assert np.array_equal(got[:, :, 0, :], want_hi), np.argwhere(got[:, :, 0, :] != want_hi)[:5]
+    assert np.array_equal(got[:, :, 1, :], want_lo), np.argwhere(got[:, :, 1, :] != want_lo)[:5]
+    assert up.mean() > 0.4 and (~up).mean() > 0.4
+
+
 # ------------------------------------------------------------------ k = 7 (config 5 geometry)
 def test_k7_pipeline_16384_columns(L, ctx):
     """k=7: 64 KiB LDS histogram per sequence, 16 384 columns through normalisation, the operand
