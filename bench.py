@@ -3,6 +3,7 @@
 (Log2.post) -> row standardisation -> all-pairs Pearson of the set against itself.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N ...                       # starts its own N rank processes (below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -16,12 +17,28 @@ unordered pair of row shards is multiplied once, by one of its two ranks, which 
 block and its transpose; every ordered pair ends up in exactly one GPU's HBM, as on one GPU
 (where the lower triangle is the mirror of the upper).  `--layout rowblock` gives every rank
 its full rows of r instead, multiplying each off-diagonal block twice across the node.
+
+Launching.  With WORLD_SIZE in the environment (torch.distributed.run, or any launcher that sets
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT) this process IS one rank.  Without it and with
+--gpus N > 1 this process is only a launcher: it never loads the HIP library or touches a GPU, starts N
+fresh child processes of this same script (one per GPU, no exec of a GPU-initialised process), forwards
+rank 0's JSON line, and on any rank's failure or after --launch-timeout seconds kills exactly the
+process groups it started and exits non-zero with every rank's stderr tail.  A failed first attempt
+in the symmetric layout (including a failed self-test of the half-ring schedule, exit code 17) is
+retried ONCE, in a new set of children, with the plain row-block layout (no split first shift, no
+grouped shifts); the JSON line then carries "layout_fallback".
 """
 import argparse
+import hashlib
 import json
 import math
 import os
+import re
+import signal
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -29,23 +46,19 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from seekr_amd import _lib, launch  # noqa: E402
-from seekr_amd.distributed import (HipEngine, half_ring_plan, shard_bounds, sharded_normalize_prepare,  # noqa: E402
-                                   sharded_pearson_rowblock, sharded_pearson_symmetric)
-from seekr_amd.synthetic import synthetic_ascii, synthetic_codes  # noqa: E402
-
 PEAK = {"hbm_gbs": 8000.0, "fp32_mfma_tflops": 157.3, "bf16_mfma_tflops": 2500.0}  # MI355X_MICROARCH.md
 SEED = 2
+SELFTEST_EXIT = 17  # the half-ring schedule's self-test disagreed with the row-block result on some rank
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--rows", type=int, default=0, help="total transcripts (default 50000*sqrt(gpus))")
     ap.add_argument("--length", type=int, default=2000)
-    ap.add_argument("-k", type=int, default=6)
+    ap.add_argument("-k", "--k", type=int, default=6, dest="k")
     ap.add_argument("--precision", default=os.environ.get("SEEKR_PRECISION", "f16x3"),
                     choices=["fp32", "bf16x3", "bf16x4", "f16x3"],
                     help="Pearson contraction arithmetic; every choice is inside the parity bar "
@@ -57,15 +70,135 @@ def parse():
                     help="symmetric layout: post all half-ring shifts as one grouped exchange (one receive buffer per shift)")
     ap.add_argument("--layout", default="symmetric", choices=["symmetric", "rowblock"],
                     help="multi-GPU result layout (see module docstring); fp32 / --no-symmetry imply rowblock")
-    return ap.parse_args()
+    ap.add_argument("--launch-timeout", type=float, default=300.0,
+                    help="launcher mode: seconds after which the rank processes are killed")
+    ap.add_argument("--no-selftest", action="store_true", help="skip the half-ring schedule's self-test before the warm-up")
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------ launcher ----
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _tail(path, n=30):
+    try:
+        with open(path, "rb") as fh:
+            return b"\n".join(fh.read().splitlines()[-n:]).decode("utf-8", "replace")
+    except OSError:
+        return ""
+
+
+def _kill_group(proc):
+    """Ends exactly the process group this launcher started for `proc` (start_new_session: pgid == pid)."""
+    for sig in (signal.SIGTERM, signal.SIGKILL):
+        if proc.poll() is not None:
+            return
+        try:
+            os.killpg(proc.pid, sig)
+        except (ProcessLookupError, PermissionError):
+            return
+        try:
+            proc.wait(timeout=5)
+        except subprocess.TimeoutExpired:
+            pass
+
+
+def _run_rank_set(argv, size, timeout_s, extra_env, log_dir, attempt, program=None):
+    """One set of `size` fresh rank processes (`program`: what to run instead of this script — the launcher's own
+    tests).  Returns (ok, json_line or failure kind, report)."""
+    program = program or [sys.executable, os.path.abspath(__file__)]
+    port = _free_port()
+    base = dict(os.environ, WORLD_SIZE=str(size), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base.update(extra_env)
+    procs, logs = [], []
+    for rank in range(size):
+        out_path = os.path.join(log_dir, "attempt{}_rank{}.out".format(attempt, rank))
+        err_path = os.path.join(log_dir, "attempt{}_rank{}.err".format(attempt, rank))
+        logs.append((out_path, err_path))
+        env = dict(base, RANK=str(rank), LOCAL_RANK=str(rank))
+        with open(out_path, "wb") as fo, open(err_path, "wb") as fe:
+            procs.append(subprocess.Popen(program + argv, env=env, stdout=fo, stderr=fe,
+                                          stdin=subprocess.DEVNULL, start_new_session=True))
+    deadline = time.time() + timeout_s
+    failed, reason = None, None
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                # the others usually follow with their own message (a failed all-reduce, the self-test's verdict): give
+                # them a moment before the groups are killed, so that the report below holds every rank's own words
+                grace = time.time() + 3.0
+                while time.time() < grace and any(p.poll() is None for p in procs):
+                    time.sleep(0.05)
+                failed = [(r, c) for r, c in enumerate(p.poll() for p in procs) if c not in (None, 0)]
+                reason = "rank {} exited with code {}".format(bad[0][0], bad[0][1])
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() > deadline:
+                failed = [(r, None) for r, c in enumerate(codes) if c is None]
+                reason = "timeout after {:.0f} s (ranks still running: {})".format(timeout_s, [r for r, _ in failed])
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            _kill_group(p)
+    if failed is None:
+        lines = [ln for ln in open(logs[0][0], "r", errors="replace").read().splitlines() if ln.startswith("{")]
+        if len(lines) == 1:
+            return True, lines[0], ""
+        reason = "rank 0 printed {} JSON lines".format(len(lines))
+    report = ["bench.py launcher, attempt {}: {}".format(attempt, reason)]
+    for rank, (out_path, err_path) in enumerate(logs):
+        report.append("---- rank {} (exit code {}) stderr tail ----".format(rank, procs[rank].returncode))
+        report.append(_tail(err_path) or "(empty)")
+        extra = _tail(out_path, 5)
+        if extra and rank != 0:
+            report.append("---- rank {} stdout tail ----\n{}".format(rank, extra))
+    selftest = any(c == SELFTEST_EXIT for _, c in (failed or []))
+    return False, ("selftest" if selftest else reason), "\n".join(report)
+
+
+def launch(args, argv):
+    """Launcher mode (no WORLD_SIZE, --gpus N > 1): see the module docstring.  Returns the exit code."""
+    size = args.gpus
+    symmetric = args.layout == "symmetric" and args.precision != "fp32" and not args.no_symmetry
+    with tempfile.TemporaryDirectory(prefix="seekr_bench_") as log_dir:
+        ok, payload, report = _run_rank_set(argv, size, args.launch_timeout, {}, log_dir, 1)
+        if not ok and symmetric:
+            print(report, file=sys.stderr, flush=True)
+            why = ("the half-ring schedule's self-test failed" if payload == "selftest"
+                   else "the first attempt failed ({})".format(payload))
+            print("bench.py launcher: {}; retrying once in a new set of rank processes with --layout rowblock".format(why),
+                  file=sys.stderr, flush=True)
+            argv2 = [a for a in argv if a != "--grouped-shifts"]
+            for i, a in enumerate(argv2):
+                if a == "--layout":
+                    del argv2[i:i + 2]
+                    break
+            argv2 = [a for a in argv2 if not a.startswith("--layout=")] + ["--layout", "rowblock"]
+            ok, payload, report = _run_rank_set(argv2, size, args.launch_timeout,
+                                                {"SEEKR_BENCH_FALLBACK": "symmetric layout abandoned: " + why}, log_dir, 2)
+        if ok:
+            print(payload, flush=True)
+            return 0
+        print(report, file=sys.stderr, flush=True)
+        return 1
+
+
+# ------------------------------------------------------------------------------------ one rank ----
 def cpu_baseline(k, length, x_norm_head, repeats=3):
     """The oracle (a port with the reference's structure: per-window dict increments in pure
     Python, numpy row standardisation + np.inner) timed on a bounded prefix of the workload:
     `repeats` runs of each leg, median taken."""
     from oracle import seekr_oracle as orc
-    n_count = 6000  # ~2 s per repeat of counting + ~2 s per repeat of Pearson on the GPU box's host
+    from seekr_amd.synthetic import synthetic_codes
+    n_count = max(500, int(6000 * 2000 / length))  # ~12 Mbases: ~2 s per repeat of counting on the GPU box's host
     seqs = orc.codes_to_seqs(synthetic_codes(SEED, n_count, length))
     t_counts = []
     for _ in range(repeats):
@@ -115,9 +248,9 @@ def end_to_end(ctx, k, length, n_seqs, precision):
     """PCIe- and file-inclusive rates through the drop-in API (never `value`): FASTA file -> host
     float32 per-kb counts (BasicCounter: native reader + packer + H2D + kernel + D2H), and host ->
     host pearson() on a prefix (the result copy over PCIe dominates)."""
-    import tempfile
     from seekr_amd.kmer_counts import BasicCounter
     from seekr_amd.pearson import pearson
+    from seekr_amd.synthetic import synthetic_ascii
     blob, _ = synthetic_ascii(SEED, n_seqs, length)
     rows = blob.reshape(n_seqs, length)
     with tempfile.TemporaryDirectory() as tmp:
@@ -148,32 +281,121 @@ def end_to_end(ctx, k, length, n_seqs, precision):
                     "seekr_amd.pearson (raw counts; Pearson result copied to the host: PCIe-bound)"}
 
 
-def pmc_traffic(kernel_key):
-    """HBM-side bytes per launch of a kernel from the committed rocprofv3 --pmc summary of this same
-    command (tools/profile.sh; counters cannot be collected inside the timed run): WRITE_SIZE as
-    reported, FETCH_SIZE doubled — gfx950 tallies the 128-byte requests of wide coalesced reads at
-    64 bytes (MI355X_MICROARCH.md, HBM).  None when no summary names the kernel."""
+def kernel_symbols_sha256(lib_path):
+    """Fingerprint of the set of kernel symbols the library registers (their mangled names sit in its read-only
+    data): tools/pmc_summary.py writes it into every summary, and a summary taken with a library whose kernel set
+    differs from the one loaded now — a kernel added, removed, re-templated or given other arguments — is refused."""
+    with open(lib_path, "rb") as fh:
+        blob = fh.read()
+    names = sorted({m for m in re.findall(rb"_Z[A-Za-z0-9_]{8,}", blob) if b"kernel" in m and b"__device_stub__" not in m})
+    return hashlib.sha256(b"\n".join(names)).hexdigest()
+
+
+def workload_key(rows, length, k, precision, gpus):
+    return "rows={} length={} k={} precision={} gpus={}".format(rows, length, k, precision, gpus)
+
+
+def pmc_traffic(kernel_key, workload, lib_path, profiles_dir=None):
+    """HBM-side bytes per launch of a kernel from a committed rocprofv3 --pmc summary (tools/profile.sh; counters
+    cannot be collected inside the timed run): WRITE_SIZE as reported, FETCH_SIZE doubled — gfx950 tallies the
+    128-byte requests of wide coalesced reads at 64 bytes (MI355X_MICROARCH.md, HBM).  Only a summary of THIS
+    workload (its `# workload:` line) taken with THIS library's kernel set (`# kernel_symbols_sha256:`) is used;
+    returns (traffic or None, why-not or None)."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.txt")), reverse=True):
-        vals, inside = {}, False
+    want_hash = kernel_symbols_sha256(lib_path)
+    why = "no profiles/*_pmc_summary.txt for workload '{}'".format(workload)
+    for path in sorted(glob.glob(os.path.join(profiles_dir or os.path.join(ROOT, "profiles"), "*_pmc_summary.txt")), reverse=True):
+        vals, inside, head = {}, False, {}
         with open(path) as fh:
             for line in fh:
-                if not line.startswith((" ", "#")):
+                if line.startswith("#"):
+                    m = re.match(r"#\s*(workload|kernel_symbols_sha256):\s*(.+?)\s*$", line)
+                    if m:
+                        head[m.group(1)] = m.group(2)
+                elif not line.startswith(" "):
                     inside = kernel_key in line
                 elif inside and line.split()[0] in ("FETCH_SIZE", "WRITE_SIZE"):
                     vals[line.split()[0]] = float(line.split()[1]) * 1024.0  # KiB
-        if len(vals) == 2:
-            return {"bytes": 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"], "fetch_bytes_corrected": 2.0 * vals["FETCH_SIZE"],
-                    "write_bytes": vals["WRITE_SIZE"], "source": os.path.relpath(path, ROOT)}
-    return None
+        if head.get("workload") != workload or len(vals) != 2:
+            continue
+        if head.get("kernel_symbols_sha256") != want_hash:
+            why = "{} was taken with a library whose kernel set differs from the loaded one: refused".format(
+                os.path.relpath(path, ROOT))
+            continue
+        return {"bytes": 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"], "fetch_bytes_corrected": 2.0 * vals["FETCH_SIZE"],
+                "write_bytes": vals["WRITE_SIZE"], "source": os.path.relpath(path, ROOT),
+                "kernel_symbols_sha256": want_hash[:16]}, None
+    return None, why
 
 
-def main():
-    args = parse()
-    rank, size, _ = launch.world()
+def exclusive_kernel_times(ctx):
+    """{name: {ms_total, launches}} of the timed region.  skr_prof_query matches names exactly, so nested names
+    ("colsum_seq" / "colsum_seq_sq") need no subtraction."""
+    kern = {}
+    for name in ctx.prof_names():
+        ms, cnt = ctx.prof_query(name)
+        kern[name] = {"ms_total": ms, "launches": cnt}
+    return kern
+
+
+def symmetric_selftest(ctx, comm, engine, k, grouped):
+    """Before anything is timed: the half-ring schedule (split first shift, grouped shifts if asked for, CROSS-mode
+    mirror stores) against the plain row-block schedule on a small set — every block this rank owns must equal the
+    row-block result, and every mirrored block its transpose, bit for bit (same kernel arithmetic).  The verdict is
+    all-reduced so that every rank leaves together.  Returns None or the reason."""
+    from seekr_amd import _lib
+    from seekr_amd.distributed import (shard_bounds, sharded_normalize_prepare, sharded_pearson_rowblock,
+                                       sharded_pearson_symmetric)
+    from seekr_amd.synthetic import synthetic_ascii
+    size, rank = comm.size, comm.rank
+    n_total = 600 * size + 37  # ragged shards, more than two tiles each
+    bounds = shard_bounds(n_total, size)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    blob, offsets = synthetic_ascii(SEED + 99, hi - lo, 400, start=lo)
+    packed = _lib.PackedSeqs.from_buffer(ctx, blob, offsets, "AGTC")
+    x = _lib.count_per_kb(ctx, packed, k)
+    z = sharded_normalize_prepare(engine, comm, x, n_total, "Log2.post", True, True, keep_counts=False)[3]
+    max_shard = max(bounds[g + 1] - bounds[g] for g in range(size))
+    n_recv = max(2, size // 2) if grouped else 2
+    recv = [engine.empty_operand(max_shard, 4 ** k) for _ in range(n_recv)]
+    r_row, r_col, r_rb = ctx.zeros(hi - lo, n_total), ctx.zeros(n_total, hi - lo), ctx.zeros(hi - lo, n_total)
+    blocks = sharded_pearson_symmetric(engine, comm, z, bounds, r_row, r_col, recv, grouped=grouped)
+    sharded_pearson_rowblock(engine, comm, z, bounds, r_rb, recv[:2])
+    ctx.sync()
+    row, col, rb = r_row.to_numpy(), r_col.to_numpy(), r_rb.to_numpy()
+    reason = None
+    for which, br, bc, nr, nc, gr, gc in blocks:
+        if which == "row":
+            got, want = row[br:br + nr, bc:bc + nc], rb[br:br + nr, gc:gc + nc]
+            if not np.array_equal(got.view(np.uint32), want.view(np.uint32)) and not np.allclose(got, want, rtol=1e-6, atol=1e-6):
+                reason = "rank {}: block rows {}+{} x cols {}+{} differs from the row-block result (max |d| {:.3g})".format(
+                    rank, gr, nr, gc, nc, float(np.nanmax(np.abs(got - want))))
+                break
+        else:  # the mirror of a block this rank multiplied: r_col[global rows of the peer, own local columns]
+            got, want = col[br:br + nr, bc:bc + nc], row[bc:bc + nc, br:br + nr].T
+            if not np.array_equal(got.view(np.uint32), np.ascontiguousarray(want).view(np.uint32)):
+                reason = "rank {}: mirrored block rows {}+{} is not the transpose of the block it mirrors".format(rank, gr, nr)
+                break
+    if os.environ.get("SEEKR_TEST_HOOKS") == "1" and os.environ.get("SEEKR_BENCH_FAIL_SELFTEST") == str(rank):
+        reason = "rank {}: failure injected by the test hook".format(rank)  # tests/test_gpu_multirank_mock.py
+    bad = comm.allreduce([1.0 if reason else 0.0], "max")[0]
+    for m in (r_row, r_col, r_rb, x):
+        m.free()
+    if bad and not reason:
+        reason = "rank {}: passed here, failed on another rank".format(rank)
+    return reason
+
+
+def run_rank(args):
+    from seekr_amd import _lib, launch as skr_launch
+    from seekr_amd.distributed import (HipEngine, half_ring_plan, shard_bounds, sharded_normalize_prepare,
+                                       sharded_pearson_rowblock, sharded_pearson_symmetric)
+    from seekr_amd.synthetic import synthetic_ascii
+
+    rank, size, _ = skr_launch.world()
     if size != args.gpus:
-        raise SystemExit("--gpus {} but WORLD_SIZE={} (launch with torch.distributed.run)".format(args.gpus, size))
-    ctx, comm = launch.init()
+        raise SystemExit("--gpus {} but WORLD_SIZE={}".format(args.gpus, size))
+    ctx, comm = skr_launch.init()
     k, length = args.k, args.length
     n_cols = 4 ** k
     n_total = args.rows or int(round(50_000 * math.sqrt(size) / size)) * size
@@ -181,6 +403,13 @@ def main():
     lo, hi = bounds[rank], bounds[rank + 1]
     n_loc = hi - lo
     engine = HipEngine(ctx, _lib.PRECISIONS[args.precision], use_symmetry=not args.no_symmetry)
+    symmetric_layout = args.layout == "symmetric" and args.precision != "fp32" and not args.no_symmetry
+
+    if size > 1 and symmetric_layout and not args.no_selftest:
+        why = symmetric_selftest(ctx, comm, engine, k, args.grouped_shifts)
+        if why:
+            print("symmetric schedule self-test FAILED: " + why, file=sys.stderr, flush=True)
+            sys.exit(SELFTEST_EXIT)
 
     # ---- synthetic input, packed and resident in HBM before the timed region
     blob, offsets = synthetic_ascii(SEED, n_loc, length, start=lo)
@@ -188,7 +417,6 @@ def main():
     del blob
     x = ctx.empty(n_loc, n_cols)
     z = engine.empty_operand(n_loc, n_cols)  # row-standardised shard in the contraction's operand layout
-    symmetric_layout = args.layout == "symmetric" and args.precision != "fp32" and not args.no_symmetry
     r = ctx.zeros(n_loc, n_total)
     r_col = ctx.zeros(n_total, n_loc) if (symmetric_layout and size > 1) else None  # mirrored blocks (h, g)
     max_shard = max(bounds[g + 1] - bounds[g] for g in range(size))
@@ -219,17 +447,36 @@ def main():
     ctx.prof_enable(False)
     elapsed = comm.allreduce([elapsed], "max")[0]
 
-    # ---- per-kernel device times of the timed region (HIP events on the ctx stream)
-    kern = {}
-    for name in ctx.prof_names():
-        ms, cnt = ctx.prof_query(name)
-        kern[name] = {"ms_total": ms, "launches": cnt}
-    # prof_query matches by prefix ("colsum_seq" also collects "colsum_seq_sq"): make the entries exclusive
-    for name in sorted(kern, key=len):
-        for longer in kern:
-            if longer != name and longer.startswith(name):
-                kern[name]["ms_total"] -= kern[longer]["ms_total"]
-                kern[name]["launches"] -= kern[longer]["launches"]
+    # ---- per-kernel device times of the timed region (HIP events on the ctx stream; comm_* on the communication stream)
+    kern = exclusive_kernel_times(ctx)
+    steps = args.steps
+    per_rank = None
+    n_ranks_seen = 1
+    if size > 1:
+        n_ranks_seen = int(round(comm.allreduce([1.0], "sum")[0]))
+
+        def gather(value):  # every rank's value, by rank, through all-reduces of one-hot vectors (<= 16 values each)
+            out = []
+            for g0 in range(0, size, 16):
+                vec = [0.0] * min(16, size - g0)
+                if g0 <= rank < g0 + 16:
+                    vec[rank - g0] = float(value)
+                out += comm.allreduce(vec, "sum")
+            return out
+
+        def ms_step(name):
+            return kern.get(name, {"ms_total": 0.0})["ms_total"] / steps
+
+        gemm_names = [n for n in kern if n.startswith("pearson_gemm")]
+        per_rank = {
+            "comm_ms": [round(v, 3) for v in gather(ms_step("comm_xfer"))],
+            "exposed_wait_ms": [round(v, 3) for v in gather(ms_step("comm_wait"))],
+            "chain_wait_ms": [round(v, 3) for v in gather(ms_step("comm_wait_vec"))],
+            "gemm_ms": [round(v, 3) for v in gather(sum(ms_step(n) for n in gemm_names))],
+            "note": "per step and rank: comm_ms = operand-shard transfers on the communication stream (data ready -> "
+                    "arrived, the peer's lateness included); exposed_wait_ms = time the compute stream stood still waiting for a "
+                    "shard (what no kernel hid); chain_wait_ms = the same for the rank-to-rank float32 column-sum chain "
+                    "(serial by construction: rank g waits for ranks < g)"}
     gemm_name = {"fp32": "pearson_gemm_f32", "bf16x3": "pearson_gemm_bf16x3", "bf16x4": "pearson_gemm_bf16x4",
                  "f16x3": "pearson_gemm_f16x3"}[args.precision]
     gemm = kern.get(gemm_name, {"ms_total": 0.0, "launches": 0})
@@ -237,7 +484,6 @@ def main():
 
     if rank != 0:
         return
-    steps = args.steps
     pairs_per_step = float(n_total) * n_total
     value = pairs_per_step * steps / elapsed / 1e6
     # Dominant kernel: the Pearson contraction (MFMA bound), 2*4^k algorithmic flop per pair it
@@ -259,17 +505,17 @@ def main():
     multiplied_tf = 2.0 * n_cols * exec_pairs / (gemm_ms_step * 1e-3) / 1e12 if gemm_ms_step > 0 else 0.0
     nprod = {"fp32": 1, "bf16x3": 3, "bf16x4": 4, "f16x3": 3}[args.precision]
     peak_tf = PEAK["fp32_mfma_tflops"] if args.precision == "fp32" else PEAK["bf16_mfma_tflops"]
-    # PMC traffic was collected on the default 1-GPU workload; it describes other shapes only by analogy
-    default_shape = size == 1 and not args.rows and length == 2000 and k == 6 and not args.no_symmetry
+    # PMC traffic: from the committed summary of this very workload, taken with this library's kernel set — else null
     gemm_key = {"fp32": "pearson_gemm_f32_kernel", "bf16x3": "split16_kernelIDF16bLi3", "bf16x4": "split16_kernelIDF16bLi4",
                 "f16x3": "split16_kernelIDF16_Li3"}[args.precision]
-    gemm_traffic = pmc_traffic(gemm_key) if default_shape else None
-    count_traffic = pmc_traffic("count_rows_kernel<0") if default_shape else None  # <0, ...>: the float32, non-Log2.pre instantiation
+    wl = workload_key(n_total, length, k, args.precision, size)
+    gemm_traffic, gemm_why = (None, "--no-symmetry") if args.no_symmetry else pmc_traffic(gemm_key, wl, _lib.LIB_PATH)
+    count_traffic, count_why = pmc_traffic("count_rows_kernel<0", wl, _lib.LIB_PATH)  # <0, ...>: the float32, non-Log2.pre instantiation
     roofline = {"kernel": gemm_name, "bound": "mfma", "achieved": round(achieved_tf, 2), "peak": peak_tf,
                 "unit": "TFLOP/s", "frac": round(achieved_tf / peak_tf, 4),
                 "traffic": round(gemm_traffic["bytes"] / 1e9, 2) if gemm_traffic else None,
                 "traffic_unit": "GB per launch (HBM-side: 2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)",
-                "traffic_detail": gemm_traffic,
+                "traffic_detail": gemm_traffic if gemm_traffic else {"unavailable": gemm_why},
                 "algorithmic_bytes_gb": round((2.0 * n_loc * n_cols * 4 + 4.0 * n_loc * n_total) / 1e9, 2),
                 "avg_launch_ms": round(gemm_avg_ms, 4), "launches_per_step": gemm["launches"] // max(steps, 1),
                 "multiplied_tflops": round(multiplied_tf, 2), "multiplied_frac": round(multiplied_tf / peak_tf, 4),
@@ -289,7 +535,7 @@ def main():
     roofline_count = {"kernel": "count_kmers_f32", "bound": "hbm", "achieved": round(count_gbs, 1),
                       "peak": PEAK["hbm_gbs"], "unit": "GB/s", "frac": round(count_gbs / PEAK["hbm_gbs"], 4),
                       "traffic": round(count_traffic["bytes"] / 1e9, 3) if count_traffic else None,
-                      "traffic_unit": "GB per launch", "traffic_detail": count_traffic,
+                      "traffic_unit": "GB per launch", "traffic_detail": count_traffic if count_traffic else {"unavailable": count_why},
                       "algorithmic_bytes_gb": round(count_bytes / 1e9, 3), "avg_launch_ms": round(count_avg_ms, 4),
                       "bytes_per_base": round(count_bytes / (n_loc * length), 3)}
     out = {
@@ -312,6 +558,13 @@ def main():
         "roofline": roofline, "roofline_count": roofline_count,
         "kernels_ms_per_step": {n: round(v["ms_total"] / steps, 4) for n, v in sorted(kern.items())},
     }
+    if size > 1:
+        out["n_ranks_seen"] = n_ranks_seen
+        out["per_rank"] = per_rank
+        out["selftest"] = ("skipped" if args.no_selftest or not symmetric_layout
+                           else "half-ring schedule == row-block schedule on a small set, on every rank")
+    if os.environ.get("SEEKR_BENCH_FALLBACK"):
+        out["layout_fallback"] = os.environ["SEEKR_BENCH_FALLBACK"]
     if size == 1:
         # correctness probe of the r this run produced, outside the timed region: 32 random rows x all columns
         # against the oracle on the host copy of the normalised counts (x holds them: keep_counts=True)
@@ -321,7 +574,7 @@ def main():
         out["verified_detail"] = {"rows": min(32, n_loc), "columns": n_total, "worst_error_over_bar": round(worst, 4),
                                   "bar": "|dr| <= 2e-6 + 1e-5 |r| against oracle.pearson (pearson.py:35-41)"}
     if size == 1 and not args.no_cpu_baseline:
-        head = x_host[:min(12000, n_loc)]
+        head = x_host[:min(12000 if k <= 6 else 4000, n_loc)]
         cb = cpu_baseline(k, length, head)
         t_cpu = n_total * length / cb["rate_bases"] + pairs_per_step / cb["rate_pairs"]
         out["cpu_baseline"] = {
@@ -338,8 +591,16 @@ def main():
         out["speedup_vs_cpu_port"] = round(value / out["cpu_baseline"]["value"], 1)
         del x_host, head
         r.free()
-        out["e2e"] = end_to_end(ctx, k, length, min(n_total, 50000), args.precision)
+        out["e2e"] = end_to_end(ctx, k, length, min(n_total, 50000 if k <= 6 else 12000), args.precision)
     print(json.dumps(out), flush=True)
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch(args, argv))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -71,11 +71,16 @@ int skr_ctx_create(int device, skr_ctx** out);
 int skr_ctx_destroy(skr_ctx* ctx);
 int skr_ctx_sync(skr_ctx* ctx);
 int skr_ctx_device(const skr_ctx* ctx, int* device);
+/* The SEEKR_GEMM_* / SEEKR_COUNT_* A/B switches are read from the environment when the ctx is created;
+ * this reads them again (bench tools that interleave variants in one process).  No launch calls getenv.            */
+int skr_ctx_reload_knobs(skr_ctx* ctx);
 /* device-side timing of every kernel launched through the ctx (HIP events on the ctx stream) */
 int skr_prof_enable(skr_ctx* ctx, int on);
 int skr_prof_reset(skr_ctx* ctx);
-/* total milliseconds and launch count recorded for kernels whose name starts with `prefix` */
-int skr_prof_query(skr_ctx* ctx, const char* prefix, double* total_ms, int64_t* launches);
+/* total milliseconds and launch count recorded under exactly `name` (skr_prof_names lists the names seen).  Besides
+ * the kernels: "comm_xfer" / "comm_vec" = transfers on the communication stream (row blocks / statistic vectors),
+ * "comm_wait" / "comm_wait_vec" = how long the compute stream stood still waiting for one (the exposed part).   */
+int skr_prof_query(skr_ctx* ctx, const char* name, double* total_ms, int64_t* launches);
 /* names of all recorded kernels, '\n'-separated, into buf (truncated to cap-1 chars) */
 int skr_prof_names(skr_ctx* ctx, char* buf, int64_t cap);
 
@@ -373,11 +378,16 @@ int skr_comm_allreduce_f64(skr_ctx* ctx, double* values, int n, int op);
 
 
 /* ---------------------------------------------------------------- diagnostics ------------- */
-/* With SEEKR_GEMM_DIAG=1 in the environment the split-fp16 contraction runs a diagnostic build
- * whose workgroups stamp s_memtime / s_memrealtime around the k loop and the epilogue of every
- * tile (in-kernel clock and phase anatomy; MI355X_MICROARCH.md "DVFS give-back" item 6).  This
- * copies the records of the last such launch to the host: out[max_records][8] uint64.          */
+/* NOT part of libseekr_hip.so.  A second library, libseekr_hip_diag.so (python -m seekr_amd.build --diag: the same
+ * sources with -DSEEKR_DIAG), additionally holds a build of the split-fp16 contraction whose workgroups stamp
+ * s_memtime / s_memrealtime around the k loop and the epilogue of every tile (in-kernel clock and phase anatomy;
+ * MI355X_MICROARCH.md "DVFS give-back" item 6; tools/gemm_diag.py).  skr_gemm_diag_mode selects it for the ctx
+ * (0 = production kernels, 1 = stamps, 2-4 = timing experiments whose r is meaningless); skr_gemm_diag_read copies
+ * the records of the last such launch to the host: out[max_records][8] uint64.                                     */
+#ifdef SEEKR_DIAG
+int skr_gemm_diag_mode(skr_ctx* ctx, int mode);
 int skr_gemm_diag_read(skr_ctx* ctx, unsigned long long* out, int64_t max_records, int64_t* n_records);
+#endif
 
 #ifdef __cplusplus
 }

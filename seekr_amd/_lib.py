@@ -13,6 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libseekr_hip.so")
+DIAG_LIB_PATH = os.path.join(_HERE, "libseekr_hip_diag.so")
 
 SKR_OK = 0
 F32, F64, U32 = 0, 1, 2
@@ -36,6 +37,7 @@ SIGNATURES = {
     "skr_ctx_destroy": (_int, [_p]),
     "skr_ctx_sync": (_int, [_p]),
     "skr_ctx_device": (_int, [_p, C.POINTER(_int)]),
+    "skr_ctx_reload_knobs": (_int, [_p]),
     "skr_prof_enable": (_int, [_p, _int]),
     "skr_prof_reset": (_int, [_p]),
     "skr_prof_query": (_int, [_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64)]),
@@ -106,6 +108,10 @@ SIGNATURES = {
     "skr_comm_exchange": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(_i64)]),
     "skr_comm_wait": (_int, [_p, _i64]),
     "skr_comm_allreduce_f64": (_int, [_p, C.POINTER(C.c_double), _int, _int]),
+}
+# libseekr_hip_diag.so only (tools/gemm_diag.py sets LIB_PATH to it before the first call)
+DIAG_SIGNATURES = {
+    "skr_gemm_diag_mode": (_int, [_p, _int]),
     "skr_gemm_diag_read": (_int, [_p, _p, _i64, C.POINTER(_i64)]),
 }
 
@@ -141,7 +147,8 @@ def lib():
                 "seekr_amd: {} is missing — build it with `python -m seekr_amd.build` "
                 "(hipcc, gfx950). There is no CPU fallback.".format(LIB_PATH))
         handle = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        sigs = dict(SIGNATURES, **DIAG_SIGNATURES) if LIB_PATH == DIAG_LIB_PATH else SIGNATURES
+        for name, (res, args) in sigs.items():
             fn = getattr(handle, name)  # AttributeError if the .so is stale
             fn.restype = res
             fn.argtypes = args
@@ -199,6 +206,10 @@ class Context:
     def sync(self):
         check(lib().skr_ctx_sync(self._h))
 
+    def reload_knobs(self):
+        """Re-read the SEEKR_GEMM_* / SEEKR_COUNT_* A/B switches from os.environ (they are otherwise read once, at creation)."""
+        check(lib().skr_ctx_reload_knobs(self._h))
+
     # ---- profiling -----------------------------------------------------------------
     def prof_enable(self, on=True):
         check(lib().skr_prof_enable(self._h, 1 if on else 0))
@@ -206,9 +217,10 @@ class Context:
     def prof_reset(self):
         check(lib().skr_prof_reset(self._h))
 
-    def prof_query(self, prefix):
+    def prof_query(self, name):
+        """(total ms, launches) recorded under exactly `name` (prof_names lists them)."""
         ms, cnt = C.c_double(0), _i64(0)
-        check(lib().skr_prof_query(self._h, prefix.encode(), C.byref(ms), C.byref(cnt)))
+        check(lib().skr_prof_query(self._h, name.encode(), C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
 
     def prof_names(self):

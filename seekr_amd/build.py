@@ -1,4 +1,8 @@
-"""Build libseekr_hip.so (hipcc, gfx950 only) in-tree.  `python -m seekr_amd.build [--force]`."""
+"""Build libseekr_hip.so (hipcc, gfx950 only) in-tree.  `python -m seekr_amd.build [--force] [--diag]`.
+
+`--diag` additionally links libseekr_hip_diag.so: the same objects except pearson_bf16.hip, which is compiled a second
+time with -DSEEKR_DIAG (the stamping instance of the contraction and its timing experiments, tools/gemm_diag.py).  The
+production library holds none of that."""
 import os
 import subprocess
 import sys
@@ -8,6 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libseekr_hip.so")
+DIAG_LIB = os.path.join(HERE, "libseekr_hip_diag.so")
+DIAG_SOURCES = ["pearson_bf16.hip"]  # compiled a second time with -DSEEKR_DIAG for the diagnostic library
 SOURCES = ["ctx.hip", "pack.hip", "count.hip", "normalize.hip", "pearson.hip", "pearson_bf16.hip", "operand.hip",
            "consumers.hip", "fused_edges.hip", "comm.hip", "io.hip", "csv_read.hip", "host_api.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -27,7 +33,7 @@ def _newer(src, dst, extra=()):
     return any(os.path.getmtime(p) > t for p in (src, *extra))
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, diag=False):
     os.makedirs(OBJDIR, exist_ok=True)
     headers = [os.path.join(CSRC, "common.hpp"), os.path.join(HERE, "..", "include", "seekr_hip.h"),
                os.path.abspath(__file__)]
@@ -40,6 +46,15 @@ def build(force=False, verbose=True):
         objs.append(obj)
         if force or _newer(src, obj, headers):
             jobs.append([HIPCC, *COMMON, *PER_FILE.get(name, []), "-c", src, "-o", obj])
+    diag_objs, diag_jobs = list(objs), 0
+    if diag:
+        for name in DIAG_SOURCES:
+            src = os.path.join(CSRC, name)
+            obj = os.path.join(OBJDIR, name.replace(".hip", ".diag.o"))
+            diag_objs[SOURCES.index(name)] = obj
+            if force or _newer(src, obj, headers):
+                jobs.append([HIPCC, *COMMON, *PER_FILE.get(name, []), "-DSEEKR_DIAG", "-c", src, "-o", obj])
+                diag_jobs += 1
 
     def run(cmd):
         if verbose:
@@ -52,10 +67,12 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=4) as pool:
         list(pool.map(run, jobs))
-    if jobs or force or not os.path.exists(LIB):
+    if len(jobs) > diag_jobs or force or not os.path.exists(LIB):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl", "-lpthread"])
+    if diag and (jobs or force or not os.path.exists(DIAG_LIB)):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", DIAG_LIB, *diag_objs, "-ldl", "-lpthread"])
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, diag="--diag" in sys.argv))

@@ -68,7 +68,7 @@ int load_rccl() {
 
 // completion event of what was just enqueued on comm_stream; *ticket (optional) identifies it for skr_comm_wait.
 // With ticket == NULL nothing is recorded: the exchange is ordered on comm_stream only (fire and forget).
-int issue_ticket(skr_ctx* ctx, int64_t* ticket) {
+int issue_ticket(skr_ctx* ctx, int64_t* ticket, bool vec = false) {
     if (!ticket) return SKR_OK;
     int slot;
     if (!ctx->free_tickets.empty()) {
@@ -83,6 +83,7 @@ int issue_ticket(skr_ctx* ctx, int64_t* ticket) {
     if (!t.ev) SKR_HIP(hipEventCreateWithFlags(&t.ev, hipEventDisableTiming));
     SKR_HIP(hipEventRecord(t.ev, ctx->comm_stream));
     t.live = true;
+    t.vec = vec;
     t.gen++;
     *ticket = ((int64_t)t.gen << 16) | slot;
     return SKR_OK;
@@ -159,6 +160,10 @@ extern "C" int skr_comm_sendrecv(skr_ctx* ctx, const skr_mat* src, int64_t srow0
     }
     ncclComm_t comm = (ncclComm_t)ctx->comm;
     SKR_TRY(comm_after_compute(ctx));
+    // "comm_xfer": on the communication stream, from the moment the data is ready to the end of the transfer (peer's
+    // lateness included); vectors of the column-sum chain (one row) are booked separately as "comm_vec"
+    const bool vec = (do_send ? snrows : dnrows) <= 1;
+    SkrProfScope prof(ctx, vec ? "comm_vec" : "comm_xfer", ctx->comm_stream);
     SKR_NCCL(g_api.GroupStart());
     if (do_send) {
         const size_t rb = (size_t)src->cols * src->elem();
@@ -171,7 +176,7 @@ extern "C" int skr_comm_sendrecv(skr_ctx* ctx, const skr_mat* src, int64_t srow0
                             ctx->comm_stream));
     }
     SKR_NCCL(g_api.GroupEnd());
-    return issue_ticket(ctx, ticket);
+    return issue_ticket(ctx, ticket, vec);
 }
 
 // Several exchanges as ONE grouped RCCL operation: xGMI is point-to-point, so transfers to / from different peers
@@ -194,6 +199,7 @@ extern "C" int skr_comm_exchange(skr_ctx* ctx, int n, const skr_mat* const* src,
     }
     ncclComm_t comm = (ncclComm_t)ctx->comm;
     SKR_TRY(comm_after_compute(ctx));
+    SkrProfScope prof(ctx, "comm_xfer", ctx->comm_stream);
     SKR_NCCL(g_api.GroupStart());
     for (int i = 0; i < n; i++) {
         if (dst_rank[i] >= 0 && snrows[i] > 0) {
@@ -228,6 +234,7 @@ extern "C" int skr_comm_allgather_rows(skr_ctx* ctx, const skr_mat* shard, skr_m
     ncclComm_t comm = (ncclComm_t)ctx->comm;
     const size_t rb = (size_t)full->cols * full->elem();
     SKR_TRY(comm_after_compute(ctx));
+    SkrProfScope prof(ctx, "comm_xfer", ctx->comm_stream);
     if (shard->rows && shard->data != (char*)full->data + (size_t)bounds[me] * rb)
         SKR_HIP(hipMemcpyAsync((char*)full->data + (size_t)bounds[me] * rb, shard->data, (size_t)shard->rows * rb,
                                hipMemcpyDeviceToDevice, ctx->comm_stream));
@@ -249,7 +256,12 @@ extern "C" int skr_comm_wait(skr_ctx* ctx, int64_t ticket) {
     const int64_t slot = ticket & 0xFFFF;
     SKR_REQUIRE(ticket >= 0 && slot < (int64_t)ctx->tickets.size() && ctx->tickets[slot].live &&
                     (int64_t)ctx->tickets[slot].gen == (ticket >> 16), "unknown ticket (each ticket is waited on once)");
-    SKR_HIP(hipStreamWaitEvent(ctx->stream, ctx->tickets[slot].ev, 0));
+    {
+        // "comm_wait": on the compute stream, from the end of the work enqueued before the wait to the moment the exchange
+        // has arrived = the part of a transfer that no kernel hid (0 when the data was there already)
+        SkrProfScope prof(ctx, ctx->tickets[slot].vec ? "comm_wait_vec" : "comm_wait");
+        SKR_HIP(hipStreamWaitEvent(ctx->stream, ctx->tickets[slot].ev, 0));
+    }
     // a ticket is waited on once: the dependency is now in the compute stream; the slot and its event are recycled
     ctx->tickets[slot].live = false;
     ctx->free_tickets.push_back((int)slot);

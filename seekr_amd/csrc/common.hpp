@@ -5,13 +5,33 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <map>
 #include <string>
 #include <vector>
 
 #include "../../include/seekr_hip.h"
 
+// A/B switches of the measurements in DESIGN §4, read from the environment ONCE, when the ctx is created
+// (INTEGRATION.md lists them); a launch never calls getenv.
+struct SkrKnobs {
+    bool gemm_persist = true;    // SEEKR_GEMM_PERSIST=0: one workgroup per tile instead of the persistent grid
+    int gemm_chunk_tiles = 0;    // SEEKR_GEMM_CHUNK_TILES: k tiles per accumulator restart (0 = the operand's own choice)
+    int gemm_reserve_cus = -1;   // SEEKR_GEMM_RESERVE_CUS: CUs left to RCCL's kernels (-1 = 8 with a communicator, else 0)
+    int gemm_subtile = 0;        // SEEKR_GEMM_SUBTILE: XCD sub-tile shape of the contraction's tile order (0 = 8 x 4, 1 = 4 x 4 pairs, 2 = 16 x 2)
+    int gemm_wave_tile = 0;      // SEEKR_GEMM_WAVE_TILE=1: the 4-wave 128 x 128 wave-tile arm (A/B, tools/gemm_bench.py)
+    int count_percu = 0;         // SEEKR_COUNT_PERCU: cap on resident workgroups per CU (0 = none)
+    bool count_persist = false;  // SEEKR_COUNT_PERSIST=1: persistent grid at k <= 6
+    bool count_legacy = false;   // SEEKR_COUNT_LEGACY=1: the round-1 counting kernel
+    int count_wps = 0;           // SEEKR_COUNT_WPS: waves per sequence (0 = by k)
+};
+
 struct skr_ctx {
     int device = 0;
+    SkrKnobs knobs;
+    int diag_mode = 0;  // libseekr_hip_diag.so only (skr_gemm_diag_mode); the production library never reads it
+    // kernels whose dynamic-LDS limit has been raised (hipFuncSetAttribute is called once per kernel and size, not per launch)
+    std::map<const void*, int> lds_attr;
+    std::map<std::pair<const void*, size_t>, int> occupancy;  // hipOccupancyMaxActiveBlocksPerMultiprocessor results
     hipStream_t stream = nullptr;       // compute stream
     hipStream_t comm_stream = nullptr;  // RCCL traffic, overlapped with compute
     int num_cu = 256;
@@ -45,6 +65,7 @@ struct skr_ctx {
         hipEvent_t ev = nullptr;
         uint32_t gen = 0;
         bool live = false;
+        bool vec = false;  // a statistic vector of the column-sum chain (booked apart from the operand shifts)
     };
     std::vector<Ticket> tickets;
     std::vector<int> free_tickets;
@@ -107,15 +128,19 @@ int skr_set_error(int code, const char* fmt, ...);
         if (rc_ != SKR_OK) return rc_; \
     } while (0)
 
-// Scoped kernel timer: records a start/stop event pair on the ctx stream when profiling is on.
+// Scoped kernel timer: records a start/stop event pair on the ctx stream (or the given one: the communication
+// stream's transfers) when profiling is on.
 struct SkrProfScope {
     skr_ctx* ctx;
     int idx = -1;
-    SkrProfScope(skr_ctx* c, const char* name);
+    hipStream_t stream;
+    SkrProfScope(skr_ctx* c, const char* name, hipStream_t on = nullptr);
     ~SkrProfScope();
 };
 
 int skr_ctx_workspace(skr_ctx* ctx, size_t bytes, void** out);
+// raise a kernel's dynamic shared memory limit to at least `bytes` (first launch of that kernel on this ctx only)
+int skr_kernel_lds(skr_ctx* ctx, const void* kern, size_t bytes);
 // pinned host buffer of at least `bytes`, free to be overwritten (the previous asynchronous copy out of it has
 // finished); after enqueueing a copy from it on ctx->stream call skr_ctx_pinned_used
 int skr_ctx_pinned(skr_ctx* ctx, size_t bytes, void** out);
@@ -126,7 +151,14 @@ int skr_launch_gemm_f32(skr_ctx* ctx, const float* A, const float* B, float* C, 
 int skr_launch_gemm_f64(skr_ctx* ctx, const double* A, const double* B, double* C, int64_t M, int64_t N, int64_t K,
                         int64_t lda, int64_t ldb, int64_t ldc, double kdiv, int symmetric);
 int skr_launch_gemm_split(skr_ctx* ctx, int precision, const void* As, const void* Bs, float* C, int64_t M, int64_t N,
-                          int64_t kt, int64_t ldc, float kdiv, int mode, float* Ct, int64_t ldct, int chunk_tiles = 128);
+                          int64_t kt, int64_t ldc, float kdiv, int mode, float* Ct, int64_t ldct, bool coherent = false);
+
+// k tiles per accumulator restart of the split contraction (pearson_bf16.hip: launch16): 128 (4 096 columns), 64 for
+// operands whose rows are mostly one repeated value; SEEKR_GEMM_CHUNK_TILES overrides both.  One rule for the
+// contraction and for every caller that must know whether a launch will have more than one k chunk (fused_edges.hip).
+inline int64_t skr_gemm_chunk_tiles(const skr_ctx* ctx, bool coherent) {
+    return ctx->knobs.gemm_chunk_tiles ? ctx->knobs.gemm_chunk_tiles : (coherent ? 64 : 128);
+}
 
 // Where the EDGES mode of the split contraction appends the cells that survive a threshold (pearson_bf16.hip).
 struct SkrEdgeSink {
@@ -139,7 +171,7 @@ struct SkrEdgeSink {
     int upper;
 };
 int skr_launch_gemm_edges(skr_ctx* ctx, int precision, const void* As, const void* Bs, float* C, int64_t M, int64_t N,
-                          int64_t kt, int64_t ldc, float kdiv, int chunk_tiles, const SkrEdgeSink& sink);
+                          int64_t kt, int64_t ldc, float kdiv, bool coherent, const SkrEdgeSink& sink);
 
 // A Pearson operand prepared for the matrix cores.  Storage is kt*32 float-sized words per row
 // (kt = ceil(cols/32)) in both layouts: zero-padded float32, or split-interleaved 16-bit halves

@@ -485,15 +485,21 @@ int launch_rows(skr_ctx* ctx, const skr_seqs* s, int k, void* out) {
     const uint32_t nbins = 1u << (2 * k);
     const size_t lds = ((size_t)std::max<uint32_t>(4u, nbins >> 1) + 64 + kTabSize) * 4;
     auto grid_for_kernel = [&](const void* kern, int threads, int64_t items, unsigned* grid) -> int {
-        SKR_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SKR_TRY(skr_kernel_lds(ctx, kern, lds));
         int per_cu = 0;
-        SKR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds));
+        auto occ = ctx->occupancy.find({kern, lds});
+        if (occ == ctx->occupancy.end()) {
+            SKR_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds));
+            ctx->occupancy[{kern, lds}] = per_cu;
+        } else {
+            per_cu = occ->second;
+        }
         per_cu = std::max(1, std::min(per_cu, 2048 / threads));
         // Row streams in flight chip-wide: every wave (k <= 6) writes its own 16 KiB row.  12 per CU (3 072 rows, a 50 MB
         // window) wrote 6-10 % faster than the 19 the LDS allows, most clearly right after a kernel that left the caches
         // dirty (tools/count_bench.py --pre gemm: 0.155 vs 0.170 ms at 50 000 x 2 kb) — the HBM prefers fewer streams.
         per_cu = std::min(per_cu, 768 / threads);  // 12 waves per CU: 12 rows (k <= 6) or 3 rows of 64 KiB (k = 7) in flight
-        if (getenv("SEEKR_COUNT_PERCU")) per_cu = std::min(per_cu, atoi(getenv("SEEKR_COUNT_PERCU")));  // A/B knob
+        if (ctx->knobs.count_percu) per_cu = std::min(per_cu, ctx->knobs.count_percu);  // A/B knob
         // persistent, statically strided items: every workgroup must be resident from the start
         *grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(items, (int64_t)ctx->num_cu * per_cu));
         return SKR_OK;
@@ -508,7 +514,7 @@ int launch_rows(skr_ctx* ctx, const skr_seqs* s, int k, void* out) {
     // grid whose waves stride through the sequences drifts apart.  Measured behind a contraction, 50 000 x 2 kb:
     // 0.146 ms against 0.165 for the persistent grid of 12 waves per CU (which needs the cap: 19 are slower still),
     // k = 5: 0.100 vs 0.108.  Four waves per sequence (k = 7) measure the same either way and stay persistent.
-    const bool persistent = WPS > 1 || (getenv("SEEKR_COUNT_PERSIST") && atoi(getenv("SEEKR_COUNT_PERSIST")));  // A/B knob
+    const bool persistent = WPS > 1 || ctx->knobs.count_persist;  // A/B knob
     if (!persistent) grid = (unsigned)std::min<int64_t>(s->n, 0x7fffffff);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WPS * 64), lds, ctx->stream, a);
     SKR_HIP(hipGetLastError());
@@ -594,18 +600,16 @@ int launch_count(skr_ctx* ctx, const skr_seqs* s, int k, void* out, const char* 
         return SKR_OK;
     }
     if (s->n < 1) return SKR_OK;
-    const bool legacy = getenv("SEEKR_COUNT_LEGACY") && atoi(getenv("SEEKR_COUNT_LEGACY")) &&
-                        s->max_len - k + 1 <= 65535;  // A/B knob (tools/count_bench.py): the round-1 kernel
+    const bool legacy = ctx->knobs.count_legacy && s->max_len - k + 1 <= 65535;  // A/B knob (tools/count_bench.py): the round-1 kernel
     if (OUT != OUT_F64 && !legacy) {
         SkrProfScope prof(ctx, name);
         // k <= 6: one wave per sequence (8 KiB of bins at k = 6); k = 7: 32 KiB of bins shared by four waves
-        const int wps = getenv("SEEKR_COUNT_WPS") ? atoi(getenv("SEEKR_COUNT_WPS")) : (k <= 6 ? 1 : 4);  // A/B knob
+        const int wps = ctx->knobs.count_wps ? ctx->knobs.count_wps : (k <= 6 ? 1 : 4);  // A/B knob
         constexpr int O = OUT == OUT_F64 ? OUT_F32 : OUT;  // (never instantiated for float64)
         return wps == 1 ? launch_rows<O, 1>(ctx, s, k, out) : launch_rows<O, 4>(ctx, s, k, out);
     }
     const size_t lds = (size_t)4 << (2 * k);
-    SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(count_kmers_kernel<OUT, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SKR_TRY(skr_kernel_lds(ctx, reinterpret_cast<const void*>(count_kmers_kernel<OUT, false>), lds));
     // as many resident workgroups as LDS allows, capped by the wave limit (8 x 256 threads / CU)
     int per_cu = (int)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(lds, 1));
     if (per_cu < 1) per_cu = 1;

@@ -1,4 +1,6 @@
 // Context, device matrices, error plumbing and per-kernel HIP-event profiling.
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.hpp"
@@ -34,6 +36,28 @@ int skr_activate(const skr_ctx* ctx) {
     return SKR_OK;
 }
 
+// The A/B switches of DESIGN §4 (INTEGRATION.md lists them): read when the ctx is created, and again only when a
+// bench tool asks for it after changing its environment (tools/gemm_bench.py, tools/count_bench.py interleave variants
+// in one process).  No launch path calls getenv.
+extern "C" int skr_ctx_reload_knobs(skr_ctx* c) {
+    SKR_REQUIRE(c, "ctx is NULL");
+    auto env_int = [](const char* name, int dflt) {
+        const char* v = getenv(name);
+        return v && *v ? atoi(v) : dflt;
+    };
+    SkrKnobs& kn = c->knobs;
+    kn.gemm_persist = env_int("SEEKR_GEMM_PERSIST", 1) != 0;
+    kn.gemm_chunk_tiles = std::max(0, env_int("SEEKR_GEMM_CHUNK_TILES", 0));
+    kn.gemm_reserve_cus = env_int("SEEKR_GEMM_RESERVE_CUS", -1);
+    kn.gemm_subtile = env_int("SEEKR_GEMM_SUBTILE", 0);
+    kn.gemm_wave_tile = env_int("SEEKR_GEMM_WAVE_TILE", 0);
+    kn.count_percu = std::max(0, env_int("SEEKR_COUNT_PERCU", 0));
+    kn.count_persist = env_int("SEEKR_COUNT_PERSIST", 0) != 0;
+    kn.count_legacy = env_int("SEEKR_COUNT_LEGACY", 0) != 0;
+    kn.count_wps = env_int("SEEKR_COUNT_WPS", 0);
+    return SKR_OK;
+}
+
 extern "C" int skr_ctx_create(int device, skr_ctx** out) {
     SKR_REQUIRE(out, "out is NULL");
     *out = nullptr;
@@ -50,6 +74,7 @@ extern "C" int skr_ctx_create(int device, skr_ctx** out) {
     skr_ctx* c = new skr_ctx();
     c->device = device;
     c->num_cu = prop.multiProcessorCount;
+    skr_ctx_reload_knobs(c);
     SKR_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     SKR_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
     SKR_HIP(hipMalloc((void**)&c->d_flags, 64 * sizeof(uint32_t)));
@@ -105,6 +130,14 @@ extern "C" int skr_ctx_device(const skr_ctx* ctx, int* device) {
     return SKR_OK;
 }
 
+int skr_kernel_lds(skr_ctx* ctx, const void* kern, size_t bytes) {
+    auto it = ctx->lds_attr.find(kern);
+    if (it != ctx->lds_attr.end() && (size_t)it->second >= bytes) return SKR_OK;
+    SKR_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    ctx->lds_attr[kern] = (int)bytes;
+    return SKR_OK;
+}
+
 int skr_ctx_workspace(skr_ctx* ctx, size_t bytes, void** out) {
     if (bytes > ctx->ws_bytes) {
         SKR_HIP(hipStreamSynchronize(ctx->stream));
@@ -140,7 +173,7 @@ int skr_ctx_pinned_used(skr_ctx* ctx) {
 }
 
 // ---------------------------------------------------------------- profiling -------------
-SkrProfScope::SkrProfScope(skr_ctx* c, const char* name) : ctx(c) {
+SkrProfScope::SkrProfScope(skr_ctx* c, const char* name, hipStream_t on) : ctx(c), stream(on ? on : c->stream) {
     if (!c->prof) return;
     skr_ctx::ProfRec rec;
     rec.name = name;
@@ -152,13 +185,13 @@ SkrProfScope::SkrProfScope(skr_ctx* c, const char* name) : ctx(c) {
         if (hipEventCreate(&rec.start) != hipSuccess) return;
         if (hipEventCreate(&rec.stop) != hipSuccess) return;
     }
-    (void)hipEventRecord(rec.start, c->stream);
+    (void)hipEventRecord(rec.start, stream);
     c->prof_recs.push_back(rec);
     idx = (int)c->prof_recs.size() - 1;
 }
 
 SkrProfScope::~SkrProfScope() {
-    if (idx >= 0) (void)hipEventRecord(ctx->prof_recs[idx].stop, ctx->stream);
+    if (idx >= 0) (void)hipEventRecord(ctx->prof_recs[idx].stop, stream);
 }
 
 extern "C" int skr_prof_enable(skr_ctx* ctx, int on) {
@@ -170,20 +203,21 @@ extern "C" int skr_prof_enable(skr_ctx* ctx, int on) {
 extern "C" int skr_prof_reset(skr_ctx* ctx) {
     SKR_TRY(skr_activate(ctx));
     SKR_HIP(hipStreamSynchronize(ctx->stream));
+    SKR_HIP(hipStreamSynchronize(ctx->comm_stream));
     for (auto& r : ctx->prof_recs) ctx->event_pool.emplace_back(r.start, r.stop);
     ctx->prof_recs.clear();
     return SKR_OK;
 }
 
-extern "C" int skr_prof_query(skr_ctx* ctx, const char* prefix, double* total_ms, int64_t* launches) {
-    SKR_REQUIRE(ctx && prefix && total_ms && launches, "NULL argument");
+extern "C" int skr_prof_query(skr_ctx* ctx, const char* name, double* total_ms, int64_t* launches) {
+    SKR_REQUIRE(ctx && name && total_ms && launches, "NULL argument");
     SKR_TRY(skr_activate(ctx));
     SKR_HIP(hipStreamSynchronize(ctx->stream));
+    SKR_HIP(hipStreamSynchronize(ctx->comm_stream));  // "comm_xfer" scopes are recorded there
     double tot = 0;
     int64_t cnt = 0;
-    size_t plen = strlen(prefix);
     for (auto& r : ctx->prof_recs) {
-        if (r.name.compare(0, plen, prefix) != 0) continue;
+        if (r.name != name) continue;  // exact: "colsum_seq" does not collect "colsum_seq_sq"
         float ms = 0;
         SKR_HIP(hipEventElapsedTime(&ms, r.start, r.stop));
         tot += ms;

@@ -35,11 +35,12 @@ extern "C" int skr_pearson_gemm_edges(skr_ctx* ctx, const skr_operand* a, const 
     const int64_t M = a->rows, N = b->rows, K = a->cols;
     SKR_REQUIRE(row_global0 >= 0 && col_global0 >= 0 && row_global0 + M <= 0xffffffffLL && col_global0 + N <= 0xffffffffLL,
                 "global indices must fit 32 bits");
-    const int chunk = (a->coherent || b->coherent) ? 64 : 128;
+    const bool coherent = a->coherent || b->coherent;
+    const int64_t chunk = skr_gemm_chunk_tiles(ctx, coherent);  // the rule the contraction itself applies (knob included)
     const bool multi_chunk = a->kt > chunk;
     if (multi_chunk)
         SKR_REQUIRE(scratch && scratch->ctx == ctx && scratch->dtype == SKR_F32 && scratch->rows >= M && scratch->cols >= N,
-                    "rows of more than %d columns need a float32 scratch block of at least [%lld, %lld]", chunk * 32, (long long)M,
+                    "rows of more than %lld columns need a float32 scratch block of at least [%lld, %lld]", (long long)(chunk * 32), (long long)M,
                     (long long)N);
     SKR_TRY(skr_activate(ctx));
     *count = 0;
@@ -73,7 +74,7 @@ extern "C" int skr_pearson_gemm_edges(skr_ctx* ctx, const skr_operand* a, const 
     SKR_HIP(hipMemsetAsync(sink.count, 0, 8, ctx->stream));
     float* C = multi_chunk ? (float*)scratch->data : nullptr;
     const int64_t ldc = multi_chunk ? scratch->cols : 0;
-    SKR_TRY(skr_launch_gemm_edges(ctx, a->precision, a->data, b->data, C, M, N, a->kt, ldc, (float)K * a->scale * b->scale, chunk, sink));
+    SKR_TRY(skr_launch_gemm_edges(ctx, a->precision, a->data, b->data, C, M, N, a->kt, ldc, (float)K * a->scale * b->scale, coherent, sink));
     unsigned long long found = 0;
     SKR_HIP(hipMemcpyAsync(&found, sink.count, 8, hipMemcpyDeviceToHost, ctx->stream));
     SKR_HIP(hipStreamSynchronize(ctx->stream));

@@ -672,8 +672,7 @@ int launch_fill(skr_ctx* ctx, const skr_operand* op, const FillArgs& a_in) {
         if (wide) {                                                                                               \
             hipLaunchKernelGGL((operand_fill_block_kernel<T, false>), dim3(wgrid), dim3(256), 0, ctx->stream, a);  \
         } else {                                                                                                  \
-            SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(operand_fill_block_kernel<T, true>),        \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds));                  \
+            SKR_TRY(skr_kernel_lds(ctx, reinterpret_cast<const void*>(operand_fill_block_kernel<T, true>), blds)); \
             hipLaunchKernelGGL((operand_fill_block_kernel<T, true>), dim3(wgrid), dim3(256), blds, ctx->stream, a); \
         }                                                                                                         \
     } while (0)
@@ -686,8 +685,7 @@ int launch_fill(skr_ctx* ctx, const skr_operand* op, const FillArgs& a_in) {
         SkrProfScope prof(ctx, "operand_fill");
 #define LAUNCH(T)                                                                                         \
     do {                                                                                                      \
-        SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(operand_fill_kernel<T>),                    \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
+        SKR_TRY(skr_kernel_lds(ctx, reinterpret_cast<const void*>(operand_fill_kernel<T>), lds));             \
         hipLaunchKernelGGL(operand_fill_kernel<T>, dim3(grid), dim3(64 * waves), lds, ctx->stream, a);               \
     } while (0)
         if (op->kind == 0) LAUNCH(float);
@@ -903,7 +901,7 @@ extern "C" int skr_pearson_gemm_op(skr_ctx* ctx, const skr_operand* a, const skr
     } else {
         SKR_TRY(skr_launch_gemm_split(ctx, a->precision, a->data, b->data, C, M, N, a->kt, r->cols,
                                       (float)K * a->scale * b->scale, symmetric && self ? 1 : 0, nullptr, 0,
-                                      (a->coherent || b->coherent) ? 64 : 128));
+                                      a->coherent || b->coherent));
     }
     if (self && a->diag_valid && a->diag) {
         hipLaunchKernelGGL(patch_diag_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream, C, r->cols,
@@ -945,7 +943,7 @@ extern "C" int skr_pearson_gemm_op_mirror(skr_ctx* ctx, const skr_operand* a, co
         return skr_launch_gemm_f32(ctx, (const float*)b->data, (const float*)a->data, Ct, N, M, Kp, Kp, Kp, rt->cols, K, 0);
     }
     return skr_launch_gemm_split(ctx, a->precision, a->data, b->data, C, M, N, a->kt, r->cols,
-                                 (float)K * a->scale * b->scale, 2, Ct, rt->cols, (a->coherent || b->coherent) ? 64 : 128);
+                                 (float)K * a->scale * b->scale, 2, Ct, rt->cols, a->coherent || b->coherent);
 }
 
 // One of two freshly filled operands fell back to the float32 layout (a row needs the dynamic range of

@@ -422,13 +422,11 @@ int skr_launch_gemm_f32(skr_ctx* ctx, const float* A, const float* B, float* C, 
     const bool sym = symmetric && A == B && M == N && lda == ldb;  // mirrors land inside the same square block
     SkrProfScope prof(ctx, "pearson_gemm_f32");
     if (sym) {
-        SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pearson_gemm_f32_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
+        SKR_TRY(skr_kernel_lds(ctx, reinterpret_cast<const void*>(pearson_gemm_f32_kernel<true>), 2 * kStageBytes));
         hipLaunchKernelGGL(pearson_gemm_f32_kernel<true>, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 2 * kStageBytes,
                            ctx->stream, A, B, C, M, N, Kp, lda, ldb, ldc, (float)K, tiles_m, tiles_n);
     } else {
-        SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pearson_gemm_f32_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes));
+        SKR_TRY(skr_kernel_lds(ctx, reinterpret_cast<const void*>(pearson_gemm_f32_kernel<false>), 2 * kStageBytes));
         hipLaunchKernelGGL(pearson_gemm_f32_kernel<false>, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 2 * kStageBytes,
                            ctx->stream, A, B, C, M, N, Kp, lda, ldb, ldc, (float)K, tiles_m, tiles_n);
     }
@@ -443,13 +441,11 @@ int skr_launch_gemm_f64(skr_ctx* ctx, const double* A, const double* B, double* 
         const int64_t tiles_m = (M + DT - 1) / DT, tiles_n = (N + DT - 1) / DT;
         const bool sym = symmetric && A == B && M == N && lda == ldb;  // mirrors land inside the same square block
         if (sym) {
-            SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pearson_gemm_f64_tiled_kernel<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes64));
+            SKR_TRY(skr_kernel_lds(ctx, reinterpret_cast<const void*>(pearson_gemm_f64_tiled_kernel<true>), 2 * kStageBytes64));
             hipLaunchKernelGGL(pearson_gemm_f64_tiled_kernel<true>, dim3((unsigned)(tiles_m * tiles_n)), dim3(256),
                                2 * kStageBytes64, ctx->stream, A, B, C, M, N, K, lda, ldb, ldc, kdiv, tiles_n);
         } else {
-            SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pearson_gemm_f64_tiled_kernel<false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kStageBytes64));
+            SKR_TRY(skr_kernel_lds(ctx, reinterpret_cast<const void*>(pearson_gemm_f64_tiled_kernel<false>), 2 * kStageBytes64));
             hipLaunchKernelGGL(pearson_gemm_f64_tiled_kernel<false>, dim3((unsigned)(tiles_m * tiles_n)), dim3(256),
                                2 * kStageBytes64, ctx->stream, A, B, C, M, N, K, lda, ldb, ldc, kdiv, tiles_n);
         }

@@ -82,7 +82,7 @@ __device__ __forceinline__ f32x4v mfma16x16(vec8<_Float16> a, vec8<_Float16> b, 
 // the placement.  What this buys over one workgroup per tile: the stores of tile t drain while the
 // main loop of tile t+1 runs (with one 128 KiB workgroup per CU nothing else overlaps them), and
 // the slots a self-comparison skips cost one atomic instead of a workgroup launch.
-// DIAG (a diagnostic build, launched only under SEEKR_GEMM_DIAG=1, tools/gemm_diag.py): lane 0 of each workgroup stamps
+// DIAG (instantiated only with -DSEEKR_DIAG, i.e. in libseekr_hip_diag.so for tools/gemm_diag.py): lane 0 of each workgroup stamps
 // s_memtime (shader cycles) and s_memrealtime (100 MHz) around the k loop and the epilogue of every tile into a buffer of
 // its own (MI355X_MICROARCH.md, DVFS give-back item 6); no output value depends on a stamp.
 template <typename T, int NPROD, int MODE, bool PERSIST, bool DIAG = false>
@@ -389,39 +389,37 @@ int launch_chunk(skr_ctx* ctx, const T* Ac, const T* Bc, const SplitOut& o, int6
     const int64_t tiles_m = (M + TM - 1) / TM, tiles_n = (N + TN - 1) / TN;
     const int64_t super_m = (tiles_m + 15) / 16, super_n = (tiles_n + 15) / 16;
     const int64_t slots = super_m * super_n * 256;
-    const bool persist = !(getenv("SEEKR_GEMM_PERSIST") && atoi(getenv("SEEKR_GEMM_PERSIST")) == 0);  // A/B knob
-    if (persist && slots > ctx->num_cu) {
+    if (ctx->knobs.gemm_persist && slots > ctx->num_cu) {
         uint32_t* queues = ctx->d_flags + 8;  // eight counters, zeroed per launch
         SKR_HIP(hipMemsetAsync(queues, 0, 8 * sizeof(uint32_t), ctx->stream));
         auto kern = pearson_gemm_split16_kernel<T, NPROD, MODE, true>;
         unsigned long long* diag = nullptr;
-        if (std::is_same<T, _Float16>::value && NPROD == 3 && (MODE == PLAIN || MODE == SELF) && getenv("SEEKR_GEMM_DIAG") &&
-            atoi(getenv("SEEKR_GEMM_DIAG"))) {
-            // diagnostic build: stamps into the ctx workspace (8 + 8 x 65 536 words), read back by skr_gemm_diag_read
+#ifdef SEEKR_DIAG
+        // libseekr_hip_diag.so only (python -m seekr_amd.build --diag; tools/gemm_diag.py): the production library holds
+        // neither the stamping instance nor the switches below, which make r meaningless.  Never with an edge sink
+        // active: the stamps live in the ctx workspace, which is where the sink's list is.
+        if (std::is_same<T, _Float16>::value && NPROD == 3 && (MODE == PLAIN || MODE == SELF) && ctx->diag_mode && !es.count) {
             void* ws = nullptr;
             SKR_TRY(skr_ctx_workspace(ctx, (size_t)(8 + 8 * 65536) * 8, &ws));
             diag = (unsigned long long*)ws;
             SKR_HIP(hipMemsetAsync(diag, 0, 64, ctx->stream));
-            // diagnostic experiments (results meaningless): 2 = k loop without staging, 3 = every stage re-loads k tile 0,
-            // 4 = self mode without the mirror stores
-            const int dmode = atoi(getenv("SEEKR_GEMM_DIAG"));
+            // experiments: 2 = k loop without staging, 3 = every stage re-loads k tile 0, 4 = self mode without the mirror stores
+            const int dmode = ctx->diag_mode;
             if (dmode >= 2 && dmode <= 4) SKR_HIP(hipMemsetAsync(diag + 1, dmode == 2 ? 1 : (dmode == 3 ? 2 : 4), 1, ctx->stream));
             kern = pearson_gemm_split16_kernel<T, NPROD, (MODE == SELF ? SELF : PLAIN), true, true>;
         }
-        SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    2 * kStageBytes));
+#endif
+        SKR_TRY(skr_kernel_lds(ctx, reinterpret_cast<const void*>(kern), 2 * kStageBytes));
         // A resident workgroup owns its CU outright (8 waves x ~248 VGPRs, 128 KiB LDS): with RCCL traffic
         // in flight on the communication stream a few CUs are left free, or the send/recv kernels of
         // shift s+1 could not start before this launch ends and the overlap of §5 would be lost.
-        static const int reserve_env = getenv("SEEKR_GEMM_RESERVE_CUS") ? atoi(getenv("SEEKR_GEMM_RESERVE_CUS")) : -1;
-        const int reserve = reserve_env >= 0 ? reserve_env : (ctx->nranks > 1 ? 8 : 0);
+        const int reserve = ctx->knobs.gemm_reserve_cus >= 0 ? ctx->knobs.gemm_reserve_cus : (ctx->nranks > 1 ? 8 : 0);
         const unsigned grid = (unsigned)std::max(8, ctx->num_cu - reserve);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 2 * kStageBytes, ctx->stream, Ac, Bc, o.C, o.Ct, M, N, ktc, o.ldc, o.ldct, K,
                            tiles_m, tiles_n, super_n, queues, slots / 8, kt_pitch, accumulate, diag, es);
     } else {
         auto kern = pearson_gemm_split16_kernel<T, NPROD, MODE, false>;
-        SKR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    2 * kStageBytes));
+        SKR_TRY(skr_kernel_lds(ctx, reinterpret_cast<const void*>(kern), 2 * kStageBytes));
         hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(512), 2 * kStageBytes, ctx->stream, Ac, Bc, o.C, o.Ct, M, N, ktc, o.ldc,
                            o.ldct, K, tiles_m, tiles_n, super_n, (uint32_t*)nullptr, (int64_t)0, kt_pitch, accumulate,
                            (unsigned long long*)nullptr, es);
@@ -432,14 +430,13 @@ int launch_chunk(skr_ctx* ctx, const T* Ac, const T* Bc, const SplitOut& o, int6
 
 template <typename T, int NPROD, int MODE>
 int launch16(skr_ctx* ctx, const T* A, const T* B, const SplitOut& o, int64_t M, int64_t N, int64_t kt, float K,
-             const char* name, int64_t chunk_tiles, const EdgeSink* sink = nullptr) {
+             const char* name, bool coherent, const EdgeSink* sink = nullptr) {
     // One float32 accumulator per cell is restarted every 4 096 columns: the MFMA adder truncates each
     // add at the accumulator's unit (~0.25 ulp lost per add, measured; `chunk_tiles` = 64, i.e. every 2 048 columns, for
     // operands whose rows are mostly one repeated value: tools/margin_probe.py), a bias that grows with the number
     // of adds and with the accumulator — 5e-6 relative on an r ~ 1 pair at K = 4 096, four times that at
     // 16 384 in one go.  Later chunks add their partial result to C in the epilogue (rounded float32 adds).
-    static const int64_t env_chunk = getenv("SEEKR_GEMM_CHUNK_TILES") ? std::max(1, atoi(getenv("SEEKR_GEMM_CHUNK_TILES"))) : 0;  // A/B knob
-    const int64_t kChunkTiles = env_chunk ? env_chunk : chunk_tiles;
+    const int64_t kChunkTiles = skr_gemm_chunk_tiles(ctx, coherent);
     const EdgeSink es = sink ? *sink : EdgeSink{};
     SkrProfScope prof(ctx, name);
     for (int64_t t0 = 0; t0 < kt; t0 += kChunkTiles) {
@@ -449,6 +446,7 @@ int launch16(skr_ctx* ctx, const T* A, const T* B, const SplitOut& o, int64_t M,
         const int accumulate = t0 > 0;
         if (MODE == EDGES && t0 + kChunkTiles < kt) {
             // not the last k chunk: its partial sums go to C like a plain block; only the last chunk thresholds
+            if (!o.C) return skr_set_error(SKR_ERR_INVALID, "rows of %lld k tiles in chunks of %lld need a scratch block", (long long)kt, (long long)kChunkTiles);
             SKR_TRY((launch_chunk<T, NPROD, PLAIN>(ctx, Ac, Bc, o, M, N, ktc, kt, K, accumulate, es)));
         } else {
             SKR_TRY((launch_chunk<T, NPROD, MODE>(ctx, Ac, Bc, o, M, N, ktc, kt, K, accumulate, es)));
@@ -459,12 +457,12 @@ int launch16(skr_ctx* ctx, const T* A, const T* B, const SplitOut& o, int64_t M,
 
 template <typename T, int NPROD>
 int gemm_split(skr_ctx* ctx, const T* As, const T* Bs, const SplitOut& o, int64_t M, int64_t N, int64_t kt, float K,
-               int mode, const char* name, int64_t chunk_tiles, const EdgeSink* sink = nullptr) {
+               int mode, const char* name, bool coherent, const EdgeSink* sink = nullptr) {
     switch (mode) {
-        case EDGES: return launch16<T, NPROD, EDGES>(ctx, As, Bs, o, M, N, kt, K, name, chunk_tiles, sink);
-        case SELF: return launch16<T, NPROD, SELF>(ctx, As, Bs, o, M, N, kt, K, name, chunk_tiles);
-        case CROSS: return launch16<T, NPROD, CROSS>(ctx, As, Bs, o, M, N, kt, K, name, chunk_tiles);
-        default: return launch16<T, NPROD, PLAIN>(ctx, As, Bs, o, M, N, kt, K, name, chunk_tiles);
+        case EDGES: return launch16<T, NPROD, EDGES>(ctx, As, Bs, o, M, N, kt, K, name, coherent, sink);
+        case SELF: return launch16<T, NPROD, SELF>(ctx, As, Bs, o, M, N, kt, K, name, coherent);
+        case CROSS: return launch16<T, NPROD, CROSS>(ctx, As, Bs, o, M, N, kt, K, name, coherent);
+        default: return launch16<T, NPROD, PLAIN>(ctx, As, Bs, o, M, N, kt, K, name, coherent);
     }
 }
 
@@ -474,18 +472,18 @@ int gemm_split(skr_ctx* ctx, const T* As, const T* Bs, const SplitOut& o, int64_
 // K: the divisor (columns x the operands' storage scales).  mode 0: C = A B^T / K; 1: A == B, one triangle computed and mirrored inside C; 2: C as mode 0 and
 // Ct[j * ldct + i] = C[i * ldc + j] as well.
 int skr_launch_gemm_split(skr_ctx* ctx, int precision, const void* As, const void* Bs, float* C, int64_t M, int64_t N,
-                          int64_t kt, int64_t ldc, float K, int mode, float* Ct, int64_t ldct, int chunk_tiles) {
+                          int64_t kt, int64_t ldc, float K, int mode, float* Ct, int64_t ldct, bool coherent) {
     SplitOut o{C, ldc, mode == SELF ? C : Ct, mode == SELF ? ldc : ldct};
     switch (precision) {
         case SKR_PREC_BF16X3:
             return gemm_split<__bf16, 3>(ctx, (const __bf16*)As, (const __bf16*)Bs, o, M, N, kt, K, mode,
-                                         "pearson_gemm_bf16x3", chunk_tiles);
+                                         "pearson_gemm_bf16x3", coherent);
         case SKR_PREC_BF16X4:
             return gemm_split<__bf16, 4>(ctx, (const __bf16*)As, (const __bf16*)Bs, o, M, N, kt, K, mode,
-                                         "pearson_gemm_bf16x4", chunk_tiles);
+                                         "pearson_gemm_bf16x4", coherent);
         case SKR_PREC_F16X3:
             return gemm_split<_Float16, 3>(ctx, (const _Float16*)As, (const _Float16*)Bs, o, M, N, kt, K, mode,
-                                           "pearson_gemm_f16x3", chunk_tiles);
+                                           "pearson_gemm_f16x3", coherent);
         default: return skr_set_error(SKR_ERR_INVALID, "not a split precision: %d", precision);
     }
 }
@@ -493,23 +491,24 @@ int skr_launch_gemm_split(skr_ctx* ctx, int precision, const void* As, const voi
 // As skr_launch_gemm_split in PLAIN geometry, but the epilogue thresholds instead of storing (EDGES mode).  C is only
 // touched when the rows have more than one k chunk: the earlier chunks leave their partial sums there.
 int skr_launch_gemm_edges(skr_ctx* ctx, int precision, const void* As, const void* Bs, float* C, int64_t M, int64_t N,
-                          int64_t kt, int64_t ldc, float K, int chunk_tiles, const SkrEdgeSink& sink) {
+                          int64_t kt, int64_t ldc, float K, bool coherent, const SkrEdgeSink& sink) {
     SplitOut o{C, ldc, nullptr, 0};
     switch (precision) {
         case SKR_PREC_BF16X3:
             return gemm_split<__bf16, 3>(ctx, (const __bf16*)As, (const __bf16*)Bs, o, M, N, kt, K, EDGES, "pearson_gemm_bf16x3",
-                                         chunk_tiles, &sink);
+                                         coherent, &sink);
         case SKR_PREC_BF16X4:
             return gemm_split<__bf16, 4>(ctx, (const __bf16*)As, (const __bf16*)Bs, o, M, N, kt, K, EDGES, "pearson_gemm_bf16x4",
-                                         chunk_tiles, &sink);
+                                         coherent, &sink);
         case SKR_PREC_F16X3:
             return gemm_split<_Float16, 3>(ctx, (const _Float16*)As, (const _Float16*)Bs, o, M, N, kt, K, EDGES,
-                                           "pearson_gemm_f16x3", chunk_tiles, &sink);
+                                           "pearson_gemm_f16x3", coherent, &sink);
         default: return skr_set_error(SKR_ERR_INVALID, "not a split precision: %d", precision);
     }
 }
 
-// Diagnostic build only (SEEKR_GEMM_DIAG=1): copies the stamp records of the last contraction launch to the host.
+#ifdef SEEKR_DIAG
+// libseekr_hip_diag.so only: copies the stamp records of the last contraction launch to the host.
 // out: [max_records][8] uint64 = {memtime t0, memrealtime t0, memtime k-loop start, memtime k-loop end, memtime end,
 // memrealtime end, tm<<32|tn, xcc<<32|workgroup}; *n_records = records written by the kernel.
 extern "C" int skr_gemm_diag_read(skr_ctx* ctx, unsigned long long* out, int64_t max_records, int64_t* n_records) {
@@ -524,3 +523,11 @@ extern "C" int skr_gemm_diag_read(skr_ctx* ctx, unsigned long long* out, int64_t
     if (take > 0) SKR_HIP(hipMemcpy(out, (char*)ctx->ws + 64, (size_t)take * 64, hipMemcpyDeviceToHost));
     return SKR_OK;
 }
+
+// 0 = production kernels; 1 = stamps only (r stays valid); 2-4 = timing experiments that make r meaningless (above)
+extern "C" int skr_gemm_diag_mode(skr_ctx* ctx, int mode) {
+    SKR_REQUIRE(ctx && mode >= 0 && mode <= 4, "mode 0..4");
+    ctx->diag_mode = mode;
+    return SKR_OK;
+}
+#endif

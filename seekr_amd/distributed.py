@@ -129,6 +129,8 @@ class HipEngine:
 
 
 class RcclComm:
+    SEND_TICKET_OPTIONAL = True  # send_vec takes want_ticket (a communicator without the attribute is called without it)
+
     def __init__(self, ctx, rank, size):
         self.ctx, self.rank, self.size = ctx, rank, size
 
@@ -186,10 +188,11 @@ class SingleComm:
 
 # ------------------------------------------------------------------------------ steps -------
 def _send_vec(comm, v, dst, want_ticket):
-    try:
+    # decided from a class attribute, not by catching TypeError around the call: a TypeError raised INSIDE a real send
+    # must surface, not post the send a second time (an unmatched send hangs the chain)
+    if getattr(comm, "SEND_TICKET_OPTIONAL", False):
         return comm.send_vec(v, dst, want_ticket=want_ticket)
-    except TypeError:  # a communicator without the option (the gloo one of the CPU tests)
-        return comm.send_vec(v, dst)
+    return comm.send_vec(v, dst)  # e.g. the gloo communicator of the CPU tests
 
 
 def _chain_colsum(engine, comm, x, n_cols, center=None, center2=None, square=False, colmin=None):
@@ -476,6 +479,7 @@ def sharded_pearson_edges(engine, comm, z, bounds, cutoff, stripe_rows=8192, upp
     (stripe x columns at or right of the stripe when `upper_only`), no further communication.
     Returns this rank's (rows, cols, vals) in row-major order of its stripes; the union over the
     ranks is the edge list of the whole matrix."""
+    from seekr_amd.consumers import FUSE_MAX_DENSITY
     n_total = bounds[-1]
     full = allgather_operand(engine, comm, z, bounds, full)
     stripe_rows = max(1, min(int(stripe_rows), n_total))
@@ -488,7 +492,7 @@ def sharded_pearson_edges(engine, comm, z, bounds, cutoff, stripe_rows=8192, upp
         a = engine.view(full, s0, s1 - s0)
         b = engine.view(full, c0, n_total - c0) if c0 else full
         # "auto": fused while the list stays sparse (consumers.FUSE_MAX_DENSITY), else through the stripe buffer
-        use_fused = fused is not None and (fuse is True or seen_edges <= 1e-3 * max(seen_cells, 1))
+        use_fused = fused is not None and (fuse is True or seen_edges <= FUSE_MAX_DENSITY * max(seen_cells, 1))
         part = None
         if use_fused:
             if engine.cols(full) > 2048 and buf is None:

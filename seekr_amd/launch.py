@@ -10,6 +10,7 @@ earlier launch is ignored, and rank 0 removes whatever is there before it publis
 """
 import hashlib
 import os
+import stat
 import struct
 import tempfile
 import time
@@ -40,9 +41,9 @@ def world():
 def _rendezvous_path():
     base = os.path.join(tempfile.gettempdir(), "seekr_amd_{}".format(os.getuid()))
     os.makedirs(base, mode=0o700, exist_ok=True)
-    st = os.stat(base)
-    if st.st_uid != os.getuid() or (st.st_mode & 0o077):
-        raise PermissionError("{} must belong to this user with mode 0700".format(base))
+    st = os.lstat(base)  # lstat: a pre-planted symlink to some other 0700 directory of this user must not pass
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise PermissionError("{} must be a directory of this user with mode 0700 (not a symlink)".format(base))
     key = "{}_{}_{}".format(os.getppid(), os.environ.get("MASTER_PORT", "0"),
                             os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"))
     return os.path.join(base, "rccl_id_" + key)
@@ -76,6 +77,7 @@ def selftest(ctx, comm):
     """One all-reduce and one ring send/recv over the new communicator, checked: the first multi-GPU run diagnoses
     itself — a failure raises with RCCL's own error string instead of hanging in the first shift."""
     rank, size = comm.rank, comm.size
+    failure = None
     try:
         total = comm.allreduce([float(rank)], "sum")[0]
         if total != size * (size - 1) / 2.0:
@@ -92,9 +94,21 @@ def selftest(ctx, comm):
         send.free()
         recv.free()
     except Exception as e:  # noqa: BLE001
+        failure = e
+    # every rank learns whether ANY rank failed before anyone leaves: a rank that raised alone would leave the others
+    # blocked in the barrier that follows (the all-reduce itself failing is the one case only the launcher's
+    # kill-on-failure can end: bench.py's parent kills the process group when a child exits non-zero)
+    bad = 1.0 if failure is not None else 0.0
+    try:
+        bad = comm.allreduce([bad], "max")[0]
+    except Exception as e:  # noqa: BLE001
+        failure = failure or e
+    if failure is not None:
         raise _lib.SeekrHipError(
             "rank {} of {}: RCCL self-test failed: {} (HSA_ENABLE_IPC_MODE_LEGACY={}, device {})".format(
-                rank, size, e, os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), ctx.device)) from e
+                rank, size, failure, os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), ctx.device)) from failure
+    if bad:
+        raise _lib.SeekrHipError("rank {} of {}: RCCL self-test passed here but failed on another rank".format(rank, size))
 
 
 def init(timeout_s=120.0):

@@ -20,12 +20,29 @@ def test_library_exports_every_declared_symbol():
     from seekr_amd import _lib
     handle = _lib.lib()
     header = open(os.path.join(ROOT, "include", "seekr_hip.h")).read()
-    declared = set(re.findall(r"\b(skr_[a-z0-9_]+)\s*\(", header))
+    product, _, diag = header.partition("#ifdef SEEKR_DIAG")
+    declared = set(re.findall(r"\b(skr_[a-z0-9_]+)\s*\(", product))
     assert declared, "no declarations parsed"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(handle, name), name
     assert handle.skr_abi_version() == 1
+    # the diagnostic entry points (and the stamping instance of the contraction with its result-corrupting switches)
+    # live in libseekr_hip_diag.so only: the production library must not export them
+    diag_declared = set(re.findall(r"\b(skr_[a-z0-9_]+)\s*\(", diag.partition("#endif")[0]))
+    assert diag_declared == set(_lib.DIAG_SIGNATURES), diag_declared ^ set(_lib.DIAG_SIGNATURES)
+    for name in diag_declared:
+        assert not hasattr(handle, name), name + " is exported by the production library"
+
+
+def test_no_launch_path_reads_the_environment():
+    """ADVICE r2 / VERDICT r2 weak 8: environment switches are read in skr_ctx_reload_knobs (ctx creation), never per
+    launch; what is left are the two host-side test hooks (FASTA piece size, the RCCL library override)."""
+    import glob
+    allowed = {"ctx.hip": 1, "pack.hip": 1, "comm.hip": 2}
+    for path in glob.glob(os.path.join(ROOT, "seekr_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "seekr_amd", "csrc", "*.hpp")):
+        n = len(re.findall(r"\bgetenv\s*\(", open(path).read()))
+        assert n <= allowed.get(os.path.basename(path), 0), (path, n)
 
 
 def test_product_fails_loudly_without_gpu():
@@ -151,3 +168,68 @@ def test_test_hooks_are_off_without_the_opt_in():
     assert out.stdout.strip() == "5", out.stdout + out.stderr
     out = subprocess.run([sys.executable, "-c", code], env=dict(env, SEEKR_TEST_HOOKS="1"), capture_output=True, text=True, timeout=120)
     assert out.stdout.strip() == "0", out.stdout + out.stderr
+
+
+# ---------------------------------------------------------------- bench.py: launcher and measurement contract ----
+def _bench():
+    import importlib
+    sys.path.insert(0, ROOT)
+    return importlib.import_module("bench")
+
+
+def test_bench_launcher_reports_every_rank_and_retries_once():
+    """`python bench.py --gpus 2` without WORLD_SIZE starts its own rank processes.  Here there is no
+    GPU (or, on a test box, one): both attempts fail, and the launcher must say so loudly — non-zero exit, every
+    rank's stderr tail, the one retry with --layout rowblock — instead of dying in argument checking or hanging."""
+    from seekr_amd import _lib
+    if _lib.device_count() >= 2:
+        pytest.skip("two GPUs are visible: the launch would succeed")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--launch-timeout", "120"], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 1 and res.stdout.strip() == ""
+    err = res.stderr
+    assert "attempt 1" in err and "attempt 2" in err and "retrying once" in err and "--layout rowblock" in err
+    for rank in (0, 1):
+        assert err.count("---- rank %d (exit code" % rank) == 2
+    assert "SeekrHipError" in err or "out of range" in err
+
+
+def test_bench_launcher_kills_a_hung_rank_set(tmp_path):
+    bench = _bench()
+    t0 = __import__("time").time()
+    ok, kind, report = bench._run_rank_set(["-c", "import sys, time; sys.stderr.write('hung rank\\n'); sys.stderr.flush(); time.sleep(600)"],
+                                           2, 2.0, {}, str(tmp_path), 1, program=[sys.executable])
+    assert not ok and "timeout" in kind and report.count("hung rank") == 2
+    assert __import__("time").time() - t0 < 30
+    # a rank set that works: rank 0's single JSON line comes back
+    ok, line, _ = bench._run_rank_set(["-c", "import os; print('{\"rank\": %s}' % os.environ['RANK']) if os.environ['RANK'] == '0' else None"],
+                                      3, 30.0, {}, str(tmp_path), 2, program=[sys.executable])
+    assert ok and line == '{"rank": 0}'
+    # the self-test's exit code is told apart from any other failure
+    ok, kind, _ = bench._run_rank_set(["-c", "import sys; sys.exit(%d)" % bench.SELFTEST_EXIT], 2, 30.0, {}, str(tmp_path), 3,
+                                      program=[sys.executable])
+    assert not ok and kind == "selftest"
+
+
+def test_pmc_traffic_refuses_a_summary_of_other_kernels(tmp_path):
+    """bench.py quotes roofline.traffic from a committed --pmc summary only when that summary was
+    taken on the same workload with a library holding the same kernel symbols as the one loaded now."""
+    bench = _bench()
+    lib_path = os.path.join(ROOT, "seekr_amd", "libseekr_hip.so")
+    h = bench.kernel_symbols_sha256(lib_path)
+    assert len(h) == 64
+    wl = bench.workload_key(50000, 2000, 6, "f16x3", 1)
+    body = "_ZN12_GLOBAL__N_127pearson_gemm_split16_kernelIDF16_Li3ELi1ELb1ELb0EEEv\n    FETCH_SIZE      1000\n    WRITE_SIZE      500\n"
+    (tmp_path / "a_pmc_summary.txt").write_text("# workload: %s\n# kernel_symbols_sha256: %s\n%s" % (wl, "0" * 64, body))
+    got, why = bench.pmc_traffic("split16_kernelIDF16_Li3", wl, lib_path, profiles_dir=str(tmp_path))
+    assert got is None and "refused" in why
+    (tmp_path / "b_pmc_summary.txt").write_text("# workload: %s\n# kernel_symbols_sha256: %s\n%s" % (wl, h, body))
+    got, why = bench.pmc_traffic("split16_kernelIDF16_Li3", wl, lib_path, profiles_dir=str(tmp_path))
+    assert why is None and got["bytes"] == (2 * 1000 + 500) * 1024.0
+    got, why = bench.pmc_traffic("split16_kernelIDF16_Li3", bench.workload_key(200000, 2000, 6, "f16x3", 1), lib_path,
+                                 profiles_dir=str(tmp_path))
+    assert got is None and "no profiles" in why
+    # the committed summaries either match the library that is built from this tree or are not quoted
+    got, why = bench.pmc_traffic("split16_kernelIDF16_Li3", wl, lib_path)
+    assert (got is None) != (why is None)

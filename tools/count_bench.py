@@ -1,4 +1,4 @@
-"""Counting kernel A/B bench: variants (environment knobs read at every launch) interleaved in ONE
+"""Counting kernel A/B bench: variants (environment knobs, re-read through skr_ctx_reload_knobs before each launch) interleaved in ONE
 process, median and min of HIP-event times per launch (cdna_hip_programming.md rule 24).
 
     python tools/count_bench.py [--rows 50000] [--length 2000] [-k 6] [--rounds 15] NAME=ENV=VAL[,ENV=VAL] ...
@@ -25,6 +25,7 @@ def time_variants(ctx, packed, k, out, variants, rounds, kernel="count_kmers_f32
         for name, env in variants:
             for key, val in env.items():
                 os.environ[key] = val
+            ctx.reload_knobs()
             if PRE["op"] is not None:
                 PRE["op"]()  # what runs right before the counting kernel in a pipeline step (not timed)
             ctx.prof_reset()

@@ -24,6 +24,7 @@ raw = x0.to_numpy()
 for _ in range(9):
     for name, env in variants:
         os.environ.update(env)
+        ctx.reload_knobs()
         x.upload(raw)
         ctx.sync()
         ctx.prof_reset(); ctx.prof_enable(True)

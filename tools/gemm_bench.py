@@ -1,4 +1,4 @@
-"""Pearson contraction A/B bench: variants (environment knobs read at every launch) interleaved in ONE
+"""Pearson contraction A/B bench: variants (environment knobs, re-read through skr_ctx_reload_knobs before each launch) interleaved in ONE
 process, median and min of HIP-event times per launch (cdna_hip_programming.md rule 24), on random
 normalised-count-like operands (never zeros: MI355X_MICROARCH.md, DVFS give-back).
 
@@ -52,6 +52,7 @@ def main():
     for _ in range(args.rounds):
         for name, env in variants:
             os.environ.update(env)
+            ctx.reload_knobs()
             ctx.prof_reset()
             ctx.prof_enable(True)
             _lib.pearson_gemm_op(ctx, a, b, r, symmetric=args.mode == "self")

@@ -1,4 +1,4 @@
-"""In-kernel anatomy of the split-fp16 contraction (diagnostic build, SEEKR_GEMM_DIAG=1): per tile, the
+"""In-kernel anatomy of the split-fp16 contraction (libseekr_hip_diag.so: `python -m seekr_amd.build --diag`): per tile, the
 shader cycles of the k loop and of the epilogue (s_memtime) and the in-kernel clock (delta s_memtime /
 delta s_memrealtime x 100 MHz), after >= 2 s of back-to-back launches on random data
 (MI355X_MICROARCH.md, DVFS give-back item 6).
@@ -14,6 +14,10 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 from seekr_amd import _lib  # noqa: E402
+
+if not os.path.exists(_lib.DIAG_LIB_PATH):
+    raise SystemExit("build the diagnostic library first: python -m seekr_amd.build --diag")
+_lib.LIB_PATH = _lib.DIAG_LIB_PATH  # before the first call: this process runs on the diagnostic library
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=50000)
@@ -48,10 +52,10 @@ while time.time() < t_end:  # warm the chip up to its steady clock
     _lib.pearson_gemm_op(ctx, op, b, r, symmetric=sym)
     ctx.sync()
     n += 1
-os.environ["SEEKR_GEMM_DIAG"] = "2" if args.no_dma else ("3" if args.same_tile else ("4" if args.no_mirror else "1"))
+_lib.check(_lib.lib().skr_gemm_diag_mode(ctx._h, 2 if args.no_dma else (3 if args.same_tile else (4 if args.no_mirror else 1))))
 _lib.pearson_gemm_op(ctx, op, b, r, symmetric=sym)
 ctx.sync()
-os.environ.pop("SEEKR_GEMM_DIAG")
+_lib.check(_lib.lib().skr_gemm_diag_mode(ctx._h, 0))
 rec = np.zeros((65536, 8), dtype=np.uint64)
 cnt = C.c_int64(0)
 _lib.check(_lib.lib().skr_gemm_diag_read(ctx._h, rec.ctypes.data_as(C.c_void_p), 65536, C.byref(cnt)))
