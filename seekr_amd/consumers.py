@@ -12,6 +12,7 @@ Every function takes and returns device matrices (`seekr_amd._lib.Matrix`); `*_h
 wrap host arrays for drop-in use.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -136,7 +137,8 @@ class FusedEdges:
         buffers start at 2e-3 entries per cell; a block with more edges is run again with room (retry=True) or reported
         as None (retry=False: the caller has a cheaper way for lists that dense)."""
         ctx = self.ctx
-        chunk_cols = 2048 if (a.coherent or b.coherent) else 4096
+        # columns per accumulator restart of the contraction (skr_gemm_chunk_tiles; the A/B knob moves it)
+        chunk_cols = 32 * (int(os.environ.get("SEEKR_GEMM_CHUNK_TILES", "0") or 0) or (64 if (a.coherent or b.coherent) else 128))
         if a.cols > chunk_cols and scratch is None:
             if self._scratch is None or self._scratch.rows < a.rows or self._scratch.cols < b.rows:
                 if self._scratch is not None:

@@ -12,6 +12,11 @@ from oracle import seekr_oracle as orc  # noqa: E402
 from seekr_amd.pearson import pearson  # noqa: E402
 
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from strict_tally import StrictTally  # noqa: E402
+
+TALLY = StrictTally()
+
 def fuzz(seed, budget_s=60.0, max_cases=10 ** 9):
     rng = np.random.default_rng(seed)
     t0, n_cases = time.time(), 0
@@ -73,6 +78,8 @@ def fuzz(seed, budget_s=60.0, max_cases=10 ** 9):
             e_ref = np.where(ok, np.abs(w - truth), 0.0)
             e_ours = np.where(ok, np.abs(g - truth), 0.0)
             scale = np.maximum(np.abs(np.where(ok, truth, 0.0)), 1e-300)
+            if got.dtype == np.float32 and rs:
+                TALLY.add(g, w, truth, ok)
             if got.dtype == np.float64:
                 limit = 1e-12 * np.maximum(scale, 1.0) + 8 * e_ref.max()
             else:

@@ -139,6 +139,47 @@ def test_bench_under_torchrun_with_two_ranks(mock_lib):
     assert abs(out["roofline"]["pairs_multiplied_per_step"] / out["roofline"]["pairs_delivered_per_step"] - 0.5) < 0.1
 
 
+def _launcher_env(mock_lib, **extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(SEEKR_TEST_HOOKS="1", SEEKR_RCCL_LIB=mock_lib, SEEKR_FORCE_DEVICE="0", MOCK_RCCL_ASYNC="1", **extra)
+    return env
+
+
+def test_bench_starts_its_own_rank_processes(mock_lib):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the shape of the driver's N = 1 command, VERDICT r2
+    #2): the launcher spawns the two ranks itself, the half-ring self-test runs before the warm-up, and rank 0's line
+    carries n_ranks_seen and the per-rank transfer / exposed-wait times."""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "6000",
+           "--length", "500"]
+    res = subprocess.run(cmd, env=_launcher_env(mock_lib), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and "symmetric" in out["config"]["layout"]
+    assert "layout_fallback" not in out and out["selftest"].startswith("half-ring schedule == row-block")
+    pr = out["per_rank"]
+    for key in ("comm_ms", "exposed_wait_ms", "chain_wait_ms", "gemm_ms"):
+        assert len(pr[key]) == 2 and all(v >= 0 for v in pr[key]), (key, pr[key])
+    assert min(pr["gemm_ms"]) > 0 and max(pr["comm_ms"]) > 0
+    assert {"comm_xfer", "comm_wait", "comm_vec", "comm_wait_vec"} <= set(out["kernels_ms_per_step"])
+
+
+def test_bench_falls_back_to_row_blocks_when_the_selftest_fails(mock_lib):
+    """The half-ring self-test fails on rank 1 of 3 (test hook): every rank leaves with the self-test's exit code, and the
+    launcher starts a NEW set of rank processes with --layout rowblock; the line says so."""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "1", "--rows", "4500",
+           "--length", "500"]
+    res = subprocess.run(cmd, env=_launcher_env(mock_lib, SEEKR_BENCH_FAIL_SELFTEST="1"), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert "self-test FAILED" in res.stderr and "retrying once" in res.stderr and "failure injected" in res.stderr
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 3 and out["n_ranks_seen"] == 3 and out["config"]["layout"] == "row blocks"
+    assert "self-test failed" in out["layout_fallback"] and out["value"] > 0
+
+
 def test_every_rank_switches_when_one_needs_the_fp32_kernel(mock_lib, tmp_path):
     """Rank 0 holds two identical homopolymers (one-hot raw count rows): its operand falls back to the
     float32 layout, the flag is all-reduced and the other ranks follow, so shards stay compatible;

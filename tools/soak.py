@@ -18,3 +18,6 @@ out["pearson"] = fuzz_pearson.fuzz(seed + 12, budget_s=budgets[1])
 out["consumers"] = fuzz_consumers.fuzz(seed + 13, budget_s=budgets[2])
 out["fasta"] = fuzz_fasta.fuzz(seed + 14, budget_s=budgets[3])
 print("soak ok:", out)
+# strict parity (no allowance for the reference's own error): how many float32 cases met |got - ref| <= 2e-6 + 1e-5 |ref|
+print("strict parity, pipeline fuzzer:", fuzz_differential.TALLY.summary())
+print("strict parity, pearson fuzzer: ", fuzz_pearson.TALLY.summary())
