@@ -23,6 +23,9 @@ PER_FILE = {
     # numpy-order parity: no FMA contraction anywhere in the normalisation / scaling arithmetic
     "normalize.hip": ["-ffp-contract=off"],
     "count.hip": ["-ffp-contract=off"],
+    # the 4-wave geometry of the contraction has 64 accumulator tiles per lane: its epilogue loops are only unrolled (and
+    # the accumulator array only kept in registers) above clang's default 16 384-instruction limit for `#pragma unroll`
+    "pearson_bf16.hip": ["-mllvm", "-pragma-unroll-threshold=200000"],
 }
 
 

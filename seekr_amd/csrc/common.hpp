@@ -17,8 +17,8 @@ struct SkrKnobs {
     bool gemm_persist = true;    // SEEKR_GEMM_PERSIST=0: one workgroup per tile instead of the persistent grid
     int gemm_chunk_tiles = 0;    // SEEKR_GEMM_CHUNK_TILES: k tiles per accumulator restart (0 = the operand's own choice)
     int gemm_reserve_cus = -1;   // SEEKR_GEMM_RESERVE_CUS: CUs left to RCCL's kernels (-1 = 8 with a communicator, else 0)
-    int gemm_subtile = 0;        // SEEKR_GEMM_SUBTILE: XCD sub-tile shape of the contraction's tile order (0 = 8 x 4, 1 = 4 x 4 pairs, 2 = 16 x 2)
-    int gemm_wave_tile = 0;      // SEEKR_GEMM_WAVE_TILE=1: the 4-wave 128 x 128 wave-tile arm (A/B, tools/gemm_bench.py)
+    int gemm_subtile = 4;        // SEEKR_GEMM_SUBTILE: order in which an XCD's CUs take the tiles of a super-tile (pearson_bf16.hip: tile_of_block)
+    int gemm_wave_tile = 0;      // SEEKR_GEMM_WAVE_TILE=1: the 4-wave 128 x 128 wave-tile arm (libseekr_hip_diag.so only; tools/gemm_bench.py --diag-lib)
     int count_percu = 0;         // SEEKR_COUNT_PERCU: cap on resident workgroups per CU (0 = none)
     bool count_persist = false;  // SEEKR_COUNT_PERSIST=1: persistent grid at k <= 6
     bool count_legacy = false;   // SEEKR_COUNT_LEGACY=1: the round-1 counting kernel

@@ -54,13 +54,41 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst_wave_b
 // 4 B panels in that XCD's L2) and the 8 sub-tiles of the 8 XCDs form one 16 x 16 super-tile
 // whose 32 panels (~134 MB at K=4096) fit the 256 MB Infinity Cache.  Speed only, never
 // correctness: blocks that fall outside the matrix (or below the diagonal when SYM) exit.
+// `shape` (SEEKR_GEMM_SUBTILE, an A/B knob): which 32 tiles of the super-tile an XCD works on at a time and
+// in which order its CUs take them — 4 (default since round 3): 8 x 4, tile COLUMN fastest; 0: 8 x 4, tile row fastest
+// (rounds 1-2); 1: the same region as two 4 x 4 halves; 2: 16 x 2; 3: 4 x 8; 5 / 6: Morton order.  The 32 CUs of an XCD
+// drift apart by more k tiles than its 4 MB L2 holds, so what counts is which tiles START together: measured at 50 000
+// rows (PMC, profiles/r3_subtile_shapes.txt) L2 hit rate 48 % (0) / 63 % (1) / 66 % (4), HBM-side traffic 89.6 / 61.5 /
+// 55.3 GB per launch (7.7 / 5.3 / 4.75 x algorithmic), launch 22.3 / 21.9 / 21.8 ms.
 __device__ __forceinline__ bool tile_of_block(int64_t bid, int64_t super_n, int64_t tiles_m, int64_t tiles_n,
-                                              int64_t* tm, int64_t* tn) {
+                                              int64_t* tm, int64_t* tn, int shape = 0) {
     const int64_t xcd = bid & 7, i = bid >> 3;
     const int64_t s = i >> 5, j = i & 31;
     const int64_t sr = s / super_n, sc = s % super_n;
-    *tm = sr * 16 + (xcd & 1) * 8 + (j & 7);
-    *tn = sc * 16 + (xcd >> 1) * 4 + (j >> 3);
+    if (shape == 1) {
+        const int64_t sub = 2 * xcd + (j >> 4);  // 16 sub-tiles of 4 x 4
+        *tm = sr * 16 + (sub & 3) * 4 + (j & 3);
+        *tn = sc * 16 + (sub >> 2) * 4 + ((j >> 2) & 3);
+    } else if (shape == 2) {
+        *tm = sr * 16 + (j & 15);
+        *tn = sc * 16 + xcd * 2 + (j >> 4);
+    } else if (shape == 3) {  // 4 x 8, rows fastest
+        *tm = sr * 16 + (xcd >> 1) * 4 + (j & 3);
+        *tn = sc * 16 + (xcd & 1) * 8 + (j >> 2);
+    } else if (shape == 4) {  // 8 x 4 like the default, but the tile COLUMN fastest
+        *tm = sr * 16 + (xcd & 1) * 8 + (j >> 2);
+        *tn = sc * 16 + (xcd >> 1) * 4 + (j & 3);
+    } else if (shape == 5) {  // the default 8 x 4 region in Morton (Z) order: neighbours in slot order share panels both ways
+        *tm = sr * 16 + (xcd & 1) * 8 + ((j & 1) | ((j >> 1) & 2) | ((j >> 2) & 4));
+        *tn = sc * 16 + (xcd >> 1) * 4 + (((j >> 1) & 1) | ((j >> 2) & 2));
+    } else if (shape == 6) {  // two 4 x 4 halves like 1, each in Morton order
+        const int64_t sub = 2 * xcd + (j >> 4);
+        *tm = sr * 16 + (sub & 3) * 4 + ((j & 1) | ((j >> 1) & 2));
+        *tn = sc * 16 + (sub >> 2) * 4 + (((j >> 1) & 1) | ((j >> 2) & 2));
+    } else {
+        *tm = sr * 16 + (xcd & 1) * 8 + (j & 7);
+        *tn = sc * 16 + (xcd >> 1) * 4 + (j >> 3);
+    }
     return *tm < tiles_m && *tn < tiles_n;
 }
 
@@ -75,6 +103,26 @@ __device__ __forceinline__ f32x4v mfma16x16(vec8<_Float16> a, vec8<_Float16> b, 
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
+// The same instruction with the accumulator PINNED in the accumulation registers ("+a"): the 4-wave geometry keeps 256
+// accumulators per lane, which is the whole AGPR half of a one-wave-per-SIMD register file; left to the register
+// allocator (builtin form) hipcc keeps part of them in VGPRs and shuffles them through v_accvgpr_write / scratch inside
+// the k loop (264 scratch accesses and 660 accvgpr moves per two k tiles).  hipcc does not model what is inside the
+// string (cdna_hip_programming.md §5.7): consecutive statements here never touch the same accumulator (an accumulate
+// chain would need no wait state either), operands come from ds_reads the compiler does wait for, and the reads of the
+// accumulators after the k loop are fenced by hand (mfma_drain).
+__device__ __forceinline__ void mfma16x16_pinned(f32x4v& c, vec8<__bf16> a, vec8<__bf16> b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma16x16_pinned(f32x4v& c, vec8<_Float16> a, vec8<_Float16> b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+// an MFMA's result may be read by anything but the next MFMA's C operand only 12+ wait states after issue (8-pass XDL)
+__device__ __forceinline__ void mfma_drain() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // PERSIST: one workgroup per CU for the whole launch.  Tile slots are handed out by eight counters,
 // one per XCD group (slot i of group x is block id 8 i + x of the order above, so an XCD keeps
 // walking 8 x 4 sub-tiles in its own L2); a workgroup drains the queue of the XCD it runs on
@@ -85,13 +133,21 @@ __device__ __forceinline__ f32x4v mfma16x16(vec8<_Float16> a, vec8<_Float16> b, 
 // DIAG (instantiated only with -DSEEKR_DIAG, i.e. in libseekr_hip_diag.so for tools/gemm_diag.py): lane 0 of each workgroup stamps
 // s_memtime (shader cycles) and s_memrealtime (100 MHz) around the k loop and the epilogue of every tile into a buffer of
 // its own (MI355X_MICROARCH.md, DVFS give-back item 6); no output value depends on a stamp.
-template <typename T, int NPROD, int MODE, bool PERSIST, bool DIAG = false>
-__global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
+// WAVES = 8 (default): 2 x 4 waves, wave tile 128 x 64, two waves per SIMD.  WAVES = 4 (the A/B arm of VERDICT r2 #3,
+// SEEKR_GEMM_WAVE_TILE=1): 2 x 2 waves, wave tile 128 x 128, ONE wave per SIMD with the whole 512-register file (256
+// accumulators); a wave then reads 32 instead of 24 fragments per k tile but there are half as many waves: 128 instead of
+// 192 KiB of ds_read per CU and k tile.  With nobody to cover its LDS latency the k loop is software-pipelined by hand
+// (below); per accumulator the products are added in the same order, so r is the same bits.
+template <typename T, int NPROD, int MODE, bool PERSIST, bool DIAG = false, int WAVES = 8>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_kernel(
     const T* __restrict__ A, const T* __restrict__ B, float* __restrict__ C, float* __restrict__ Ct,
     int64_t M, int64_t N, int64_t kt, int64_t ldc, int64_t ldct, float kdiv, int64_t tiles_m, int64_t tiles_n,
-    int64_t super_n, uint32_t* __restrict__ queues, int64_t slots_per_queue, int64_t pitch_tiles, int accumulate,
+    int64_t super_n, uint32_t* __restrict__ queues, int64_t slots_per_queue, int64_t pitch_tiles, int flags,
     unsigned long long* __restrict__ diag, const EdgeSink es) {
-    constexpr int WN = 4, MT = 8, NT = 4, PP = 4;  // 8 waves as 2 x 4, wave tile 128 x 64
+    const int accumulate = flags & 1;  // later k chunks add to what the earlier ones left in C; bits 8..: tile order shape
+    static_assert(WAVES == 8 || (WAVES == 4 && NPROD == 3), "4-wave geometry: three products only");
+    constexpr int WN = WAVES == 8 ? 4 : 2, MT = 8, NT = WAVES == 8 ? 4 : 8, PP = 32 / WAVES;  // waves as 2 x WN, wave tile 128 x 16 NT
+    constexpr int WTN = NT * 16;                                                                // wave tile width
     constexpr bool SYM = MODE == SELF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int64_t s_bid;
@@ -123,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
         if (bid < 0) return;
     }
     int64_t tm, tn;
-    if (!tile_of_block(bid, super_n, tiles_m, tiles_n, &tm, &tn) || (SYM && tn < tm)) {  // outside, or the mirror writes it
+    if (!tile_of_block(bid, super_n, tiles_m, tiles_n, &tm, &tn, flags >> 8) || (SYM && tn < tm)) {  // outside, or the mirror writes it
         if (PERSIST) continue;
         return;
     }
@@ -173,7 +229,7 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
     }
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-        const int rb = wn * 64 + t * 16 + (lane & 15);
+        const int rb = wn * WTN + t * 16 + (lane & 15);
         b_off[t] = TM * kRowBytes + rb * kRowBytes;
         b_swz[t] = (rb >> 1) & 7;
     }
@@ -194,35 +250,140 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
     // simple form stays.
     int cur = 0;
     stage(0, 0);
+    if (WAVES == 4 && kt > 1) stage(1, 1);  // the 4-wave loop keeps two stages in flight (below)
     __syncthreads();
     if (DIAG) st[2] = __builtin_amdgcn_s_memtime();
     const bool no_dma = DIAG && (diag[1] & 1);  // diagnostic only: k loop without its staging traffic (results meaningless)
     const bool same_tile = DIAG && (diag[1] & 2);  // diagnostic only: every stage re-loads k tile 0 (served by the nearest cache)
-    for (int64_t t = 0; t < kt; t++) {
-        if (t + 1 < kt && !no_dma) stage(cur ^ 1, same_tile ? 0 : t + 1);
-        const char* base = smem + cur * kStageBytes;
-        vec8<T> ahi[MT], alo[MT], bhi[NT], blo[NT];
-#pragma unroll
-        for (int i = 0; i < NT; i++) {
-            bhi[i] = *reinterpret_cast<const vec8<T>*>(base + b_off[i] + ((q ^ b_swz[i]) << 4));
-            blo[i] = *reinterpret_cast<const vec8<T>*>(base + b_off[i] + (((4 + q) ^ b_swz[i]) << 4));
-        }
-#pragma unroll
-        for (int i = 0; i < MT; i++) {
-            ahi[i] = *reinterpret_cast<const vec8<T>*>(base + a_off[i] + ((q ^ a_swz[i]) << 4));
-            alo[i] = *reinterpret_cast<const vec8<T>*>(base + a_off[i] + (((4 + q) ^ a_swz[i]) << 4));
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) {
-                if (NPROD >= 4) acc[mt][nt] = mfma16x16(alo[mt], blo[nt], acc[mt][nt]);
-                acc[mt][nt] = mfma16x16(alo[mt], bhi[nt], acc[mt][nt]);
-                acc[mt][nt] = mfma16x16(ahi[mt], blo[nt], acc[mt][nt]);
-                acc[mt][nt] = mfma16x16(ahi[mt], bhi[nt], acc[mt][nt]);
+    if constexpr (WAVES == 8) {
+        for (int64_t t = 0; t < kt; t++) {
+            if (t + 1 < kt && !no_dma) stage(cur ^ 1, same_tile ? 0 : t + 1);
+            const char* base = smem + cur * kStageBytes;
+            vec8<T> ahi[MT], alo[MT], bhi[NT], blo[NT];
+    #pragma unroll
+            for (int i = 0; i < NT; i++) {
+                bhi[i] = *reinterpret_cast<const vec8<T>*>(base + b_off[i] + ((q ^ b_swz[i]) << 4));
+                blo[i] = *reinterpret_cast<const vec8<T>*>(base + b_off[i] + (((4 + q) ^ b_swz[i]) << 4));
             }
-        __syncthreads();
-        cur ^= 1;
+    #pragma unroll
+            for (int i = 0; i < MT; i++) {
+                ahi[i] = *reinterpret_cast<const vec8<T>*>(base + a_off[i] + ((q ^ a_swz[i]) << 4));
+                alo[i] = *reinterpret_cast<const vec8<T>*>(base + a_off[i] + (((4 + q) ^ a_swz[i]) << 4));
+            }
+    #pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+    #pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    if (NPROD >= 4) acc[mt][nt] = mfma16x16(alo[mt], blo[nt], acc[mt][nt]);
+                    acc[mt][nt] = mfma16x16(alo[mt], bhi[nt], acc[mt][nt]);
+                    acc[mt][nt] = mfma16x16(ahi[mt], blo[nt], acc[mt][nt]);
+                    acc[mt][nt] = mfma16x16(ahi[mt], bhi[nt], acc[mt][nt]);
+                }
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
+        // One wave per SIMD: every fragment a phase multiplies was requested a whole phase (1 024 MFMA cycles) earlier.
+        // Tile t: phase 1 = Alo x Bhi, phase 2 = Ahi x Blo, [barrier: stage t+1 has landed], phase 3 = Ahi x Bhi — per
+        // accumulator the order of the 8-wave kernel.  Alo(t+1) is read into Alo's registers during phase 3 (free after
+        // phase 1), Bhi(t+1) into Blo's (free after phase 2); Ahi(t), Blo(t) are read during phase 1.  The two B sets swap
+        // roles from one tile to the next, so the loop is unrolled by two.
+        // With one wave per SIMD every cycle the wave spends issuing anything but an MFMA is a cycle the matrix core
+        // idles (clumped in front of the phases, the 32 ds_reads, 16 LDS-DMA pieces and their address arithmetic cost
+        // 26 %: 28.1 vs 22.3 ms).  So (a) the non-MFMA instructions are dealt out BETWEEN the MFMAs, one per two or four of
+        // them, pinned by sched_barriers; (b) they need no vector arithmetic: the stage buffer is a compile-time constant
+        // (even k tiles use buffer 0: the body is instantiated per buffer), so every ds_read is base register +
+        // immediate, and the k tile's offset goes into the scalar base of the LDS-DMA.
+        mfma_drain();  // the zeroed accumulators (v_accvgpr_write) are settled before the first statement reads them
+        vec8<T> alo[MT], ahi[MT], b0[NT], b1[NT];
+        // per-lane LDS addresses within a stage: rows differ by multiples of 16, so the swizzle term is the same for all
+        // eight fragments of an operand half
+        const int a_lane_hi = a_off[0] + ((q ^ a_swz[0]) << 4), a_lane_lo = a_off[0] + (((4 + q) ^ a_swz[0]) << 4);
+        const int b_lane_hi = b_off[0] + ((q ^ b_swz[0]) << 4), b_lane_lo = b_off[0] + (((4 + q) ^ b_swz[0]) << 4);
+        auto rd = [&](int buf, int lane_off, int i) {
+            return *reinterpret_cast<const vec8<T>*>(smem + buf * kStageBytes + lane_off + i * 16 * kRowBytes);
+        };
+        auto dma = [&](int buf, int64_t tile, int g) {  // piece g of 16: A pieces even, B pieces odd
+            const int p = g >> 1;
+            const char* src = ((g & 1) ? b_tile : a_tile) + (size_t)tile * kRowBytes;  // uniform: scalar base
+            char* dst = smem + buf * kStageBytes + ((g & 1) ? TM * kRowBytes : 0) + (wave * PP + p) * 1024;
+            lds_dma16(src + ((g & 1) ? b_voff[p] : a_voff[p]), dst);
+        };
+#pragma unroll
+        for (int i = 0; i < MT; i++) alo[i] = rd(0, a_lane_lo, i);
+#pragma unroll
+        for (int i = 0; i < NT; i++) b0[i] = rd(0, b_lane_hi, i);
+        // STEADY: k tiles t+1 and t+2 exist (no conditions inside the interleaved schedule)
+        auto body = [&](vec8<T>(&bhi)[NT], vec8<T>(&blo)[NT], int64_t t, auto cur_c, auto steady_c) {
+            constexpr int CUR = decltype(cur_c)::value;
+            constexpr bool STEADY = decltype(steady_c)::value;
+            // Alo(t), Bhi(t) were requested a phase ago and have long arrived; said explicitly (lgkmcnt(0), free here):
+            // with 16 younger reads in flight the compiler could only express "all done" in the 4-bit counter
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_sched_barrier(0);
+            // phase 1: Alo x Bhi, and under it the reads of Blo(t), Ahi(t): one after every four MFMAs
+#pragma unroll
+            for (int g = 0; g < 16; g++) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) mfma16x16_pinned(acc[(4 * g + u) / NT][(4 * g + u) % NT], alo[(4 * g + u) / NT], bhi[(4 * g + u) % NT]);
+                if (g < NT) blo[g] = rd(CUR, b_lane_lo, g);
+                else ahi[g - NT] = rd(CUR, a_lane_hi, g - NT);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // phase 2: Ahi x Blo
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) mfma16x16_pinned(acc[mt][nt], ahi[mt], blo[nt]);
+            __builtin_amdgcn_sched_barrier(0);
+            // this wave's pieces of stage t+1 have landed (vmcnt(0), said explicitly: in one of the two instances of this
+            // body hipcc's own LDS-DMA tracking put no wait in front of the barrier), then everybody's
+            __builtin_amdgcn_s_waitcnt(0x0070);
+            __syncthreads();  // nobody reads stage t any more
+            __builtin_amdgcn_sched_barrier(0);
+            // phase 3: Ahi x Bhi; under its first half the reads of Bhi(t+1) (into Blo's registers) and Alo(t+1), under its
+            // second half the LDS-DMA of stage t+2 into the buffer tile t just left — a whole k tile ahead of its barrier
+            if constexpr (STEADY) {
+#pragma unroll
+                for (int g = 0; g < 32; g++) {
+#pragma unroll
+                    for (int u = 0; u < 2; u++) mfma16x16_pinned(acc[(2 * g + u) / NT][(2 * g + u) % NT], ahi[(2 * g + u) / NT], bhi[(2 * g + u) % NT]);
+                    if (g < NT) blo[g] = rd(CUR ^ 1, b_lane_hi, g);
+                    else if (g < 16) alo[g - NT] = rd(CUR ^ 1, a_lane_lo, g - NT);
+                    else dma(CUR, t + 2, g - 16);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                if (t + 2 < kt) {
+#pragma unroll
+                    for (int g = 0; g < 16; g++) dma(CUR, t + 2, g);
+                }
+                if (t + 1 < kt) {
+#pragma unroll
+                    for (int i = 0; i < NT; i++) blo[i] = rd(CUR ^ 1, b_lane_hi, i);
+#pragma unroll
+                    for (int i = 0; i < MT; i++) alo[i] = rd(CUR ^ 1, a_lane_lo, i);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) mfma16x16_pinned(acc[mt][nt], ahi[mt], bhi[nt]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        using std::integral_constant;
+        int64_t t = 0;
+        for (; t + 3 < kt; t += 2) {  // even tiles live in buffer 0
+            body(b0, b1, t, integral_constant<int, 0>{}, integral_constant<bool, true>{});
+            body(b1, b0, t + 1, integral_constant<int, 1>{}, integral_constant<bool, true>{});
+        }
+        for (; t + 1 < kt; t += 2) {
+            body(b0, b1, t, integral_constant<int, 0>{}, integral_constant<bool, false>{});
+            body(b1, b0, t + 1, integral_constant<int, 1>{}, integral_constant<bool, false>{});
+        }
+        if (t < kt) body(b0, b1, t, integral_constant<int, 0>{}, integral_constant<bool, false>{});
+        mfma_drain();
     }
     if (DIAG) st[3] = __builtin_amdgcn_s_memtime();
     if (MODE == EDGES) {
@@ -233,7 +394,7 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
         // so the exact test (global indices, diagonal, block edge) runs for the few candidates only.
         const float thr = rk != 0.f && !accumulate ? es.cutoff * kdiv : -INFINITY;
         auto cell = [&](int mt, int nt, int e, float& w, unsigned long long& key) -> bool {
-            const int64_t n = col_base + wn * 64 + nt * 16 + (lane & 15);
+            const int64_t n = col_base + wn * WTN + nt * 16 + (lane & 15);
             const int64_t m = row_base + wm * 128 + mt * 16 + 4 * q + e;
             const bool inside = m < M && n < N;
             w = rk != 0.f ? acc[mt][nt][e] * rk : acc[mt][nt][e] / kdiv;
@@ -242,7 +403,7 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
             key = ((unsigned long long)grow << 32) | (unsigned long long)gcol;
             return inside && !(w < es.cutoff) && w != 0.f && (es.upper ? gcol > grow : gcol != grow);
         };
-        uint32_t bits[4] = {0u, 0u, 0u, 0u};
+        uint32_t bits[MT * NT / 8] = {};
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
@@ -256,7 +417,9 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
                         if (cell(mt, nt, e, w, key)) bits[idx >> 5] |= 1u << (idx & 31);
                     }
                 }
-        const uint32_t mine = __popc(bits[0]) + __popc(bits[1]) + __popc(bits[2]) + __popc(bits[3]);
+        uint32_t mine = 0;
+#pragma unroll
+        for (int w = 0; w < MT * NT / 8; w++) mine += __popc(bits[w]);
         uint32_t incl = mine;  // inclusive scan over the wave
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -296,7 +459,7 @@ __global__ __launch_bounds__(512, 2) void pearson_gemm_split16_kernel(
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
-            const int64_t n = col_base + wn * 64 + nt * 16 + (lane & 15);
+            const int64_t n = col_base + wn * WTN + nt * 16 + (lane & 15);
             const int64_t m0 = row_base + wm * 128 + mt * 16 + 4 * q;
             float v[4];
 #pragma unroll
@@ -409,20 +572,30 @@ int launch_chunk(skr_ctx* ctx, const T* Ac, const T* Bc, const SplitOut& o, int6
             kern = pearson_gemm_split16_kernel<T, NPROD, (MODE == SELF ? SELF : PLAIN), true, true>;
         }
 #endif
+        unsigned threads = 512;
+#ifdef SEEKR_DIAG
+        if constexpr (NPROD == 3) {
+            // A/B arm (libseekr_hip_diag.so only; measured 13 % slower): 4 waves x 128 x 128 (kernel comment)
+            if (ctx->knobs.gemm_wave_tile == 1 && !diag) {
+                kern = pearson_gemm_split16_kernel<T, NPROD, MODE, true, false, 4>;
+                threads = 256;
+            }
+        }
+#endif
         SKR_TRY(skr_kernel_lds(ctx, reinterpret_cast<const void*>(kern), 2 * kStageBytes));
         // A resident workgroup owns its CU outright (8 waves x ~248 VGPRs, 128 KiB LDS): with RCCL traffic
         // in flight on the communication stream a few CUs are left free, or the send/recv kernels of
         // shift s+1 could not start before this launch ends and the overlap of §5 would be lost.
         const int reserve = ctx->knobs.gemm_reserve_cus >= 0 ? ctx->knobs.gemm_reserve_cus : (ctx->nranks > 1 ? 8 : 0);
         const unsigned grid = (unsigned)std::max(8, ctx->num_cu - reserve);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 2 * kStageBytes, ctx->stream, Ac, Bc, o.C, o.Ct, M, N, ktc, o.ldc, o.ldct, K,
-                           tiles_m, tiles_n, super_n, queues, slots / 8, kt_pitch, accumulate, diag, es);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), 2 * kStageBytes, ctx->stream, Ac, Bc, o.C, o.Ct, M, N, ktc, o.ldc, o.ldct, K,
+                           tiles_m, tiles_n, super_n, queues, slots / 8, kt_pitch, accumulate | (ctx->knobs.gemm_subtile << 8), diag, es);
     } else {
         auto kern = pearson_gemm_split16_kernel<T, NPROD, MODE, false>;
         SKR_TRY(skr_kernel_lds(ctx, reinterpret_cast<const void*>(kern), 2 * kStageBytes));
         hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(512), 2 * kStageBytes, ctx->stream, Ac, Bc, o.C, o.Ct, M, N, ktc, o.ldc,
-                           o.ldct, K, tiles_m, tiles_n, super_n, (uint32_t*)nullptr, (int64_t)0, kt_pitch, accumulate,
-                           (unsigned long long*)nullptr, es);
+                           o.ldct, K, tiles_m, tiles_n, super_n, (uint32_t*)nullptr, (int64_t)0, kt_pitch,
+                           accumulate | (ctx->knobs.gemm_subtile << 8), (unsigned long long*)nullptr, es);
     }
     SKR_HIP(hipGetLastError());
     return SKR_OK;

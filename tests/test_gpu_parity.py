@@ -1130,3 +1130,18 @@ def test_g7_alphabets_other_than_four_letters(golden_dir, tmp_path):
     c.seqs = ["ACGTA", "AC"]
     with pytest.raises(ZeroDivisionError):
         c.get_counts()
+
+
+
+def test_four_wave_geometry_gives_the_same_bits():
+    """The 4-wave / 128 x 128 wave-tile arm of the split contraction (libseekr_hip_diag.so only: measured
+    13 % slower and not shipped) adds the same products to every accumulator in the same order as the 8-wave kernel: r
+    the same bits in SELF, PLAIN, CROSS and thresholding mode, several k chunks, ragged edges (tools/w4_check.py)."""
+    import subprocess
+    import sys
+    from seekr_amd import _lib
+    if not os.path.exists(_lib.DIAG_LIB_PATH):
+        pytest.skip("libseekr_hip_diag.so is not built (python -m seekr_amd.build --diag)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "w4_check.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "w4 check ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

@@ -11,8 +11,9 @@ import bench  # noqa: E402  (stdlib + numpy only at import time)
 
 out_dir, prec = sys.argv[1], sys.argv[2]
 extra = sys.argv[3:]  # the extra bench.py arguments the passes ran with (tools/profile.sh)
-b_args = bench.parse(["--precision", prec] + extra)
-rows = b_args.rows or 50000
+is_bench = prec in ("fp32", "bf16x3", "bf16x4", "f16x3")  # else: the passes ran another program (tools/pmc_gemm.sh)
+b_args = bench.parse(["--precision", prec] + extra) if is_bench else None
+rows = (b_args.rows or 50000) if is_bench else 0
 acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
 for path in sorted(glob.glob(os.path.join(out_dir, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
     with open(path, newline="") as fh:
@@ -22,10 +23,13 @@ for path in sorted(glob.glob(os.path.join(out_dir, "pmc*", "**", "*counter_colle
             cell = acc[name][row["Counter_Name"]]
             cell[0] += float(row["Counter_Value"])
             cell[1] += 1
-print("# rocprofv3 --pmc passes (separate runs, --kernel-trace only) of: python3 bench.py --steps 2 --warmup 1 "
-      "--no-cpu-baseline --precision {} {}".format(prec, " ".join(extra)).rstrip())
-# what bench.py's pmc_traffic() matches before it quotes a number from this file
-print("# workload: " + bench.workload_key(rows, b_args.length, b_args.k, prec, 1))
+if is_bench:
+    print("# rocprofv3 --pmc passes (separate runs, --kernel-trace only) of: python3 bench.py --steps 2 --warmup 1 "
+          "--no-cpu-baseline --precision {} {}".format(prec, " ".join(extra)).rstrip())
+    # what bench.py's pmc_traffic() matches before it quotes a number from this file
+    print("# workload: " + bench.workload_key(rows, b_args.length, b_args.k, prec, 1))
+else:
+    print("# rocprofv3 --pmc passes (separate runs, --kernel-trace only): " + " ".join([prec] + extra))
 print("# kernel_symbols_sha256: " + bench.kernel_symbols_sha256(os.path.join(bench.ROOT, "seekr_amd", "libseekr_hip.so")))
 print("# per-dispatch averages; FETCH_SIZE / WRITE_SIZE in KiB as reported (gfx950: FETCH_SIZE counts 1/2 of wide "
       "coalesced reads, see MI355X_MICROARCH.md)")
