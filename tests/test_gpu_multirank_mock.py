@@ -75,13 +75,20 @@ def test_all_shifts_posted_as_one_group(size, mock_lib, single, tmp_path):
 
 def check_ranks(size, asynchronous, mock_lib, single, tmp_path, extra_env=None):
     """asynchronous = 1: the mock enqueues its copies and waits on the communication stream like RCCL's
-    kernels, so the product's event / ticket waits between the two streams are what keeps the data right."""
-    env = dict(os.environ, WORLD_SIZE=str(size), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), LOCAL_RANK="0",
-               SEEKR_TEST_HOOKS="1", SEEKR_RCCL_LIB=mock_lib, MOCK_RCCL_ASYNC=str(asynchronous))
+    kernels, so the product's event / ticket waits between the two streams are what keeps the data right.
+    mock_lib = None: the real librccl, one GPU per rank (tests/test_gpu_multirank_real.py)."""
+    env = dict(os.environ, WORLD_SIZE=str(size), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    if mock_lib is not None:
+        env.update(LOCAL_RANK="0", SEEKR_TEST_HOOKS="1", SEEKR_RCCL_LIB=mock_lib, MOCK_RCCL_ASYNC=str(asynchronous))
+    else:
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        for key in ("SEEKR_TEST_HOOKS", "SEEKR_RCCL_LIB", "SEEKR_FORCE_DEVICE"):
+            env.pop(key, None)
     env.update(extra_env or {})
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mock_rank_worker.py"), str(tmp_path),
                                str(single["n_total"]), str(single["length"]), str(single["k"])],
-                              env=dict(env, RANK=str(rank)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                              env=dict(env, RANK=str(rank), **({} if mock_lib is not None else {"LOCAL_RANK": str(rank)})),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for rank in range(size)]
     for rank, p in enumerate(procs):
         out, _ = p.communicate(timeout=300)

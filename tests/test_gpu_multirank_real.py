@@ -1,0 +1,61 @@
+"""The N > 1 path over the REAL librccl, one GPU per rank.  The pool's boxes have one GPU, so these
+tests skip there; on any box with two or more GPUs they are the first thing to run: launch.init's rendezvous and
+self-test, the rank-chained float32 column sums, the NaN-min all-reduce, both Pearson layouts (symmetric half ring with
+its split first shift, row blocks), the striped edge lists — same worker and same assertions as the mock-transport test
+(tests/test_gpu_multirank_mock.py::check_ranks): statistics and normalised counts bit-identical to the single-GPU run, r
+and edges equal to it — and bench.py starting its own rank processes."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _gpus():
+    try:
+        from seekr_amd import _lib
+        return _lib.device_count()
+    except Exception:  # noqa: BLE001 - library not built yet: nothing to run here
+        return 0
+
+
+needs2 = pytest.mark.skipif(_gpus() < 2, reason="needs two GPUs (the pool's boxes have one)")
+needs4 = pytest.mark.skipif(_gpus() < 4, reason="needs four GPUs")
+
+
+@needs2
+def test_two_ranks_over_real_rccl_equal_single_gpu(tmp_path):
+    from test_gpu_multirank_mock import check_ranks, single_gpu_reference
+    check_ranks(2, 0, None, single_gpu_reference(1101, 600, 6), tmp_path)
+
+
+@needs4
+@pytest.mark.parametrize("size", [3, 4])
+def test_more_ranks_over_real_rccl_equal_single_gpu(size, tmp_path):
+    from test_gpu_multirank_mock import check_ranks, single_gpu_reference
+    check_ranks(size, 0, None, single_gpu_reference(1101, 600, 6), tmp_path)
+
+
+@needs2
+def test_k7_over_real_rccl(tmp_path):
+    from test_gpu_multirank_mock import check_ranks, single_gpu_reference
+    check_ranks(2, 0, None, single_gpu_reference(520, 900, 7), tmp_path)
+
+
+@needs2
+@pytest.mark.parametrize("extra", [[], ["--grouped-shifts"], ["--layout", "rowblock"]])
+def test_bench_starts_two_real_ranks(extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR",
+                                                               "SEEKR_TEST_HOOKS", "SEEKR_RCCL_LIB", "SEEKR_FORCE_DEVICE")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "12000",
+           "--length", "500"] + extra
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["value"] > 0 and "layout_fallback" not in out
+    assert len(out["per_rank"]["comm_ms"]) == 2
