@@ -153,6 +153,26 @@ int skr_colsum_seq(skr_ctx* ctx, const skr_mat* x, const skr_mat* center, const 
  * Log2.post shift of kmer_counts.py:208 without a pass over the matrix.  The column count must be a multiple of 16
  * (SKR_ERR_UNSUPPORTED otherwise: use skr_colsum_seq + skr_min_nan on x).                                          */
 int skr_colsum_seq_colmin(skr_ctx* ctx, const skr_mat* x, skr_mat* acc, skr_mat* colmin);
+/* The same chain across the GPUs of a node WITHOUT a transfer between two kernels (one process per GPU).  Every rank
+ * creates a chain (a mailbox in uncached device memory for up to cols_cap columns), exports it as a 64-byte HIP IPC
+ * handle, and connects with the handles of all ranks (exchanged by the caller, e.g. through skr_comm_allgather_rows of a
+ * [nranks, 16] float32 matrix).  skr_colsum_seq_chain then runs one pass on this rank: its kernel waits — inside the
+ * kernel, its loads already in flight — for rank - 1's running sums, continues them over this rank's rows in row order
+ * and stores them into rank + 1's mailbox (a peer store over xGMI); the last rank stores the finished sums into every
+ * rank's result box, from where they are copied into `acc`.  On return (stream order) acc holds the sums over all
+ * ranks' rows: bit-identical to one GPU walking all rows.  colmin as in skr_colsum_seq_colmin, or NULL.  All ranks make
+ * the same sequence of calls.  skr_chain_check reports (and clears) whether a wait gave up because a peer never
+ * delivered (about half a minute).  skr_chain_connect_local connects chains that live in ONE process (emulation, tests). */
+typedef struct skr_chain skr_chain;
+int skr_chain_create(skr_ctx* ctx, int64_t cols_cap, skr_chain** out);
+int skr_chain_export(skr_chain* chain, char handle[64]);
+int skr_chain_connect(skr_chain* chain, int nranks, int rank, const char* handles /* [nranks][64] */);
+int skr_chain_connect_local(skr_chain* chain, int nranks, int rank, skr_chain* const* all);
+int skr_colsum_seq_chain(skr_chain* chain, const skr_mat* x, const skr_mat* center, const skr_mat* center2, int square,
+                         skr_mat* acc, skr_mat* colmin, int defer_result /* 0; 1: skr_chain_result comes later (emulation on one stream) */);
+int skr_chain_result(skr_chain* chain, skr_mat* acc);
+int skr_chain_check(skr_chain* chain, int* timed_out);
+int skr_chain_free(skr_chain* chain);
 /* v[j] = fl32(v[j] / fl32(n));  if take_sqrt: v[j] = sqrt_rn(that)  (np.mean / np.std tail) */
 int skr_vec_finish(skr_ctx* ctx, skr_mat* v, int64_t n, int take_sqrt);
 /* NaN-propagating minimum (np.min, kmer_counts.py:208) of z = (x - center) / scale over the

@@ -60,6 +60,14 @@ SIGNATURES = {
     "skr_count_per_kb": (_int, [_p, _p, _int, _int, _p]),
     "skr_colsum_seq": (_int, [_p, _p, _p, _p, _int, _p]),
     "skr_colsum_seq_colmin": (_int, [_p, _p, _p, _p]),
+    "skr_chain_create": (_int, [_p, _i64, C.POINTER(_p)]),
+    "skr_chain_export": (_int, [_p, C.c_char_p]),
+    "skr_chain_connect": (_int, [_p, _int, _int, C.c_char_p]),
+    "skr_chain_connect_local": (_int, [_p, _int, _int, C.POINTER(_p)]),
+    "skr_colsum_seq_chain": (_int, [_p, _p, _p, _p, _int, _p, _p, _int]),
+    "skr_chain_result": (_int, [_p, _p]),
+    "skr_chain_check": (_int, [_p, C.POINTER(_int)]),
+    "skr_chain_free": (_int, [_p]),
     "skr_vec_finish": (_int, [_p, _p, _i64, _int]),
     "skr_min_nan": (_int, [_p, _p, _p, _p, C.POINTER(C.c_float), C.POINTER(_int)]),
     "skr_apply": (_int, [_p, _p, _int, _p, _p, _int, C.c_float, _p, C.POINTER(_int)]),
@@ -505,6 +513,56 @@ def colsum_seq_colmin(ctx, x, acc, colmin):
     """First pass of the column sums that also leaves the raw column minima in `colmin` [4, cols]."""
     check(lib().skr_colsum_seq_colmin(ctx._h, x._h, acc._h, colmin._h))
     return acc
+
+
+class Chain:
+    """The mailboxes of the column-sum chain across GPUs (skr_chain): peer stores instead of a send/recv per hop."""
+
+    def __init__(self, ctx, cols_cap):
+        self.ctx, self.cols_cap = ctx, int(cols_cap)
+        self._h = _p()
+        check(lib().skr_chain_create(ctx._h, self.cols_cap, C.byref(self._h)))
+
+    def export(self):
+        buf = C.create_string_buffer(64)
+        check(lib().skr_chain_export(self._h, buf))
+        return buf.raw
+
+    def connect(self, rank, handles):
+        """handles: the 64-byte handle of every rank, in rank order."""
+        blob = b"".join(handles)
+        assert len(blob) == 64 * len(handles)
+        check(lib().skr_chain_connect(self._h, len(handles), int(rank), blob))
+
+    def connect_local(self, rank, chains):
+        arr = (_p * len(chains))(*[c._h for c in chains])
+        check(lib().skr_chain_connect_local(self._h, len(chains), int(rank), arr))
+
+    def colsum(self, x, acc, center=None, center2=None, square=False, colmin=None, defer_result=False):
+        check(lib().skr_colsum_seq_chain(self._h, x._h, _h(center), _h(center2), 1 if square else 0, acc._h, _h(colmin),
+                                         1 if defer_result else 0))
+        return acc
+
+    def result(self, acc):
+        """The deferred half of colsum(defer_result=True): wait for the result box and copy it into acc."""
+        check(lib().skr_chain_result(self._h, acc._h))
+        return acc
+
+    def timed_out(self):
+        flag = _int(0)
+        check(lib().skr_chain_check(self._h, C.byref(flag)))
+        return bool(flag.value)
+
+    def free(self):
+        if getattr(self, "_h", None) and not _shutdown and getattr(self.ctx, "_h", None):
+            lib().skr_chain_free(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 def vec_finish(ctx, v, n, take_sqrt=False):

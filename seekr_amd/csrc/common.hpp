@@ -23,6 +23,9 @@ struct SkrKnobs {
     bool count_persist = false;  // SEEKR_COUNT_PERSIST=1: persistent grid at k <= 6
     bool count_legacy = false;   // SEEKR_COUNT_LEGACY=1: the round-1 counting kernel
     int count_wps = 0;           // SEEKR_COUNT_WPS: waves per sequence (0 = by k)
+    bool chain_host_wait = false;  // SEEKR_CHAIN_HOST_WAIT=1 (only under SEEKR_TEST_HOOKS=1): the column-sum chain waits for its
+                                   // mailbox on the HOST before it launches — several ranks sharing one GPU (tests) cannot wait
+                                   // inside a kernel: the waiting kernel fills the CUs and the one it waits for never starts
 };
 
 struct skr_ctx {

@@ -55,6 +55,7 @@ extern "C" int skr_ctx_reload_knobs(skr_ctx* c) {
     kn.count_persist = env_int("SEEKR_COUNT_PERSIST", 0) != 0;
     kn.count_legacy = env_int("SEEKR_COUNT_LEGACY", 0) != 0;
     kn.count_wps = env_int("SEEKR_COUNT_WPS", 0);
+    kn.chain_host_wait = env_int("SEEKR_TEST_HOOKS", 0) == 1 && env_int("SEEKR_CHAIN_HOST_WAIT", 0) != 0;
     return SKR_OK;
 }
 

@@ -9,6 +9,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
+#include <unistd.h>
+#include <vector>
 
 #include "common.hpp"
 
@@ -58,11 +61,66 @@ __device__ __forceinline__ float div_scale(float x, const void* vec, int64_t col
 // `colmin` [4, cols] (NaN where it met a NaN).  Rounding is monotone, so the minimum of the NORMALISED matrix over a
 // column is the normalised minimum of the raw column (for scale >= 0): the Log2.post shift |min z| (kmer_counts.py:208)
 // then needs a scan of these four rows instead of a pass over the matrix.
+// ---- the chain across GPUs without a transfer in between (skr_chain): rank g's walker of strip s waits — the staging
+// ring already full — until rank g-1 has put the strip's 16 running sums into rank g's mailbox (peer stores over xGMI
+// into uncached memory + an epoch word per strip), continues the chain over its own rows and passes the sums on the
+// same way; the last rank writes the finished sums into every rank's result box.  Against ncclSend / ncclRecv of the
+// vector between two kernels (tools/chain_bench.py: 41 us per hop + 24 us of kernel start, x 7 hops x 3 passes) a hop is
+// one peer store and one poll.
+constexpr int kMaxChainRanks = 16;
+struct ChainLink {
+    const float* carry_in = nullptr;       // this rank's mailbox (written by rank - 1); null on rank 0 / unchained
+    const uint32_t* carry_flag = nullptr;  // [strips]
+    float* next_data = nullptr;            // rank + 1's mailbox; null on the last rank
+    uint32_t* next_flag = nullptr;
+    float* result_data[kMaxChainRanks] = {};  // last rank only: every other rank's result box
+    uint32_t* result_flag[kMaxChainRanks] = {};
+    int n_result = 0;
+    uint32_t epoch = 0;
+    uint32_t* err = nullptr;  // set when a wait gave up (a peer died): the host raises instead of the kernel hanging
+};
+
+constexpr long kChainSpinMax = 1L << 25;  // polls of ~1 us each: half a minute
+__device__ __forceinline__ void chain_wait(const uint32_t* flag, uint32_t epoch, uint32_t* err) {
+    // relaxed polls (an acquire per poll would invalidate the caches under the staging waves), one acquire at the end
+    for (long i = 0; i < kChainSpinMax; i++) {
+        const uint32_t v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((int32_t)(v - epoch) >= 0) {
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            return;
+        }
+        __builtin_amdgcn_s_sleep(4);
+    }
+    if (err) atomicOr(err, 1u);
+}
+__device__ __forceinline__ float chain_load(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void chain_store(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// the wave's lanes < 16 hold one column each of strip `strip`: write them to every box the link names (the next rank's
+// carry box, or on the last rank all result boxes), ONE system-scope release for all of them, then raise the epoch words
+__device__ __forceinline__ void chain_post_all(const ChainLink& link, int64_t strip, int64_t col, bool mine, float v, int lane) {
+    if (!link.next_data && link.n_result == 0) return;
+    if (mine) {
+        if (link.next_data) chain_store(link.next_data + col, v);
+        for (int r = 0; r < link.n_result; r++) chain_store(link.result_data[r] + col, v);
+    }
+    __threadfence_system();
+    if (lane == 0) {
+        if (link.next_flag) __hip_atomic_store(link.next_flag + strip, link.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int r = 0; r < link.n_result; r++)
+            __hip_atomic_store(link.result_flag[r] + strip, link.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 template <int CK, bool SQUARE, bool VEC, bool MINOUT = false>
 __global__ __launch_bounds__(kWgThreads) void colsum_seq_kernel(const float* __restrict__ x, int64_t rows,
                                                               int64_t cols, const void* __restrict__ center,
                                                               const float* __restrict__ center2,
-                                                              float* __restrict__ acc, float* __restrict__ colmin = nullptr) {
+                                                              float* __restrict__ acc, float* __restrict__ colmin,
+                                                              const ChainLink link) {
     // column-major tile so that the walker fetches 4 consecutive rows of its column with one
     // ds_read_b128; +4 floats of padding per column keep the 16 walker lanes on distinct banks
     __shared__ __attribute__((aligned(16))) float tile[2][kColsPerWG][kTileRows + 4];
@@ -89,6 +147,12 @@ __global__ __launch_bounds__(kWgThreads) void colsum_seq_kernel(const float* __r
         float running = mine ? acc[col0 + wl] : 0.f;
         for (int64_t t = -kDepth; t < n_pad; t++) {
             __syncthreads();  // tile t is in buffer t & 1 (the first kDepth rounds only fill the stagers' ring)
+            if (t == 0 && link.carry_flag) {
+                // the previous rank's sums of this strip: waited for HERE, with kDepth tiles of this rank's rows already
+                // on their way (the stagers stand at the next barrier), not in front of the launch
+                if (wl == 0) chain_wait(link.carry_flag + strip, link.epoch, link.err);
+                running = mine ? chain_load(link.carry_in + col0 + wl) : 0.f;
+            }
             if (wl < kColsPerWG && t >= 0 && t < n_tiles) {
                 const int64_t left = rows - t * kTileRows;
                 const int nr = (int)(left < kTileRows ? left : kTileRows);
@@ -134,6 +198,7 @@ __global__ __launch_bounds__(kWgThreads) void colsum_seq_kernel(const float* __r
             // which this wave reaches when it is done here
         }
         if (mine) acc[col0 + wl] = running;
+        chain_post_all(link, strip, col0 + wl, mine, running, wl);
         return;
     }
     // ---- the staging waves
@@ -247,6 +312,35 @@ __global__ __launch_bounds__(kWgThreads) void colsum_seq_kernel(const float* __r
                 if (col0 + lane_c4 + j < cols) colmin[(size_t)swave * cols + col0 + lane_c4 + j] = m[j];
         }
     }
+}
+
+// A rank without rows still passes the sums on: one thread per column, one wave per four strips.
+__global__ __launch_bounds__(64) void chain_forward_kernel(int64_t cols, float* __restrict__ acc, const ChainLink link) {
+    const int lane = threadIdx.x, wl = lane & 15;
+    const int64_t strip = (int64_t)blockIdx.x * 4 + (lane >> 4);
+    const int64_t col = strip * kColsPerWG + wl;
+    const bool mine = col < cols;
+    float v = mine ? acc[col] : 0.f;
+    if (link.carry_flag && strip * kColsPerWG < cols) {
+        if (wl == 0) chain_wait(link.carry_flag + strip, link.epoch, link.err);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (link.carry_flag && mine) v = chain_load(link.carry_in + col);
+    if (mine) acc[col] = v;
+    if (strip * kColsPerWG >= cols) return;
+    chain_post_all(link, strip, col, mine, v, wl);
+}
+
+// Every rank but the last: the finished sums arrive in the result box, strip by strip; copy them into acc.
+__global__ __launch_bounds__(64) void chain_result_kernel(int64_t cols, float* __restrict__ acc, const float* __restrict__ box,
+                                                          const uint32_t* __restrict__ flag, uint32_t epoch, uint32_t* err) {
+    const int lane = threadIdx.x, wl = lane & 15;
+    const int64_t strip = (int64_t)blockIdx.x * 4 + (lane >> 4);
+    const int64_t col = strip * kColsPerWG + wl;
+    if (strip * kColsPerWG >= cols) return;
+    if (wl == 0) chain_wait(flag + strip, epoch, err);
+    __builtin_amdgcn_wave_barrier();
+    if (col < cols) acc[col] = chain_load(box + col);
 }
 
 __global__ void vec_finish_kernel(float* v, int64_t cols, float n, int take_sqrt) {
@@ -419,8 +513,10 @@ int check_f32(const skr_ctx* ctx, const skr_mat* m, const char* what) {
 
 }  // namespace
 
-extern "C" int skr_colsum_seq(skr_ctx* ctx, const skr_mat* x, const skr_mat* center, const skr_mat* center2,
-                              int square, skr_mat* acc) {
+// One launch of the column-sum kernel: plain (link empty), with the column minima (colmin != NULL: first pass only), or
+// as a link of the chain across GPUs.
+static int launch_colsum(skr_ctx* ctx, const skr_mat* x, const skr_mat* center, const skr_mat* center2, int square, skr_mat* acc,
+                         skr_mat* colmin, const ChainLink& link) {
     SKR_REQUIRE(ctx, "ctx is NULL");
     SKR_TRY(check_f32(ctx, x, "x"));
     SKR_TRY(check_f32(ctx, acc, "acc"));
@@ -432,55 +528,267 @@ extern "C" int skr_colsum_seq(skr_ctx* ctx, const skr_mat* x, const skr_mat* cen
         SKR_TRY(check_f32(ctx, center2, "center2"));
         SKR_REQUIRE(center2->rows * center2->cols == x->cols, "center2 must hold one float per column");
     }
+    if (colmin) {
+        SKR_TRY(check_f32(ctx, colmin, "colmin"));
+        SKR_REQUIRE(!center && !square, "the column minima ride on the first pass (no centre, no square)");
+        SKR_REQUIRE(colmin->rows == 4 && colmin->cols == x->cols, "colmin must be [4, %lld]", (long long)x->cols);
+        if (x->cols % kColsPerWG != 0 || x->rows == 0)
+            return skr_set_error(SKR_ERR_UNSUPPORTED, "column minima ride on the vector path: the column count must be a multiple of %d",
+                                 kColsPerWG);
+    }
     SKR_TRY(skr_activate(ctx));
-    if (x->cols == 0 || x->rows == 0) return SKR_OK;  // no rows: acc stays as it is
+    if (x->cols == 0) return SKR_OK;
     const unsigned grid = (unsigned)((x->cols + kColsPerWG - 1) / kColsPerWG);
+    if (x->rows == 0) {  // no rows: acc stays as it is — but a link of the chain still passes the sums on
+        if (link.carry_flag || link.next_data || link.n_result) {
+            hipLaunchKernelGGL(chain_forward_kernel, dim3((grid + 3) / 4), dim3(64), 0, ctx->stream, x->cols, (float*)acc->data, link);
+            SKR_HIP(hipGetLastError());
+        }
+        return SKR_OK;
+    }
     const float* c2 = center2 ? (const float*)center2->data : nullptr;
     const void* c1 = center ? center->data : nullptr;
+    float* cm = colmin ? (float*)colmin->data : nullptr;
     SkrProfScope prof(ctx, square ? "colsum_seq_sq" : "colsum_seq");
     const bool vec = x->cols % kColsPerWG == 0;  // every strip is full: 16-byte loads
-#define LAUNCH(CK_, SQ_)                                                                                         \
-    do {                                                                                                         \
-        if (vec)                                                                                                 \
-            hipLaunchKernelGGL((colsum_seq_kernel<CK_, SQ_, true>), dim3(grid), dim3(kWgThreads), 0, ctx->stream, \
-                               (const float*)x->data, x->rows, x->cols, c1, c2, (float*)acc->data);              \
-        else                                                                                                     \
-            hipLaunchKernelGGL((colsum_seq_kernel<CK_, SQ_, false>), dim3(grid), dim3(kWgThreads), 0, ctx->stream, \
-                               (const float*)x->data, x->rows, x->cols, c1, c2, (float*)acc->data);              \
+#define LAUNCH(CK_, SQ_, MIN_)                                                                                         \
+    do {                                                                                                               \
+        if (vec)                                                                                                       \
+            hipLaunchKernelGGL((colsum_seq_kernel<CK_, SQ_, true, MIN_>), dim3(grid), dim3(kWgThreads), 0, ctx->stream, \
+                               (const float*)x->data, x->rows, x->cols, c1, c2, (float*)acc->data, cm, link);          \
+        else                                                                                                           \
+            hipLaunchKernelGGL((colsum_seq_kernel<CK_, SQ_, false, false>), dim3(grid), dim3(kWgThreads), 0, ctx->stream, \
+                               (const float*)x->data, x->rows, x->cols, c1, c2, (float*)acc->data, cm, link);          \
     } while (0)
-    if (square) {
-        if (ck == C_NONE) LAUNCH(C_NONE, true);
-        else if (ck == C_F32) LAUNCH(C_F32, true);
-        else LAUNCH(C_F64, true);
+    if (colmin) {
+        LAUNCH(C_NONE, false, true);
+    } else if (square) {
+        if (ck == C_NONE) LAUNCH(C_NONE, true, false);
+        else if (ck == C_F32) LAUNCH(C_F32, true, false);
+        else LAUNCH(C_F64, true, false);
     } else {
-        if (ck == C_NONE) LAUNCH(C_NONE, false);
-        else if (ck == C_F32) LAUNCH(C_F32, false);
-        else LAUNCH(C_F64, false);
+        if (ck == C_NONE) LAUNCH(C_NONE, false, false);
+        else if (ck == C_F32) LAUNCH(C_F32, false, false);
+        else LAUNCH(C_F64, false, false);
     }
 #undef LAUNCH
     SKR_HIP(hipGetLastError());
     return SKR_OK;
 }
 
+extern "C" int skr_colsum_seq(skr_ctx* ctx, const skr_mat* x, const skr_mat* center, const skr_mat* center2,
+                              int square, skr_mat* acc) {
+    return launch_colsum(ctx, x, center, center2, square, acc, nullptr, ChainLink{});
+}
+
 // First pass of the column statistics with the column minima of the raw matrix as a by-product (see MINOUT above).
 // colmin: float32 [4, cols]; min over its four rows = the column's minimum (NaN if the column holds a NaN).
 extern "C" int skr_colsum_seq_colmin(skr_ctx* ctx, const skr_mat* x, skr_mat* acc, skr_mat* colmin) {
-    SKR_REQUIRE(ctx, "ctx is NULL");
-    SKR_TRY(check_f32(ctx, x, "x"));
-    SKR_TRY(check_f32(ctx, acc, "acc"));
-    SKR_TRY(check_f32(ctx, colmin, "colmin"));
-    SKR_REQUIRE(acc->rows * acc->cols == x->cols, "acc must hold one float per column");
-    SKR_REQUIRE(colmin->rows == 4 && colmin->cols == x->cols, "colmin must be [4, %lld]", (long long)x->cols);
-    if (x->cols % kColsPerWG != 0 || x->rows == 0)
-        return skr_set_error(SKR_ERR_UNSUPPORTED, "column minima ride on the vector path: the column count must be a multiple of %d",
-                             kColsPerWG);
+    SKR_REQUIRE(colmin, "colmin is NULL");
+    return launch_colsum(ctx, x, nullptr, nullptr, 0, acc, colmin, ChainLink{});
+}
+
+// ---------------------------------------------------------------------------------------
+// skr_chain: the mailboxes of the column-sum chain across GPUs (ChainLink above).  Every rank owns one block of
+// UNCACHED device memory — carry box + result box, one float per column each, and an epoch word per strip for either —
+// exports it as a HIP IPC handle and opens the other ranks' blocks; a kernel then stores straight into a peer's block.
+// ---------------------------------------------------------------------------------------
+struct skr_chain {
+    skr_ctx* ctx = nullptr;
+    int64_t cols_cap = 0, strips_cap = 0;
+    char* block = nullptr;  // own mailbox
+    size_t bytes = 0;
+    int nranks = 1, rank = 0;
+    char* peer[kMaxChainRanks] = {};     // every rank's mailbox as seen from here (peer[rank] == block)
+    bool opened[kMaxChainRanks] = {};    // came from hipIpcOpenMemHandle (to be closed)
+    uint32_t epoch = 0;
+    uint32_t* d_err = nullptr;
+    float* carry(char* b) const { return (float*)b; }
+    float* result(char* b) const { return (float*)b + cols_cap; }
+    uint32_t* carry_flag(char* b) const { return (uint32_t*)((float*)b + 2 * cols_cap); }
+    uint32_t* result_flag(char* b) const { return carry_flag(b) + strips_cap; }
+};
+
+extern "C" int skr_chain_create(skr_ctx* ctx, int64_t cols_cap, skr_chain** out) {
+    SKR_REQUIRE(ctx && out && cols_cap > 0, "bad argument");
+    *out = nullptr;
     SKR_TRY(skr_activate(ctx));
-    const unsigned grid = (unsigned)(x->cols / kColsPerWG);
-    SkrProfScope prof(ctx, "colsum_seq");
-    hipLaunchKernelGGL((colsum_seq_kernel<C_NONE, false, true, true>), dim3(grid), dim3(kWgThreads), 0, ctx->stream,
-                       (const float*)x->data, x->rows, x->cols, (const void*)nullptr, (const float*)nullptr, (float*)acc->data,
-                       (float*)colmin->data);
+    skr_chain* c = new skr_chain();
+    c->ctx = ctx;
+    c->cols_cap = (cols_cap + kColsPerWG - 1) / kColsPerWG * kColsPerWG;
+    c->strips_cap = c->cols_cap / kColsPerWG;
+    c->bytes = ((size_t)(2 * c->cols_cap + 2 * c->strips_cap) * 4 + 4095) & ~(size_t)4095;
+    void* p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&p, c->bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) {
+        delete c;
+        return skr_set_error(SKR_ERR_HIP, "hipExtMallocWithFlags(%zu bytes, uncached) for the chain mailbox: %s", c->bytes, hipGetErrorString(e));
+    }
+    c->block = (char*)p;
+    e = hipMemsetAsync(c->block, 0, c->bytes, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(c->block);
+        delete c;
+        return skr_set_error(SKR_ERR_HIP, "clearing the chain mailbox: %s", hipGetErrorString(e));
+    }
+    c->d_err = ctx->d_flags + 20;  // one free word of the ctx flag block (0-7 kernels' flags, 8-15 tile queues, 32-63 all-reduce)
+    c->peer[0] = c->block;
+    *out = c;
+    return SKR_OK;
+}
+
+extern "C" int skr_chain_export(skr_chain* c, char handle[64]) {
+    SKR_REQUIRE(c && handle, "NULL argument");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "a HIP IPC memory handle is expected to be 64 bytes");
+    SKR_TRY(skr_activate(c->ctx));
+    hipIpcMemHandle_t h;
+    SKR_HIP(hipIpcGetMemHandle(&h, c->block));
+    memcpy(handle, &h, 64);
+    return SKR_OK;
+}
+
+static void chain_close_peers(skr_chain* c) {
+    for (int g = 0; g < kMaxChainRanks; g++) {
+        if (c->opened[g] && c->peer[g]) (void)hipIpcCloseMemHandle(c->peer[g]);
+        c->opened[g] = false;
+        c->peer[g] = nullptr;
+    }
+}
+
+// handles: [nranks][64] as exported by every rank (this rank's own entry is not opened)
+extern "C" int skr_chain_connect(skr_chain* c, int nranks, int rank, const char* handles) {
+    SKR_REQUIRE(c && handles, "NULL argument");
+    SKR_REQUIRE(nranks >= 1 && nranks <= kMaxChainRanks && rank >= 0 && rank < nranks, "bad rank %d of %d (at most %d)", rank, nranks,
+                kMaxChainRanks);
+    SKR_TRY(skr_activate(c->ctx));
+    chain_close_peers(c);
+    for (int g = 0; g < nranks; g++) {
+        if (g == rank) {
+            c->peer[g] = c->block;
+            continue;
+        }
+        hipIpcMemHandle_t h;
+        memcpy(&h, handles + (size_t)g * 64, 64);
+        void* p = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            chain_close_peers(c);
+            return skr_set_error(SKR_ERR_COMM, "hipIpcOpenMemHandle of rank %d's chain mailbox: %s", g, hipGetErrorString(e));
+        }
+        c->peer[g] = (char*)p;
+        c->opened[g] = true;
+    }
+    c->nranks = nranks;
+    c->rank = rank;
+    return SKR_OK;
+}
+
+// the ranks of a single-process emulation (tools/chain_bench.py, tests): all[g] lives in this process
+extern "C" int skr_chain_connect_local(skr_chain* c, int nranks, int rank, skr_chain* const* all) {
+    SKR_REQUIRE(c && all && nranks >= 1 && nranks <= kMaxChainRanks && rank >= 0 && rank < nranks, "bad argument");
+    chain_close_peers(c);
+    for (int g = 0; g < nranks; g++) {
+        SKR_REQUIRE(all[g] && all[g]->cols_cap == c->cols_cap, "rank %d's mailbox has another size", g);
+        c->peer[g] = all[g]->block;
+    }
+    c->nranks = nranks;
+    c->rank = rank;
+    return SKR_OK;
+}
+
+extern "C" int skr_chain_free(skr_chain* c) {
+    if (!c) return SKR_OK;
+    (void)hipSetDevice(c->ctx->device);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    chain_close_peers(c);
+    if (c->block) (void)hipFree(c->block);
+    delete c;
+    return SKR_OK;
+}
+
+// One pass of the chain on this rank (kmer_counts.py:168,174 over all ranks' rows in global row order): the column-sum
+// kernel as a link — it waits for rank - 1's sums inside the kernel and stores its own into rank + 1's mailbox — and, on
+// every rank but the last, the copy of the finished sums from the result box into `acc`.  On return (stream order) acc
+// holds the sums over ALL ranks' rows, the same bits on every rank.  Every rank must make the same sequence of calls.
+// Test-only (SEEKR_CHAIN_HOST_WAIT under SEEKR_TEST_HOOKS): the host polls the epoch words of the first `strips` strips
+// until all of them have reached `epoch`, so that the kernel launched next finds its mailbox full and never spins.
+static int chain_host_wait(skr_chain* c, const uint32_t* flags, unsigned strips, uint32_t epoch) {
+    skr_ctx* ctx = c->ctx;
+    std::vector<uint32_t> h(strips);
+    for (int tries = 0; tries < 600000; tries++) {  // ~ 30 s
+        SKR_HIP(hipMemcpyAsync(h.data(), flags, (size_t)strips * 4, hipMemcpyDeviceToHost, ctx->comm_stream));
+        SKR_HIP(hipStreamSynchronize(ctx->comm_stream));
+        bool all = true;
+        for (unsigned i = 0; i < strips && all; i++) all = (int32_t)(h[i] - epoch) >= 0;
+        if (all) return SKR_OK;
+        usleep(50);
+    }
+    return skr_set_error(SKR_ERR_COMM, "the chain mailbox was not filled within 30 s (epoch %u)", epoch);
+}
+
+static int chain_result(skr_chain* c, skr_mat* acc, int64_t cols) {
+    skr_ctx* ctx = c->ctx;
+    if (c->rank >= c->nranks - 1 || cols <= 0) return SKR_OK;
+    const unsigned strips = (unsigned)((cols + kColsPerWG - 1) / kColsPerWG);
+    if (ctx->knobs.chain_host_wait) SKR_TRY(chain_host_wait(c, c->result_flag(c->block), strips, c->epoch));
+    SkrProfScope prof(ctx, "chain_result_wait");
+    hipLaunchKernelGGL(chain_result_kernel, dim3((strips + 3) / 4), dim3(64), 0, ctx->stream, cols, (float*)acc->data,
+                       (const float*)c->result(c->block), (const uint32_t*)c->result_flag(c->block), c->epoch, c->d_err);
     SKR_HIP(hipGetLastError());
+    return SKR_OK;
+}
+
+// defer_result != 0 (single-process emulation of several ranks on ONE stream): the wait for the result box is left to a
+// later skr_chain_result, issued once the last rank's link is in the stream too
+extern "C" int skr_chain_result(skr_chain* c, skr_mat* acc) {
+    SKR_REQUIRE(c && acc, "NULL argument");
+    SKR_TRY(check_f32(c->ctx, acc, "acc"));
+    SKR_TRY(skr_activate(c->ctx));
+    return chain_result(c, acc, acc->rows * acc->cols);
+}
+
+extern "C" int skr_colsum_seq_chain(skr_chain* c, const skr_mat* x, const skr_mat* center, const skr_mat* center2, int square,
+                                    skr_mat* acc, skr_mat* colmin, int defer_result) {
+    SKR_REQUIRE(c && x && acc, "NULL argument");
+    skr_ctx* ctx = c->ctx;
+    SKR_REQUIRE(x->cols <= c->cols_cap, "the chain was created for at most %lld columns", (long long)c->cols_cap);
+    SKR_TRY(skr_activate(ctx));
+    const int P = c->nranks, g = c->rank, last = P - 1;
+    c->epoch++;
+    ChainLink link;
+    link.epoch = c->epoch;
+    link.err = c->d_err;
+    if (g > 0) {
+        link.carry_in = c->carry(c->block);
+        link.carry_flag = c->carry_flag(c->block);
+    }
+    if (g < last) {
+        link.next_data = c->carry(c->peer[g + 1]);
+        link.next_flag = c->carry_flag(c->peer[g + 1]);
+    } else {
+        for (int r = 0; r < last; r++) {
+            link.result_data[link.n_result] = c->result(c->peer[r]);
+            link.result_flag[link.n_result] = c->result_flag(c->peer[r]);
+            link.n_result++;
+        }
+    }
+    if (ctx->knobs.chain_host_wait && g > 0 && x->cols > 0)
+        SKR_TRY(chain_host_wait(c, link.carry_flag, (unsigned)((x->cols + kColsPerWG - 1) / kColsPerWG), c->epoch));
+    SKR_TRY(launch_colsum(ctx, x, center, center2, square, acc, colmin, link));
+    if (!defer_result) SKR_TRY(chain_result(c, acc, x->cols));
+    return SKR_OK;
+}
+
+// 1 when a wait of the chain gave up since the last call (a peer never delivered); clears the mark.  Synchronises.
+extern "C" int skr_chain_check(skr_chain* c, int* timed_out) {
+    SKR_REQUIRE(c && timed_out, "NULL argument");
+    SKR_TRY(skr_activate(c->ctx));
+    uint32_t v = 0;
+    SKR_HIP(hipStreamSynchronize(c->ctx->stream));
+    SKR_HIP(hipMemcpy(&v, c->d_err, 4, hipMemcpyDeviceToHost));
+    if (v) SKR_HIP(hipMemset(c->d_err, 0, 4));
+    *timed_out = v != 0;
     return SKR_OK;
 }
 

@@ -68,6 +68,11 @@ class HipEngine:
         else:
             _lib.colsum_seq(self.ctx, x, acc, center, center2, square)
 
+    def colsum_chain(self, chain, x, acc, center=None, center2=None, square=False, colmin=None):
+        """One pass of the column sums as a link of the peer-mailbox chain (skr_colsum_seq_chain): on return `acc` holds
+        the sums over all ranks' rows."""
+        chain.colsum(x, acc, center, center2, square, colmin)
+
     def colmin_buffer(self, x):
         """A [4, cols] buffer for the raw column minima the first column-sum pass can produce on the way (None when
         the column count does not allow it: then the Log2.post minimum is scanned from the matrix)."""
@@ -133,6 +138,67 @@ class RcclComm:
 
     def __init__(self, ctx, rank, size):
         self.ctx, self.rank, self.size = ctx, rank, size
+        self._chain = None        # None: not tried yet; False: unavailable (the vectors travel by send/recv); else _lib.Chain
+        self._chain_note = ""
+
+    def chain_for(self, engine, n_cols):
+        """The peer-mailbox chain for the column sums (skr_chain), set up collectively on first use: every rank exports
+        its mailbox, the 64-byte IPC handles are all-gathered, every rank opens the others', and one small chained pass is
+        checked against the send/recv chain.  Any failure on any rank — IPC refused, a store that never becomes visible
+        (the waits are bounded) — and ALL ranks stay with send/recv.  SEEKR_CHAIN=rccl|mailbox forces the choice; under
+        SEEKR_TEST_HOOKS=1 (several ranks sharing one GPU: a kernel that waits for another process's kernel can keep it
+        from ever being scheduled) the default is rccl."""
+        import os
+        if self._chain is not None and (self._chain is False or self._chain.cols_cap >= n_cols):
+            return self._chain or None
+        want = os.environ.get("SEEKR_CHAIN", "rccl" if os.environ.get("SEEKR_TEST_HOOKS") == "1" else "mailbox")
+        if self.size < 2 or self.size > 16 or want != "mailbox":
+            self._chain, self._chain_note = False, "not requested"
+            return None
+        ctx = self.ctx
+        if self._chain:
+            self._chain.free()
+        chain, why = None, ""
+        try:
+            chain = _lib.Chain(ctx, max(int(n_cols), 16384))
+            mine = np.frombuffer(chain.export(), dtype=np.float32).reshape(1, 16)
+        except Exception as e:  # noqa: BLE001
+            why, mine = "export: {}".format(e), np.zeros((1, 16), np.float32)
+        # the all-gather is collective: every rank takes part, whatever happened to it so far
+        shard, full = ctx.from_numpy(mine), ctx.zeros(self.size, 16)
+        self.wait(_lib.comm_allgather_rows(ctx, shard, full, list(range(self.size + 1))))
+        ctx.sync()
+        handles = [full.to_numpy(g, 1).tobytes() for g in range(self.size)]
+        if not why:
+            try:
+                chain.connect(self.rank, handles)
+            except Exception as e:  # noqa: BLE001
+                why = "connect: {}".format(e)
+        bad = self.allreduce([1.0 if why else 0.0], "max")[0]
+        if not bad:
+            # self-test: a small chained pass must equal the same pass over send/recv, bit for bit, on every rank
+            try:
+                rows = 5 + self.rank
+                x = ctx.from_numpy((np.arange(rows * 48, dtype=np.float32).reshape(rows, 48) % 7 + self.rank) * np.float32(0.37))
+                got = engine.zeros_vec(48)
+                engine.colsum_chain(chain, x, got)
+                if chain.timed_out():
+                    raise _lib.SeekrHipError("a peer's store never became visible")
+                self._chain = False  # the reference pass below must take the send/recv path
+                want_vec = _chain_colsum(engine, self, x, 48)
+                ctx.sync()
+                if not np.array_equal(got.vector().view(np.uint32), want_vec.vector().view(np.uint32)):
+                    raise _lib.SeekrHipError("the mailbox chain and the send/recv chain disagree")
+            except Exception as e:  # noqa: BLE001
+                why = "self-test: {}".format(e)
+            bad = self.allreduce([1.0 if why else 0.0], "max")[0]
+        if bad:
+            if chain is not None:
+                chain.free()
+            self._chain, self._chain_note = False, why or "another rank could not set it up"
+            return None
+        self._chain, self._chain_note = chain, "peer mailboxes over HIP IPC"
+        return chain
 
     def send_vec(self, v, dst, want_ticket=True):
         """Returns a ticket: the compute stream must wait on it before it overwrites `v`.  want_ticket=False: fire
@@ -199,6 +265,12 @@ def _chain_colsum(engine, comm, x, n_cols, center=None, center2=None, square=Fal
     """Sequential float32 column sums over ALL ranks' rows in global row order; the finished
     sums end on every rank.  `colmin` (first pass only): also filled with this rank's raw column minima."""
     acc = engine.zeros_vec(n_cols)
+    chain = comm.chain_for(engine, n_cols) if comm.size > 1 and hasattr(comm, "chain_for") and hasattr(engine, "colsum_chain") else None
+    if chain is not None:
+        # no transfer between two kernels: the kernel itself waits for the previous rank's sums and stores its own into
+        # the next rank's mailbox; the finished sums come back through the result box (skr_colsum_seq_chain)
+        engine.colsum_chain(chain, x, acc, center, center2, square, colmin)
+        return acc
     if comm.size > 1 and comm.rank > 0:
         comm.recv_vec(acc, comm.rank - 1)
     if colmin is not None:

@@ -55,7 +55,8 @@ def main():
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), mean=mean.vector(), std=std.vector(), x=x.to_numpy(),
              r_row=r_row.to_numpy(), r_col=r_col.to_numpy(), r=r.to_numpy(), has_nan=np.array(has_nan),
              blocks=np.array([(0 if b[0] == "row" else 1,) + tuple(b[1:]) for b in blocks], dtype=np.int64),
-             e_i=e[0], e_j=e[1], e_v=e[2], lo=np.array(lo), hi=np.array(hi))
+             e_i=e[0], e_j=e[1], e_v=e[2], lo=np.array(lo), hi=np.array(hi),
+             chain_note=np.array(getattr(comm, "_chain_note", "")))
     comm.barrier()
     ctx.sync()
 

@@ -146,6 +146,38 @@ def test_bench_under_torchrun_with_two_ranks(mock_lib):
     assert abs(out["roofline"]["pairs_multiplied_per_step"] / out["roofline"]["pairs_delivered_per_step"] - 0.5) < 0.1
 
 
+def test_column_sum_chain_through_peer_mailboxes(mock_lib, single, tmp_path):
+    """SEEKR_CHAIN=mailbox with two rank processes on one GPU: each rank's mailbox (uncached device memory) is exported as a
+    HIP IPC handle and opened by the other process for real; the column-sum kernel of rank 1 waits inside the kernel for
+    rank 0's running sums and the finished sums come back through the result box — no send/recv between two kernels.
+    Statistics and normalised counts must equal the single-GPU run bit for bit, as over send/recv.
+    (SEEKR_CHAIN_HOST_WAIT=1: on a shared GPU the wait for the mailbox is done by the host before the launch — a waiting
+    kernel fills every CU and the kernel it waits for would never start; between GPUs the wait is inside the kernel.)"""
+    check_ranks(2, 1, mock_lib, single, tmp_path, extra_env={"SEEKR_CHAIN": "mailbox", "SEEKR_CHAIN_HOST_WAIT": "1"})
+    notes = [str(np.load(str(tmp_path / ("rank%d.npz" % rank)))["chain_note"]) for rank in range(2)]
+    assert all("peer mailboxes" in n for n in notes), notes
+
+
+@pytest.mark.parametrize("size", [3, 4])
+def test_column_sum_chain_through_peer_mailboxes_more_ranks(size, mock_lib, single, tmp_path):
+    check_ranks(size, 1, mock_lib, single, tmp_path, extra_env={"SEEKR_CHAIN": "mailbox", "SEEKR_CHAIN_HOST_WAIT": "1"})
+    notes = [str(np.load(str(tmp_path / ("rank%d.npz" % rank)))["chain_note"]) for rank in range(size)]
+    assert all("peer mailboxes" in n for n in notes), notes
+
+
+def test_column_sum_chain_with_empty_shards(mock_lib, tmp_path):
+    """Fewer rows than ranks: a rank without rows still passes the running sums on (chain_forward_kernel)."""
+    check_ranks(4, 1, mock_lib, single_gpu_reference(3, 400, 2), tmp_path, extra_env={"SEEKR_CHAIN": "mailbox", "SEEKR_CHAIN_HOST_WAIT": "1"})
+
+
+def test_column_sum_chain_falls_back_to_send_recv(mock_lib, single, tmp_path):
+    """Without the opt-in the ranks of a shared GPU keep the send/recv chain (a kernel waiting for another process's
+    kernel on the SAME GPU may keep it from being scheduled); the note says so."""
+    check_ranks(3, 1, mock_lib, single, tmp_path)
+    notes = [str(np.load(str(tmp_path / ("rank%d.npz" % rank)))["chain_note"]) for rank in range(3)]
+    assert all(n == "not requested" for n in notes), notes
+
+
 def _launcher_env(mock_lib, **extra):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
     env.update(SEEKR_TEST_HOOKS="1", SEEKR_RCCL_LIB=mock_lib, SEEKR_FORCE_DEVICE="0", MOCK_RCCL_ASYNC="1", **extra)
