@@ -473,10 +473,13 @@ def run_rank(args):
             "exposed_wait_ms": [round(v, 3) for v in gather(ms_step("comm_wait"))],
             "chain_wait_ms": [round(v, 3) for v in gather(ms_step("comm_wait_vec"))],
             "gemm_ms": [round(v, 3) for v in gather(sum(ms_step(n) for n in gemm_names))],
+            "colsum_ms": [round(v, 3) for v in gather(sum(ms_step(n) for n in kern if n.startswith("colsum_seq")))],
+            "column_sum_chain": getattr(comm, "_chain_note", "") or "send/recv",
             "note": "per step and rank: comm_ms = operand-shard transfers on the communication stream (data ready -> "
                     "arrived, the peer's lateness included); exposed_wait_ms = time the compute stream stood still waiting for a "
                     "shard (what no kernel hid); chain_wait_ms = the same for the rank-to-rank float32 column-sum chain "
-                    "(serial by construction: rank g waits for ranks < g)"}
+                    "(serial by construction: rank g waits for ranks < g); with column_sum_chain = peer mailboxes that wait happens "
+                    "inside the column-sum kernels (colsum_ms: rank g's kernels are resident and waiting while ranks < g walk)"}
     gemm_name = {"fp32": "pearson_gemm_f32", "bf16x3": "pearson_gemm_bf16x3", "bf16x4": "pearson_gemm_bf16x4",
                  "f16x3": "pearson_gemm_f16x3"}[args.precision]
     gemm = kern.get(gemm_name, {"ms_total": 0.0, "launches": 0})
