@@ -331,6 +331,11 @@ def sharded_stats(engine, comm, x, n_total, log2="Log2.post", mean=True, std=Tru
             gmin = comm.allreduce([float(local_min) if not local_nan else 0.0], "min")[0]
             local_min = np.float32(np.nan) if flag else np.float32(gmin)
         shift = float(np.abs(local_min))  # NaN stays NaN (np.abs(np.min(...)), :208)
+        # the minimum came back to the host, i.e. the stream is drained: the moment to ask whether a link of the mailbox
+        # chain gave up waiting for a peer (its waits are bounded; the sums would be garbage) — an error, not a hang
+        chain = getattr(comm, "_chain", None)
+        if chain and chain.timed_out():
+            raise _lib.SeekrHipError("rank {}: the column-sum chain gave up waiting for a peer's mailbox store".format(comm.rank))
     return center, scale, post, shift
 
 

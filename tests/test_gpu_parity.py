@@ -1145,3 +1145,64 @@ def test_four_wave_geometry_gives_the_same_bits():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "w4_check.py")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "w4 check ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("cols,shards", [(4096, [700, 0, 513, 1200]), (16384, [300, 301]), (1000, [64, 1, 0, 0, 90, 7, 300, 5]), (48, [3, 9])])
+def test_peer_mailbox_chain_links_in_one_process(cols, shards, L, ctx):
+    """skr_colsum_seq_chain (the column-sum chain across GPUs through peer mailboxes) with the ranks' mailboxes connected
+    inside ONE process (skr_chain_connect_local) and the links issued rank after rank on one stream: plain, centred and
+    squared-deviation passes and the first pass's column minima must equal ONE kernel over all rows bit for bit — ragged
+    shards, empty shards (chain_forward_kernel), a column count that is not a multiple of 16, k = 7 (1 024 strips)."""
+    rng = np.random.default_rng(cols)
+    n = sum(shards)
+    x = (rng.binomial(1995, 1.0 / 4096, size=(n, cols)) * np.float32(0.5)).astype(np.float32)
+    whole = ctx.from_numpy(x)
+    bounds = np.concatenate([[0], np.cumsum(shards)])
+    parts = [ctx.from_numpy(x[bounds[g]:bounds[g + 1]]) if shards[g] else ctx.empty(0, cols) for g in range(len(shards))]
+    P = len(shards)
+    chains = [L.Chain(ctx, cols) for _ in range(P)]
+    for g, c in enumerate(chains):
+        c.connect_local(g, chains)
+
+    def chained(center=None, center2=None, square=False, want_min=False):
+        accs = [ctx.zeros(1, cols) for _ in range(P)]
+        mins = [ctx.zeros(4, cols) if (want_min and shards[g]) else None for g in range(P)]
+        for g in range(P):
+            chains[g].colsum(parts[g], accs[g], center, center2, square, colmin=mins[g], defer_result=True)
+        for g in range(P - 1):
+            chains[g].result(accs[g])
+        ctx.sync()
+        assert not any(c.timed_out() for c in chains)
+        vecs = [a.vector() for a in accs]
+        for v in vecs[1:]:
+            assert_bits(v, vecs[0], "every rank ends with the same sums")
+        return vecs[0], mins
+
+    # pass 1 (+ minima), pass 2 (centred), pass 3 (squared deviations)
+    acc = ctx.zeros(1, cols)
+    can_min = cols % 16 == 0
+    if can_min:
+        cm = ctx.zeros(4, cols)
+        L.colsum_seq_colmin(ctx, whole, acc, cm)
+    else:
+        L.colsum_seq(ctx, whole, acc)
+    got, mins = chained(want_min=can_min)
+    assert_bits(got, acc.vector(), "chained plain sums")
+    if can_min:
+        want_min = np.fmin.reduce(cm.to_numpy(), axis=0)
+        got_min = np.fmin.reduce(np.concatenate([m.to_numpy() for m in mins if m is not None]), axis=0)
+        assert_bits(got_min, want_min, "column minima gathered over the links")
+    mean = ctx.from_numpy(acc.vector().reshape(1, -1))
+    L.vec_finish(ctx, mean, n)
+    acc2 = ctx.zeros(1, cols)
+    L.colsum_seq(ctx, whole, acc2, mean)
+    got2, _ = chained(center=mean)
+    assert_bits(got2, acc2.vector(), "chained centred sums")
+    mp = ctx.from_numpy(acc2.vector().reshape(1, -1))
+    L.vec_finish(ctx, mp, n)
+    acc3 = ctx.zeros(1, cols)
+    L.colsum_seq(ctx, whole, acc3, mean, mp, True)
+    got3, _ = chained(center=mean, center2=mp, square=True)
+    assert_bits(got3, acc3.vector(), "chained squared deviations")
+    for c in chains:
+        c.free()
