@@ -327,9 +327,10 @@ def sharded_stats(engine, comm, x, n_total, log2="Log2.post", mean=True, std=Tru
     if post:
         local_min, local_nan = engine.min_nan(colmin if colmin is not None else x, center, scale)
         if comm.size > 1:
-            flag = comm.allreduce([1.0 if local_nan else 0.0], "max")[0]
-            gmin = comm.allreduce([float(local_min) if not local_nan else 0.0], "min")[0]
-            local_min = np.float32(np.nan) if flag else np.float32(gmin)
+            # ONE host all-reduce (each costs a stream drain and a round trip): min over [the local minimum or +inf where
+            # the shard holds a NaN, minus the NaN flag] — min(-flag) = -max(flag)
+            gmin, neg_flag = comm.allreduce([float(local_min) if not local_nan else float("inf"), -1.0 if local_nan else 0.0], "min")
+            local_min = np.float32(np.nan) if neg_flag < 0 else np.float32(gmin)
         shift = float(np.abs(local_min))  # NaN stays NaN (np.abs(np.min(...)), :208)
         # the minimum came back to the host, i.e. the stream is drained: the moment to ask whether a link of the mailbox
         # chain gave up waiting for a peer (its waits are bounded; the sums would be garbage) — an error, not a hang
@@ -345,6 +346,16 @@ def _any_rank(comm, flag):
     return bool(flag)
 
 
+def _verdicts(comm, fell_back, coherent, has_nan):
+    """The three per-step verdicts of the normalisation as ONE host all-reduce (a stream drain and a round trip each,
+    were they separate): did any rank's operand fall back to the float32 layout, is any rank's shard 'mostly one repeated
+    value', did any rank see a NaN.  sharded_normalize and sharded_normalize_prepare both end with it, so that ranks may
+    mix the two entry points (tests/dist_worker.py does)."""
+    if comm.size > 1:
+        return tuple(v > 0 for v in comm.allreduce([1.0 if fell_back else 0.0, 1.0 if coherent else 0.0, 1.0 if has_nan else 0.0], "max"))
+    return bool(fell_back), bool(coherent), bool(has_nan)
+
+
 def sharded_normalize(engine, comm, x, n_total, log2="Log2.post", mean=True, std=True):
     """kmer_counts.py:203-209 on a row shard `x` of a matrix with `n_total` rows, in place.
     (Log2.pre is fused into counting and therefore not handled here.)
@@ -353,7 +364,7 @@ def sharded_normalize(engine, comm, x, n_total, log2="Log2.post", mean=True, std
     has_nan = False
     if center is not None or scale is not None or post:
         has_nan = engine.apply(x, center, scale, post, shift)
-    return center, scale, _any_rank(comm, has_nan)
+    return center, scale, _verdicts(comm, False, False, has_nan)[2]
 
 
 def sharded_normalize_prepare(engine, comm, x, n_total, log2="Log2.post", mean=True, std=True, keep_counts=True,
@@ -366,20 +377,22 @@ def sharded_normalize_prepare(engine, comm, x, n_total, log2="Log2.post", mean=T
     # A rank whose rows need more dynamic range than the split contraction has (skr_operand_kind) comes
     # back with a float32-layout operand; shards are multiplied against each other, so then every rank
     # switches (rare: raw counts of homopolymer-like sequences).  Needs the normalised counts in x.
-    if comm.size > 1 and hasattr(engine, "layout"):
-        fell_back = engine.layout(operand) == 0 and engine.precision != _lib.PREC_FP32
-        if _any_rank(comm, fell_back) and engine.layout(operand) != 0:
+    # "rows are mostly one repeated value" (skr_operand_coherent) decides how often the contraction restarts its
+    # accumulators: a block (g, h) must be treated the same whichever of its two ranks multiplies it, so that flag is
+    # made global too (receive buffers adopt it from the local shard in sharded_pearson_*).  The three verdicts travel
+    # in ONE host all-reduce (round 3: they were three, each a stream drain and a round trip per step).
+    if comm.size > 1:
+        fell_back = hasattr(engine, "layout") and engine.layout(operand) == 0 and engine.precision != _lib.PREC_FP32
+        coherent = bool(getattr(operand, "coherent", False))
+        any_fell_back, any_coherent, any_nan = _verdicts(comm, fell_back, coherent, has_nan)
+        if any_fell_back and hasattr(engine, "layout") and engine.layout(operand) != 0:
             if not keep_counts:
                 raise NotImplementedError("a rank fell back to the float32 contraction; re-run with keep_counts=True")
             operand = engine.prepare_f32(x)
-    # "rows are mostly one repeated value" (skr_operand_coherent) decides how often the contraction restarts its
-    # accumulators: a block (g, h) must be treated the same whichever of its two ranks multiplies it, so the flag
-    # is made global (receive buffers adopt it from the local shard in sharded_pearson_*)
-    if comm.size > 1 and hasattr(operand, "coherent"):
-        flag = _any_rank(comm, operand.coherent)
-        if flag != operand.coherent:
-            operand.coherent = flag
-    return center, scale, _any_rank(comm, has_nan), operand
+        if hasattr(operand, "coherent") and any_coherent != bool(operand.coherent) and not any_fell_back:
+            operand.coherent = any_coherent
+        has_nan = any_nan
+    return center, scale, bool(has_nan), operand
 
 
 def sharded_pearson_rowblock(engine, comm, z, bounds, r, recv_bufs):
