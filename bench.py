@@ -25,8 +25,9 @@ fresh child processes of this same script (one per GPU, no exec of a GPU-initial
 rank 0's JSON line, and on any rank's failure or after --launch-timeout seconds kills exactly the
 process groups it started and exits non-zero with every rank's stderr tail.  A failed first attempt
 in the symmetric layout (including a failed self-test of the half-ring schedule, exit code 17) is
-retried ONCE, in a new set of children, with the plain row-block layout (no split first shift, no
-grouped shifts); the JSON line then carries "layout_fallback".
+retried ONCE, in a new set of children, with the most conservative configuration — the plain row-block
+layout (no split first shift, no grouped shifts) and the column-sum chain over send/recv; the JSON line
+then carries "layout_fallback".
 """
 import argparse
 import hashlib
@@ -149,7 +150,8 @@ def _run_rank_set(argv, size, timeout_s, extra_env, log_dir, attempt, program=No
         for p in procs:
             _kill_group(p)
     if failed is None:
-        lines = [ln for ln in open(logs[0][0], "r", errors="replace").read().splitlines() if ln.startswith("{")]
+        with open(logs[0][0], "r", errors="replace") as fh:
+            lines = [ln for ln in fh.read().splitlines() if ln.startswith("{")]
         if len(lines) == 1:
             return True, lines[0], ""
         reason = "rank 0 printed {} JSON lines".format(len(lines))
@@ -182,8 +184,10 @@ def launch(args, argv):
                     del argv2[i:i + 2]
                     break
             argv2 = [a for a in argv2 if not a.startswith("--layout=")] + ["--layout", "rowblock"]
+            # the retry is the most conservative configuration: row blocks, and the column-sum chain over send/recv
             ok, payload, report = _run_rank_set(argv2, size, args.launch_timeout,
-                                                {"SEEKR_BENCH_FALLBACK": "symmetric layout abandoned: " + why}, log_dir, 2)
+                                                {"SEEKR_BENCH_FALLBACK": "symmetric layout abandoned: " + why, "SEEKR_CHAIN": "rccl"},
+                                                log_dir, 2)
         if ok:
             print(payload, flush=True)
             return 0
