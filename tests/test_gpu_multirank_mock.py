@@ -198,6 +198,7 @@ def test_bench_starts_its_own_rank_processes(mock_lib):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and "symmetric" in out["config"]["layout"]
     assert "layout_fallback" not in out and out["selftest"].startswith("half-ring schedule == row-block")
+    assert out["verified"] is True and out["verified_detail"]["worst_error_over_bar"] <= 1.0
     pr = out["per_rank"]
     for key in ("comm_ms", "exposed_wait_ms", "chain_wait_ms", "gemm_ms"):
         assert len(pr[key]) == 2 and all(v >= 0 for v in pr[key]), (key, pr[key])
