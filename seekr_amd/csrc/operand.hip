@@ -108,6 +108,102 @@ struct FillArgs {
     uint32_t* flags;
 };
 
+
+// ---- numpy's pairwise summation, addition for addition (numpy/_core/src/umath/loops_utils.h.src: @TYPE@_pairwise_sum),
+// which is what np.mean / np.std(axis=1) of pearson.py:35-38 run along a row: fewer than 8 values are added one after the
+// other; up to 128 go into eight accumulators r[j] += a[i + j] (i in steps of 8) that are folded as
+// ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)), the n % 8 leftovers added one by one; more than 128 are split at n/2 rounded
+// down to a multiple of 8, recursively.  On rows whose standardisation is ill-conditioned (4 or 16 near-equal values:
+// k = 1, 2) the float32 result depends on every one of these roundings, so the rows the generic fill kernel serves
+// (every width but the three register-resident ones) are summed in exactly this order: z is then numpy's z bit for bit
+// and what is left between the device and the reference is the inner product's own rounding.  (Checked against
+// np.add.reduce for every n up to 300 and a dozen larger ones: tests/test_oracle_golden.py.)
+constexpr int kNpMaxLeaves = 128;  // n <= 8 192 (a leaf holds 65 .. 128 values once n > 128)
+constexpr int kNpExactMaxCols = 8192;
+struct NpPlan {
+    int n_leaves, prog_len;
+    unsigned short leaf_start[kNpMaxLeaves], leaf_n[kNpMaxLeaves];
+    unsigned char prog[2 * kNpMaxLeaves];  // post-order: 0 = push the next leaf's sum, 1 = add the two on top
+    float leaf_sum[kNpMaxLeaves];
+    float stack[16];
+};
+
+// built once per wave by lane 0 (the same for every row of the launch)
+__device__ inline void np_plan_build(NpPlan* p, int n) {
+    int sp = 0, st_s[24], st_n[24], st_k[24];  // explicit recursion stack: (start, n, 0 = expand | 1 = emit an add)
+    p->n_leaves = 0;
+    p->prog_len = 0;
+    st_s[sp] = 0, st_n[sp] = n, st_k[sp] = 0, sp++;
+    while (sp > 0) {
+        sp--;
+        const int s0 = st_s[sp], n0 = st_n[sp], k0 = st_k[sp];
+        if (k0 == 1) {
+            p->prog[p->prog_len++] = 1;
+        } else if (n0 <= 128) {
+            p->leaf_start[p->n_leaves] = (unsigned short)s0;
+            p->leaf_n[p->n_leaves] = (unsigned short)n0;
+            p->n_leaves++;
+            p->prog[p->prog_len++] = 0;
+        } else {
+            int n2 = n0 / 2;
+            n2 -= n2 % 8;
+            st_s[sp] = 0, st_n[sp] = 0, st_k[sp] = 1, sp++;                 // after both halves: add
+            st_s[sp] = s0 + n2, st_n[sp] = n0 - n2, st_k[sp] = 0, sp++;     // right half (popped second)
+            st_s[sp] = s0, st_n[sp] = n2, st_k[sp] = 0, sp++;               // left half (popped first)
+        }
+    }
+}
+
+// sum of f(0) .. f(n-1) in numpy's order; all 64 lanes call it, all return the sum.  Eight lanes share a leaf (one
+// accumulator each), eight leaves per round.
+template <class F>
+__device__ __forceinline__ float np_pairwise_sum(NpPlan* p, F f, int lane) {
+    const int slot = lane >> 3, j = lane & 7;
+    for (int base = 0; base < p->n_leaves; base += 8) {
+        const int leaf = base + slot;
+        const bool live = leaf < p->n_leaves;
+        const int s0 = live ? p->leaf_start[leaf] : 0, n0 = live ? p->leaf_n[leaf] : 0;
+        float r = 0.f;
+        if (n0 >= 8) {
+            r = f(s0 + j);
+            for (int i = 8; i < n0 - (n0 % 8); i += 8) r = __fadd_rn(r, f(s0 + i + j));
+        } else if (j == 0) {
+            for (int i = 0; i < n0; i++) r = __fadd_rn(r, f(s0 + i));  // res = 0.; res += a[i]
+        }
+        // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)): the lanes of a leaf are neighbours
+        float x = __fadd_rn(r, __shfl_down(r, 1, 64));
+        float y = __fadd_rn(x, __shfl_down(x, 2, 64));
+        float z = __fadd_rn(y, __shfl_down(y, 4, 64));
+        if (live && j == 0) {
+            if (n0 >= 8) {
+                for (int i = n0 - (n0 % 8); i < n0; i++) z = __fadd_rn(z, f(s0 + i));
+                p->leaf_sum[leaf] = z;
+            } else {
+                p->leaf_sum[leaf] = r;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float res = 0.f;
+    if (lane == 0) {  // the recursion's additions, in its order
+        int sp = 0, next = 0;
+        for (int i = 0; i < p->prog_len; i++) {
+            if (p->prog[i] == 0) {
+                p->stack[sp++] = p->leaf_sum[next++];
+            } else {
+                sp--;
+                p->stack[sp - 1] = __fadd_rn(p->stack[sp - 1], p->stack[sp]);
+            }
+        }
+        res = p->stack[0];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return __shfl(res, 0, 64);
+}
+
 // One WAVE per row (grid-stride over rows): the row is loaded once with 16-byte coalesced loads,
 // parked in a wave-private LDS slice between the passes, and all reductions are wave shuffles, so
 // there is no workgroup barrier anywhere.  T = float (zero-padded float32 operand), __bf16 or
@@ -132,6 +228,15 @@ __global__ __launch_bounds__(256) void operand_fill_kernel(FillArgs a) {
     const int64_t K = a.cols, Kp = a.kt * 32;
     float* row = lds + (size_t)wave * ((K + 3) & ~(int64_t)3);
     const bool vec = (K & 3) == 0;
+    // numpy-ordered row sums (above): the plan lives behind the row slices, one per wave
+    const bool np_exact = a.row_standardize && K <= kNpExactMaxCols;
+    NpPlan* plan = reinterpret_cast<NpPlan*>(lds + (size_t)waves * ((K + 3) & ~(int64_t)3)) + wave;
+    if (np_exact) {
+        if (lane == 0) np_plan_build(plan, (int)K);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     bool any_nan = false, overflow = false, outlier = false, coherent = false;
     for (int64_t r = (int64_t)blockIdx.x * waves + wave; r < a.rows; r += (int64_t)gridDim.x * waves) {
         const float* xr = a.x + (size_t)r * K;
@@ -158,7 +263,21 @@ __global__ __launch_bounds__(256) void operand_fill_kernel(FillArgs a) {
         }
         // ---- pass 2: row statistics in the order pearson.py:35-38 computes them
         float mean = 0.f, sd = 1.f;
-        if (a.row_standardize) {
+        if (np_exact) {
+            // np.mean(x, 1); x - mean; np.std of that: mean of the centred row, squared deviations from it, sqrt — every sum
+            // in numpy's pairwise order, every step a separately rounded float32 operation (numpy/_core/_methods.py: _mean, _var)
+            const float kf = (float)K;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the row parked above is read across lanes
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            mean = __fdiv_rn(np_pairwise_sum(plan, [&](int c) { return row[c]; }, lane), kf);
+            const float m2 = __fdiv_rn(np_pairwise_sum(plan, [&](int c) { return __fsub_rn(row[c], mean); }, lane), kf);
+            const float var = __fdiv_rn(np_pairwise_sum(plan, [&](int c) {
+                const float d = __fsub_rn(__fsub_rn(row[c], mean), m2);
+                return __fmul_rn(d, d);
+            }, lane), kf);
+            sd = (float)sqrt((double)var);  // correctly rounded, as np.sqrt
+        } else if (a.row_standardize) {
             const float kf = (float)K;
             mean = wave_sum(s) / kf;
             s = 0.f;
@@ -195,7 +314,7 @@ __global__ __launch_bounds__(256) void operand_fill_kernel(FillArgs a) {
             for (int j = 0; j < 8; j++) {
                 const int64_t k = k0 + j;
                 float v = k < K ? row[k] : 0.f;
-                if (a.row_standardize && k < K) v = (v - mean) / sd;
+                if (a.row_standardize && k < K) v = __fdiv_rn(__fsub_rn(v, mean), sd);
                 z[j] = v;
                 sq = __fmaf_rn(v, v, sq);
             }
@@ -339,7 +458,7 @@ __global__ __launch_bounds__(256) void operand_fill_block_kernel(FillArgs a) {
             for (int j = 0; j < 8; j++) {
                 const int64_t k = k0 + j;
                 float v = k < K ? val(k) : 0.f;
-                if (a.row_standardize && k < K) v = (v - mean) / sd;
+                if (a.row_standardize && k < K) v = __fdiv_rn(__fsub_rn(v, mean), sd);
                 z[j] = v;
                 sq = __fmaf_rn(v, v, sq);
             }
@@ -609,7 +728,7 @@ int launch_fill(skr_ctx* ctx, const skr_operand* op, const FillArgs& a_in) {
     const size_t row_floats = (size_t)((a.cols + 3) & ~(int64_t)3);
     const bool wide = row_floats * 4 > 150 * 1024;  // k >= 8: the row does not fit the LDS
     const int waves = (int)std::max<size_t>(1, std::min<size_t>(4, (64 * 1024) / (row_floats * 4)));
-    const size_t lds = row_floats * 4 * waves;
+    const size_t lds = row_floats * 4 * waves + sizeof(NpPlan) * waves;  // row slices + the numpy-order summation plans
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / lds));
     const int64_t want = (a.rows + waves - 1) / waves;
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cu * per_cu));

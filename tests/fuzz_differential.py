@@ -149,7 +149,7 @@ def fuzz(seed, budget_s=60.0, max_cases=10 ** 9, replay=None):
         with np.errstate(all="ignore"):
             truth = orc.pearson_f64_truth(ref, ref)
         ok = ~np.isnan(want) & ~np.isnan(truth)
-        TALLY.add(r, want, truth, ok)
+        TALLY.add(r, want, truth, ok, tag)
         e_ref = np.where(ok, np.abs(want - truth), 0.0)
         e_ours = np.where(ok, np.abs(r - truth), 0.0)
         slack = 4.0 * np.maximum(e_ref.max(axis=1, keepdims=True), e_ref.max(axis=0, keepdims=True))

@@ -79,7 +79,7 @@ def fuzz(seed, budget_s=60.0, max_cases=10 ** 9):
             e_ours = np.where(ok, np.abs(g - truth), 0.0)
             scale = np.maximum(np.abs(np.where(ok, truth, 0.0)), 1e-300)
             if got.dtype == np.float32 and rs:
-                TALLY.add(g, w, truth, ok)
+                TALLY.add(g, w, truth, ok, tag)
             if got.dtype == np.float64:
                 limit = 1e-12 * np.maximum(scale, 1.0) + 8 * e_ref.max()
             else:

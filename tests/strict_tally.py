@@ -11,8 +11,9 @@ class StrictTally:
         self.cases = self.strict_ok = 0
         self.worst = 0.0
         self.not_strict = []  # (strict ratio, reference's own |ref - f64| / bar on that case, device's)
+        self.tags = []        # (strict ratio, the fuzzer's description of the case) for the cases above
 
-    def add(self, got, ref, truth, ok):
+    def add(self, got, ref, truth, ok, tag=None):
         """float32 cases only; `ok`: cells where reference and truth are finite numbers worth judging."""
         if not ok.any():
             return
@@ -27,6 +28,7 @@ class StrictTally:
             e_ref = float(np.max(np.where(ok, np.abs(ref - truth), 0.0) / bar))
             e_dev = float(np.max(np.where(ok, np.abs(got - truth), 0.0) / bar))
             self.not_strict.append((round(strict, 3), round(e_ref, 3), round(e_dev, 3)))
+            self.tags.append((round(strict, 3), tag))
 
     def summary(self):
         ns = sorted(self.not_strict, reverse=True)
@@ -35,4 +37,5 @@ class StrictTally:
                 "worst_strict_ratio": round(self.worst, 3),
                 "of_those_device_closer_to_float64_than_reference": closer,
                 "of_those_min_reference_error_over_bar": min((e for _, e, _ in ns), default=None),
-                "top5 (strict, ref vs f64, device vs f64)": ns[:5]}
+                "top5 (strict, ref vs f64, device vs f64)": ns[:5],
+                "which": [t for _, t in sorted(self.tags, key=lambda x: -x[0])[:12]]}

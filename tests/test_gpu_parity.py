@@ -1206,3 +1206,31 @@ def test_peer_mailbox_chain_links_in_one_process(cols, shards, L, ctx):
     assert_bits(got3, acc3.vector(), "chained squared deviations")
     for c in chains:
         c.free()
+
+
+def test_rows_are_standardised_in_numpys_summation_order(L, ctx):
+    """pearson.py:35-38 on rows whose standardisation is ill-conditioned — 4 or 16 near-equal values (k = 1, 2), short
+    rows of large nearly constant counts — depends on every rounding of np.mean / np.std, i.e. on numpy's pairwise
+    summation order.  The generic fill kernel adds in exactly that order (operand.hip: np_pairwise_sum), so the device
+    meets the STRICT bar |got - oracle.pearson| <= 2e-6 + 1e-5 |ref| there too, where a tree sum of the same accuracy
+    lands bars away (the reference itself is up to 8 bars from float64 on such rows: tests/strict_tally.py)."""
+    from seekr_amd.pearson import pearson
+    rng = np.random.default_rng(11)
+    worst = 0.0
+    for K in (4, 5, 16, 31, 64, 100, 129, 255, 257, 729, 2000, 4100):
+        for scale in (1e-3, 3e-2):
+            base = rng.uniform(50, 900, size=(1, K)).astype(np.float32)
+            x = (base * (1 + scale * rng.standard_normal((40, K)))).astype(np.float32)
+            x[7] = x[3]                                # duplicates: r = 1 up to the row sums' rounding
+            x[9] = x[3] * np.float32(2.0)
+            with np.errstate(all="ignore"):
+                want = orc.pearson(x, x)
+                truth = orc.pearson_f64_truth(x, x)
+            got = pearson(x, x)
+            ok = np.isfinite(want)
+            assert np.array_equal(np.isfinite(got), ok), K
+            ratio = float(np.max(np.abs(got[ok].astype(np.float64) - want[ok]) / (ATOL_R + RTOL * np.abs(want[ok]))))
+            ref_off = float(np.max(np.abs(want[ok].astype(np.float64) - truth[ok]) / (ATOL_R + RTOL * np.abs(truth[ok]))))
+            worst = max(worst, ratio)
+            assert ratio <= 1.0, (K, scale, ratio, ref_off)
+    assert worst <= 1.0

@@ -305,3 +305,56 @@ def test_g8_file_whose_first_line_is_not_a_header(golden_dir, tmp_path):
     assert Reader(path).get_seqs() == g["seqs"] == g["counter_seqs"]
     raw = orc.raw_counts(g["seqs"], 2)
     assert np.array_equal(raw.view(np.uint32), np.array(g["raw_k2_bits"], dtype=np.uint32))
+
+
+def test_numpy_adds_a_row_in_the_pairwise_order_the_fill_kernel_reproduces():
+    """The order seekr_amd/csrc/operand.hip: np_pairwise_sum reproduces on the device, restated in Python and pinned
+    against np.add.reduce itself (float32, every length up to 300 and the widths the product meets): fewer than 8 values
+    one after the other; up to 128 in eight strided accumulators folded ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)) plus
+    leftovers; longer rows split at n/2 rounded down to a multiple of 8.  And with it np.mean / np.std(axis=1) of
+    pearson.py:35-38, step by step."""
+    f32 = np.float32
+
+    def pw(a):
+        n = len(a)
+        if n < 8:
+            res = f32(0.0)
+            for v in a:
+                res = f32(res + v)
+            return res
+        if n <= 128:
+            r = [f32(a[j]) for j in range(8)]
+            i = 8
+            while i < n - (n % 8):
+                for j in range(8):
+                    r[j] = f32(r[j] + a[i + j])
+                i += 8
+            res = f32(f32(f32(r[0] + r[1]) + f32(r[2] + r[3])) + f32(f32(r[4] + r[5]) + f32(r[6] + r[7])))
+            while i < n:
+                res = f32(res + a[i])
+                i += 1
+            return res
+        n2 = n // 2
+        n2 -= n2 % 8
+        return f32(pw(a[:n2]) + pw(a[n2:]))
+
+    rng = np.random.default_rng(0)
+    for n in list(range(1, 300)) + [625, 729, 1000, 1023, 1024, 1025, 2048, 3125, 4096, 4100]:
+        a = (rng.standard_normal(n) * rng.choice([1, 1e3, 1e-3]) + rng.choice([0, 5, 100])).astype(f32)
+        m = np.stack([a, a[::-1]])
+        want = np.add.reduce(m, axis=1)
+        assert pw(m[0]).view(np.uint32) == want[0].view(np.uint32) and pw(m[1]).view(np.uint32) == want[1].view(np.uint32), n
+    for K in (1, 2, 3, 4, 5, 16, 31, 64, 100, 255, 257, 625, 1024):
+        x = (rng.binomial(30, 0.1, size=(5, K)) * f32(0.5) + rng.choice([0, 3])).astype(f32)
+        with np.errstate(all="ignore"):
+            c = (x.T - np.mean(x, axis=1)).T
+            z = (c.T / np.std(c, axis=1)).T
+            mine = np.empty_like(x)
+            for i, row in enumerate(x):
+                mean = f32(pw(row) / f32(K))
+                cc = (row - mean).astype(f32)
+                m2 = f32(pw(cc) / f32(K))
+                d = (cc - m2).astype(f32)
+                sd = np.sqrt(f32(pw((d * d).astype(f32)) / f32(K)), dtype=f32)
+                mine[i] = (cc / sd).astype(f32)
+        assert np.array_equal(np.nan_to_num(z, nan=7).view(np.uint32), np.nan_to_num(mine, nan=7).view(np.uint32)), K
