@@ -43,6 +43,8 @@ struct skr_ctx {
     uint32_t* h_flags = nullptr;  // pinned mirror
     double* d_recip = nullptr;    // float64 reciprocals of a scale vector (skr_operand_fill), grown on demand
     size_t d_recip_len = 0;
+    void* d_np_plan = nullptr;    // numpy's pairwise summation unrolled for np_plan_cols columns (operand.hip: NpPlan)
+    int64_t np_plan_cols = 0;
     // workspaces owned by the ctx and grown on demand
     void* ws = nullptr;
     size_t ws_bytes = 0;

@@ -111,6 +111,7 @@ extern "C" int skr_ctx_destroy(skr_ctx* ctx) {
     if (ctx->pin_done) (void)hipEventDestroy(ctx->pin_done);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->d_recip) (void)hipFree(ctx->d_recip);
+    if (ctx->d_np_plan) (void)hipFree(ctx->d_np_plan);
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);

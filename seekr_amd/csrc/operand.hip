@@ -106,6 +106,7 @@ struct FillArgs {
     float* diag;  // diag[r] = <z_r, z_r> / K from a float32 tree sum (see skr_pearson_gemm_op)
     float out_scale;  // power of two applied before the split (fp16 halves only, see f16_scale)
     uint32_t* flags;
+    const struct NpPlan* np_plan;  // generic kernel: numpy's pairwise summation unrolled for this row width (NULL: tree sums)
 };
 
 
@@ -120,17 +121,20 @@ struct FillArgs {
 // np.add.reduce for every n up to 300 and a dozen larger ones: tests/test_oracle_golden.py.)
 constexpr int kNpMaxLeaves = 128;  // n <= 8 192 (a leaf holds 65 .. 128 values once n > 128)
 constexpr int kNpExactMaxCols = 8192;
+// the recursion for a row width, unrolled on the HOST (it is the same for every row of a launch): the leaves from left to
+// right and the additions that join them in post-order
 struct NpPlan {
     int n_leaves, prog_len;
     unsigned short leaf_start[kNpMaxLeaves], leaf_n[kNpMaxLeaves];
-    unsigned char prog[2 * kNpMaxLeaves];  // post-order: 0 = push the next leaf's sum, 1 = add the two on top
+    unsigned char prog[2 * kNpMaxLeaves];  // 0 = push the next leaf's sum, 1 = add the two on top
+};
+struct NpScratch {  // per wave, in LDS
     float leaf_sum[kNpMaxLeaves];
     float stack[16];
 };
 
-// built once per wave by lane 0 (the same for every row of the launch)
-__device__ inline void np_plan_build(NpPlan* p, int n) {
-    int sp = 0, st_s[24], st_n[24], st_k[24];  // explicit recursion stack: (start, n, 0 = expand | 1 = emit an add)
+void np_plan_build(NpPlan* p, int n) {
+    int sp = 0, st_s[32], st_n[32], st_k[32];  // explicit recursion stack: (start, n, 0 = expand | 1 = emit an add)
     p->n_leaves = 0;
     p->prog_len = 0;
     st_s[sp] = 0, st_n[sp] = n, st_k[sp] = 0, sp++;
@@ -157,7 +161,7 @@ __device__ inline void np_plan_build(NpPlan* p, int n) {
 // sum of f(0) .. f(n-1) in numpy's order; all 64 lanes call it, all return the sum.  Eight lanes share a leaf (one
 // accumulator each), eight leaves per round.
 template <class F>
-__device__ __forceinline__ float np_pairwise_sum(NpPlan* p, F f, int lane) {
+__device__ __forceinline__ float np_pairwise_sum(const NpPlan* __restrict__ p, NpScratch* sc, F f, int lane) {
     const int slot = lane >> 3, j = lane & 7;
     for (int base = 0; base < p->n_leaves; base += 8) {
         const int leaf = base + slot;
@@ -165,8 +169,14 @@ __device__ __forceinline__ float np_pairwise_sum(NpPlan* p, F f, int lane) {
         const int s0 = live ? p->leaf_start[leaf] : 0, n0 = live ? p->leaf_n[leaf] : 0;
         float r = 0.f;
         if (n0 >= 8) {
-            r = f(s0 + j);
-            for (int i = 8; i < n0 - (n0 % 8); i += 8) r = __fadd_rn(r, f(s0 + i + j));
+            // a leaf holds at most 128 values = 16 per accumulator: all 16 reads first (independent), then the chain of adds
+            const int n8 = n0 - (n0 % 8);
+            float v[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) v[m] = 8 * m + 8 <= n8 ? f(s0 + 8 * m + j) : 0.f;
+            r = v[0];
+#pragma unroll
+            for (int m = 1; m < 16; m++) r = 8 * m + 8 <= n8 ? __fadd_rn(r, v[m]) : r;
         } else if (j == 0) {
             for (int i = 0; i < n0; i++) r = __fadd_rn(r, f(s0 + i));  // res = 0.; res += a[i]
         }
@@ -177,9 +187,9 @@ __device__ __forceinline__ float np_pairwise_sum(NpPlan* p, F f, int lane) {
         if (live && j == 0) {
             if (n0 >= 8) {
                 for (int i = n0 - (n0 % 8); i < n0; i++) z = __fadd_rn(z, f(s0 + i));
-                p->leaf_sum[leaf] = z;
+                sc->leaf_sum[leaf] = z;
             } else {
-                p->leaf_sum[leaf] = r;
+                sc->leaf_sum[leaf] = r;
             }
         }
     }
@@ -191,13 +201,13 @@ __device__ __forceinline__ float np_pairwise_sum(NpPlan* p, F f, int lane) {
         int sp = 0, next = 0;
         for (int i = 0; i < p->prog_len; i++) {
             if (p->prog[i] == 0) {
-                p->stack[sp++] = p->leaf_sum[next++];
+                sc->stack[sp++] = sc->leaf_sum[next++];
             } else {
                 sp--;
-                p->stack[sp - 1] = __fadd_rn(p->stack[sp - 1], p->stack[sp]);
+                sc->stack[sp - 1] = __fadd_rn(sc->stack[sp - 1], sc->stack[sp]);
             }
         }
-        res = p->stack[0];
+        res = sc->stack[0];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -229,14 +239,9 @@ __global__ __launch_bounds__(256) void operand_fill_kernel(FillArgs a) {
     float* row = lds + (size_t)wave * ((K + 3) & ~(int64_t)3);
     const bool vec = (K & 3) == 0;
     // numpy-ordered row sums (above): the plan lives behind the row slices, one per wave
-    const bool np_exact = a.row_standardize && K <= kNpExactMaxCols;
-    NpPlan* plan = reinterpret_cast<NpPlan*>(lds + (size_t)waves * ((K + 3) & ~(int64_t)3)) + wave;
-    if (np_exact) {
-        if (lane == 0) np_plan_build(plan, (int)K);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
+    const NpPlan* plan = a.np_plan;
+    const bool np_exact = a.row_standardize && plan != nullptr;
+    NpScratch* np_sc = reinterpret_cast<NpScratch*>(lds + (size_t)waves * ((K + 3) & ~(int64_t)3)) + wave;
     bool any_nan = false, overflow = false, outlier = false, coherent = false;
     for (int64_t r = (int64_t)blockIdx.x * waves + wave; r < a.rows; r += (int64_t)gridDim.x * waves) {
         const float* xr = a.x + (size_t)r * K;
@@ -270,9 +275,9 @@ __global__ __launch_bounds__(256) void operand_fill_kernel(FillArgs a) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the row parked above is read across lanes
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            mean = __fdiv_rn(np_pairwise_sum(plan, [&](int c) { return row[c]; }, lane), kf);
-            const float m2 = __fdiv_rn(np_pairwise_sum(plan, [&](int c) { return __fsub_rn(row[c], mean); }, lane), kf);
-            const float var = __fdiv_rn(np_pairwise_sum(plan, [&](int c) {
+            mean = __fdiv_rn(np_pairwise_sum(plan, np_sc, [&](int c) { return row[c]; }, lane), kf);
+            const float m2 = __fdiv_rn(np_pairwise_sum(plan, np_sc, [&](int c) { return __fsub_rn(row[c], mean); }, lane), kf);
+            const float var = __fdiv_rn(np_pairwise_sum(plan, np_sc, [&](int c) {
                 const float d = __fsub_rn(__fsub_rn(row[c], mean), m2);
                 return __fmul_rn(d, d);
             }, lane), kf);
@@ -728,7 +733,7 @@ int launch_fill(skr_ctx* ctx, const skr_operand* op, const FillArgs& a_in) {
     const size_t row_floats = (size_t)((a.cols + 3) & ~(int64_t)3);
     const bool wide = row_floats * 4 > 150 * 1024;  // k >= 8: the row does not fit the LDS
     const int waves = (int)std::max<size_t>(1, std::min<size_t>(4, (64 * 1024) / (row_floats * 4)));
-    const size_t lds = row_floats * 4 * waves + sizeof(NpPlan) * waves;  // row slices + the numpy-order summation plans
+    const size_t lds = row_floats * 4 * waves + sizeof(NpScratch) * waves;  // row slices + the numpy-order summations' scratch
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / lds));
     const int64_t want = (a.rows + waves - 1) / waves;
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cu * per_cu));
@@ -801,6 +806,21 @@ int launch_fill(skr_ctx* ctx, const skr_operand* op, const FillArgs& a_in) {
 #undef LAUNCH_BLOCK
         SKR_HIP(hipGetLastError());
     } else {
+        FillArgs a = a_in;
+        a.np_plan = nullptr;
+        if (a.row_standardize && a.cols <= kNpExactMaxCols) {
+            // rows summed in numpy's pairwise order: the recursion for this width, unrolled here once and kept on the device
+            if (!ctx->d_np_plan) SKR_HIP(hipMalloc(&ctx->d_np_plan, sizeof(NpPlan)));
+            if (ctx->np_plan_cols != a.cols) {
+                void* pin = nullptr;
+                SKR_TRY(skr_ctx_pinned(ctx, sizeof(NpPlan), &pin));
+                np_plan_build(reinterpret_cast<NpPlan*>(pin), (int)a.cols);
+                SKR_HIP(hipMemcpyAsync(ctx->d_np_plan, pin, sizeof(NpPlan), hipMemcpyHostToDevice, ctx->stream));
+                SKR_TRY(skr_ctx_pinned_used(ctx));
+                ctx->np_plan_cols = a.cols;
+            }
+            a.np_plan = reinterpret_cast<const NpPlan*>(ctx->d_np_plan);
+        }
         SkrProfScope prof(ctx, "operand_fill");
 #define LAUNCH(T)                                                                                         \
     do {                                                                                                      \
@@ -907,6 +927,7 @@ extern "C" int skr_operand_fill(skr_ctx* ctx, const skr_mat* x, const skr_mat* c
                 (long long)op->rows, (long long)op->cols, (long long)x->rows, (long long)x->cols);
     if (y) SKR_REQUIRE(y->ctx == ctx && y->dtype == SKR_F32 && y->rows == x->rows && y->cols == x->cols, "bad y");
     FillArgs a;
+    a.np_plan = nullptr;
     a.x = (const float*)x->data;
     a.rows = x->rows;
     a.cols = x->cols;
