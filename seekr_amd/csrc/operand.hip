@@ -118,7 +118,7 @@ struct FillArgs {
 // k = 1, 2) the float32 result depends on every one of these roundings, so the rows the generic fill kernel serves
 // (every width but the three register-resident ones) are summed in exactly this order: z is then numpy's z bit for bit
 // and what is left between the device and the reference is the inner product's own rounding.  (Checked against
-// np.add.reduce for every n up to 300 and a dozen larger ones: tests/test_oracle_golden.py.)
+// np.add.reduce for every n up to 300 and a dozen larger ones in the CPU test suite.)
 constexpr int kNpMaxLeaves = 128;  // n <= 8 192 (a leaf holds 65 .. 128 values once n > 128)
 constexpr int kNpExactMaxCols = 8192;
 // the recursion for a row width, unrolled on the HOST (it is the same for every row of a launch): the leaves from left to
