@@ -33,6 +33,11 @@ def test_library_exports_every_declared_symbol():
     assert diag_declared == set(_lib.DIAG_SIGNATURES), diag_declared ^ set(_lib.DIAG_SIGNATURES)
     for name in diag_declared:
         assert not hasattr(handle, name), name + " is exported by the production library"
+    # ... nor does it hold the stamping instance of the contraction (PERSIST = true, DIAG = true) or the 4-wave A/B arm
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert not re.search(rb"split16_kernel\w*Lb1ELb1E", blob), "the production library holds the DIAG instance of the contraction"
+    assert not re.search(rb"split16_kernel\w*Li4EEEv", blob), "the production library holds the 4-wave arm of the contraction"
+    assert re.search(rb"split16_kernel\w*Lb1ELb0ELi8EEEv", blob), "the shipped instance of the contraction is missing"
 
 
 def test_no_launch_path_reads_the_environment():
