@@ -519,7 +519,7 @@ def run_rank(args):
     # Dominant kernel: the Pearson contraction (MFMA bound), 2*4^k algorithmic flop per pair it
     # actually multiplies.  The self block mirrors one triangle on the bf16 path, so the pairs it
     # multiplies are ~half of the pairs it delivers; both figures are reported.
-    sym = (not args.no_symmetry) and args.precision != "fp32"
+    sym = not args.no_symmetry  # the fp32 kernel mirrors its own block too (128-row tiles)
     tile = 128 if args.precision == "fp32" else 256
     exec_pairs = n_loc * (n_loc + tile) / 2.0 if sym else float(n_loc) * n_loc
     if symmetric_layout:
