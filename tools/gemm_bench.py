@@ -22,10 +22,13 @@ def main():
     ap.add_argument("--precision", default="f16x3")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--diag-lib", action="store_true", help="run on libseekr_hip_diag.so (holds the 4-wave arm, SEEKR_GEMM_WAVE_TILE=1)")
+    ap.add_argument("--lib", default="", help="another build of the library to run on (A/B across source versions, one process each)")
     ap.add_argument("variants", nargs="*")
     args = ap.parse_args()
     if args.diag_lib:
         _lib.LIB_PATH = _lib.DIAG_LIB_PATH
+    if args.lib:
+        _lib.LIB_PATH = os.path.abspath(args.lib)
     variants = []
     for spec in args.variants or ["base="]:
         name, _, envs = spec.partition("=")
