@@ -16,7 +16,9 @@ On G > 1 GPUs the default result layout is the symmetric one (seekr_amd/distribu
 unordered pair of row shards is multiplied once, by one of its two ranks, which keeps the
 block and its transpose; every ordered pair ends up in exactly one GPU's HBM, as on one GPU
 (where the lower triangle is the mirror of the upper).  `--layout rowblock` gives every rank
-its full rows of r instead, multiplying each off-diagonal block twice across the node.
+its full rows of r instead, multiplying each off-diagonal block twice across the node; `--layout
+allgather` produces the same row blocks after ONE RCCL all-gather of the prepared operands (the
+schedule BASELINE.json's north_star names: no overlap, a single collective).
 
 Launching.  With WORLD_SIZE in the environment (torch.distributed.run, or any launcher that sets
 RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT) this process IS one rank.  Without it and with
@@ -25,9 +27,9 @@ fresh child processes of this same script (one per GPU, no exec of a GPU-initial
 rank 0's JSON line, and on any rank's failure or after --launch-timeout seconds kills exactly the
 process groups it started and exits non-zero with every rank's stderr tail.  A failed first attempt
 in the symmetric layout (including a failed self-test of the half-ring schedule, exit code 17) is
-retried ONCE, in a new set of children, with the most conservative configuration — the plain row-block
-layout (no split first shift, no grouped shifts) and the column-sum chain over send/recv; the JSON line
-then carries "layout_fallback".
+retried ONCE, in a new set of children, with the most conservative configuration — row blocks after one
+all-gather of the operands (no shifts, no tickets to order) and the column-sum chain over send/recv; the
+JSON line then carries "layout_fallback".
 """
 import argparse
 import hashlib
@@ -69,8 +71,9 @@ def parse(argv=None):
                     help="compute both triangles of the self-comparison block instead of mirroring one")
     ap.add_argument("--grouped-shifts", action="store_true",
                     help="symmetric layout: post all half-ring shifts as one grouped exchange (one receive buffer per shift)")
-    ap.add_argument("--layout", default="symmetric", choices=["symmetric", "rowblock"],
-                    help="multi-GPU result layout (see module docstring); fp32 / --no-symmetry imply rowblock")
+    ap.add_argument("--layout", default="symmetric", choices=["symmetric", "rowblock", "allgather"],
+                    help="multi-GPU schedule (see module docstring): symmetric half ring, row blocks by pairwise shifts, or row "
+                         "blocks after ONE all-gather of the operands; fp32 / --no-symmetry imply rowblock")
     ap.add_argument("--launch-timeout", type=float, default=300.0,
                     help="launcher mode: seconds after which the rank processes are killed")
     ap.add_argument("--no-selftest", action="store_true", help="skip the half-ring schedule's self-test before the warm-up")
@@ -176,14 +179,14 @@ def launch(args, argv):
             print(report, file=sys.stderr, flush=True)
             why = ("the half-ring schedule's self-test failed" if payload == "selftest"
                    else "the first attempt failed ({})".format(payload))
-            print("bench.py launcher: {}; retrying once in a new set of rank processes with --layout rowblock".format(why),
+            print("bench.py launcher: {}; retrying once in a new set of rank processes with --layout allgather".format(why),
                   file=sys.stderr, flush=True)
             argv2 = [a for a in argv if a != "--grouped-shifts"]
             for i, a in enumerate(argv2):
                 if a == "--layout":
                     del argv2[i:i + 2]
                     break
-            argv2 = [a for a in argv2 if not a.startswith("--layout=")] + ["--layout", "rowblock"]
+            argv2 = [a for a in argv2 if not a.startswith("--layout=")] + ["--layout", "allgather"]
             # the retry is the most conservative configuration: row blocks, and the column-sum chain over send/recv
             ok, payload, report = _run_rank_set(argv2, size, args.launch_timeout,
                                                 {"SEEKR_BENCH_FALLBACK": "symmetric layout abandoned: " + why, "SEEKR_CHAIN": "rccl"},
@@ -393,7 +396,7 @@ def symmetric_selftest(ctx, comm, engine, k, grouped):
 def run_rank(args):
     from seekr_amd import _lib, launch as skr_launch
     from seekr_amd.distributed import (HipEngine, half_ring_plan, shard_bounds, sharded_normalize_prepare,
-                                       sharded_pearson_rowblock, sharded_pearson_symmetric)
+                                       sharded_pearson_allgather, sharded_pearson_rowblock, sharded_pearson_symmetric)
     from seekr_amd.synthetic import synthetic_ascii
 
     rank, size, _ = skr_launch.world()
@@ -425,7 +428,9 @@ def run_rank(args):
     r_col = ctx.zeros(n_total, n_loc) if (symmetric_layout and size > 1) else None  # mirrored blocks (h, g)
     max_shard = max(bounds[g + 1] - bounds[g] for g in range(size))
     n_recv = max(2, size // 2) if args.grouped_shifts else 2
-    recv = [engine.empty_operand(max_shard, n_cols) for _ in range(n_recv)] if size > 1 else [None, None]
+    use_allgather = args.layout == "allgather" and size > 1
+    recv = [engine.empty_operand(max_shard, n_cols) for _ in range(n_recv)] if size > 1 and not use_allgather else [None, None]
+    gathered = engine.empty_operand(n_total, n_cols) if use_allgather else None  # every rank's operand rows, kept between steps
 
     def step():
         _lib.count_per_kb(ctx, packed, k, out=x)
@@ -433,6 +438,8 @@ def run_rank(args):
         zz = sharded_normalize_prepare(engine, comm, x, n_total, "Log2.post", True, True, keep_counts=True, op=z)[3]
         if symmetric_layout:
             sharded_pearson_symmetric(engine, comm, zz, bounds, r, r_col, recv, grouped=args.grouped_shifts)
+        elif use_allgather:
+            sharded_pearson_allgather(engine, comm, zz, bounds, r, gathered)
         else:
             sharded_pearson_rowblock(engine, comm, zz, bounds, r, recv[:2])
 
@@ -582,7 +589,8 @@ def run_rank(args):
                                "self Pearson ({} x {} r matrix, row-sharded)".format(n_total, length, k, n_total, n_total),
                    "rows_total": n_total, "rows_per_gpu": n_loc, "length": length, "k": k,
                    "precision": args.precision, "sharding": "rows x{}".format(size),
-                   "layout": "symmetric half-ring: each ordered pair on one GPU" if symmetric_layout else "row blocks"},
+                   "layout": ("symmetric half-ring: each ordered pair on one GPU" if symmetric_layout else
+                              "row blocks after one all-gather of the operands" if use_allgather else "row blocks")},
         "mbases_per_s_counted": round(mbases * size, 1),
         "pearson_kernel_mpairs_per_s": round(pairs_per_step / (gemm_ms_step * 1e-3) / 1e6, 1) if gemm_ms_step > 0 else None,
         "roofline": roofline, "roofline_count": roofline_count,

@@ -549,6 +549,26 @@ def allgather_operand(engine, comm, z, bounds, full=None):
     return full
 
 
+def sharded_pearson_allgather(engine, comm, z, bounds, r, full=None):
+    """Row block r[n_g, N] = z_g . Z^T / K the way the north_star names it: ONE all-gather of the prepared operands
+    (every rank's shard to every rank, all xGMI links at once: skr_comm_allgather_rows), then this rank's rows against
+    the gathered matrix — the own block as a symmetric product, the columns left and right of it as plain ones, so the
+    result is the row-block layout's bit for bit (same kernel, same operands).  No transfer overlaps a contraction here:
+    the schedule trades the half ring's overlap and its halved work for a single collective, which is what makes it the
+    most robust of the three (bench.py --layout allgather).  `full`: an operand of bounds[-1] rows to gather into (kept
+    between steps by the caller).  Returns r."""
+    size, rank = comm.size, comm.rank
+    full = allgather_operand(engine, comm, z, bounds, full)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    n_total = bounds[-1]
+    engine.gemm(z, z, r, lo, symmetric=True)
+    if lo > 0:
+        engine.gemm(z, engine.view(full, 0, lo), r, 0)
+    if hi < n_total:
+        engine.gemm(z, engine.view(full, hi, n_total - hi), r, hi)
+    return r
+
+
 def stripes_of_rank(n_total, stripe_rows, size, rank):
     """Row stripes [s0, s1) this rank reduces.  Stripes are dealt in zig-zag order (0..P-1, P-1..0,
     ...): with upper_only the work of a stripe shrinks linearly with its index, and the zig-zag

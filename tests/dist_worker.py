@@ -169,7 +169,8 @@ def run(rank, size, port, n_rows, n_cols, log2, out_dir, with_nan):
     import torch
     import torch.distributed as dist
     from seekr_amd.distributed import (shard_bounds, sharded_normalize, sharded_normalize_prepare,
-                                       sharded_pearson_edges, sharded_pearson_rowblock, sharded_pearson_symmetric)
+                                       sharded_pearson_allgather, sharded_pearson_edges, sharded_pearson_rowblock,
+                                       sharded_pearson_symmetric)
 
     dist.init_process_group("gloo", rank=rank, world_size=size)
     try:
@@ -191,6 +192,9 @@ def run(rank, size, port, n_rows, n_cols, log2, out_dir, with_nan):
         recv = [np.zeros((max_shard, n_cols), np.float32), np.zeros((max_shard, n_cols), np.float32)]
         with np.errstate(all="ignore"):
             sharded_pearson_rowblock(engine, comm, z, bounds, r, recv)
+        r_ag = np.zeros((hi - lo, n_rows), dtype=np.float32)
+        with np.errstate(all="ignore"):
+            sharded_pearson_allgather(engine, comm, z, bounds, r_ag)
         # the symmetric layout: NaN-filled buffers so that unowned cells are recognisable
         r_row = np.full((hi - lo, n_rows), np.float32(-7.0))
         r_col = np.full((n_rows, hi - lo), np.float32(-7.0))
@@ -203,7 +207,7 @@ def run(rank, size, port, n_rows, n_cols, log2, out_dir, with_nan):
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), x=x, mean=mean, std=std, r=r, r_row=r_row, r_col=r_col,
                  e_up_i=e_up[0], e_up_j=e_up[1], e_up_v=e_up[2], e_all_i=e_all[0], e_all_j=e_all[1], e_all_v=e_all[2],
                  blocks=np.array([(0 if b[0] == "row" else 1,) + tuple(b[1:]) for b in blocks], dtype=np.int64),
-                 has_nan=np.array(has_nan), lo=np.array(lo), hi=np.array(hi))
+                 has_nan=np.array(has_nan), lo=np.array(lo), hi=np.array(hi), r_ag=r_ag)
         comm.barrier()
     finally:
         dist.destroy_process_group()

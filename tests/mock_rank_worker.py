@@ -12,8 +12,8 @@ sys.path.insert(0, ROOT)
 def main():
     out_dir, n_total, length, k = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     from seekr_amd import _lib, launch
-    from seekr_amd.distributed import (HipEngine, shard_bounds, sharded_normalize_prepare, sharded_pearson_edges,
-                                       sharded_pearson_rowblock, sharded_pearson_symmetric)
+    from seekr_amd.distributed import (HipEngine, shard_bounds, sharded_normalize_prepare, sharded_pearson_allgather,
+                                       sharded_pearson_edges, sharded_pearson_rowblock, sharded_pearson_symmetric)
     from seekr_amd.synthetic import synthetic_ascii
     ctx, comm = launch.init()
     rank, size = comm.rank, comm.size
@@ -51,12 +51,14 @@ def main():
     recv = recv[:2]
     r = ctx.zeros(hi - lo, n_total)
     sharded_pearson_rowblock(engine, comm, z, bounds, r, recv)
+    r_ag = ctx.zeros(hi - lo, n_total)
+    sharded_pearson_allgather(engine, comm, z, bounds, r_ag)
     e = sharded_pearson_edges(engine, comm, z, bounds, 0.05, stripe_rows=128, upper_only=True)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), mean=mean.vector(), std=std.vector(), x=x.to_numpy(),
              r_row=r_row.to_numpy(), r_col=r_col.to_numpy(), r=r.to_numpy(), has_nan=np.array(has_nan),
              blocks=np.array([(0 if b[0] == "row" else 1,) + tuple(b[1:]) for b in blocks], dtype=np.int64),
              e_i=e[0], e_j=e[1], e_v=e[2], lo=np.array(lo), hi=np.array(hi),
-             chain_note=np.array(getattr(comm, "_chain_note", "")))
+             chain_note=np.array(getattr(comm, "_chain_note", "")), r_ag=r_ag.to_numpy())
     comm.barrier()
     ctx.sync()
 

@@ -73,6 +73,7 @@ def test_sharded_pipeline_matches_single_process(size, n_rows, log2, tmp_path):
         assert np.array_equal(bits(p["x"]), bits(x[lo:hi]))
         assert not bool(p["has_nan"])
         assert np.allclose(p["r"], r[lo:hi], rtol=1e-5, atol=2e-6)
+        assert np.allclose(p["r_ag"], p["r"], rtol=1e-6, atol=1e-6)   # the all-gather schedule: the same row block
     full_r = np.concatenate([p["r"] for p in parts], axis=0)
     assert full_r.shape == (n_rows, n_rows)
     # symmetric (half-ring) layout: every ordered pair lives on exactly one rank, same values

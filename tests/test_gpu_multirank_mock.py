@@ -103,6 +103,7 @@ def check_ranks(size, asynchronous, mock_lib, single, tmp_path, extra_env=None):
         assert np.array_equal(bits(p["x"]), bits(single["x"][lo:hi]))
         assert not bool(p["has_nan"])
         assert np.allclose(p["r"], single["r"][lo:hi], rtol=1e-6, atol=1e-6)
+        assert np.array_equal(bits(p["r_ag"]), bits(p["r"]))  # the all-gather schedule: the row-block result bit for bit
     # symmetric layout: every cell on exactly one rank, exactly symmetric, same values as one GPU
     full, hits = np.zeros((n, n), np.float32), np.zeros((n, n), np.int32)
     for p in parts:
@@ -208,7 +209,7 @@ def test_bench_starts_its_own_rank_processes(mock_lib):
 
 def test_bench_falls_back_to_row_blocks_when_the_selftest_fails(mock_lib):
     """The half-ring self-test fails on rank 1 of 3 (test hook): every rank leaves with the self-test's exit code, and the
-    launcher starts a NEW set of rank processes with --layout rowblock; the line says so."""
+    launcher starts a NEW set of rank processes with --layout allgather; the line says so."""
     import json
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "1", "--rows", "4500",
            "--length", "500"]
@@ -216,7 +217,7 @@ def test_bench_falls_back_to_row_blocks_when_the_selftest_fails(mock_lib):
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert "self-test FAILED" in res.stderr and "retrying once" in res.stderr and "failure injected" in res.stderr
     out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
-    assert out["n_gpus"] == 3 and out["n_ranks_seen"] == 3 and out["config"]["layout"] == "row blocks"
+    assert out["n_gpus"] == 3 and out["n_ranks_seen"] == 3 and out["config"]["layout"].startswith("row blocks after one all-gather")
     assert "self-test failed" in out["layout_fallback"] and out["value"] > 0
 
 

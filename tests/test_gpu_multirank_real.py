@@ -48,7 +48,7 @@ def test_k7_over_real_rccl(tmp_path):
 
 
 @needs2
-@pytest.mark.parametrize("extra", [[], ["--grouped-shifts"], ["--layout", "rowblock"]])
+@pytest.mark.parametrize("extra", [[], ["--grouped-shifts"], ["--layout", "rowblock"], ["--layout", "allgather"]])
 def test_bench_starts_two_real_ranks(extra):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR",
                                                                "SEEKR_TEST_HOOKS", "SEEKR_RCCL_LIB", "SEEKR_FORCE_DEVICE")}

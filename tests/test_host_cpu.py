@@ -185,7 +185,7 @@ def _bench():
 def test_bench_launcher_reports_every_rank_and_retries_once():
     """`python bench.py --gpus 2` without WORLD_SIZE starts its own rank processes.  Here there is no
     GPU (or, on a test box, one): both attempts fail, and the launcher must say so loudly — non-zero exit, every
-    rank's stderr tail, the one retry with --layout rowblock — instead of dying in argument checking or hanging."""
+    rank's stderr tail, the one retry with --layout allgather — instead of dying in argument checking or hanging."""
     from seekr_amd import _lib
     if _lib.device_count() >= 2:
         pytest.skip("two GPUs are visible: the launch would succeed")
@@ -194,7 +194,7 @@ def test_bench_launcher_reports_every_rank_and_retries_once():
                           "--launch-timeout", "120"], env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 1 and res.stdout.strip() == ""
     err = res.stderr
-    assert "attempt 1" in err and "attempt 2" in err and "retrying once" in err and "--layout rowblock" in err
+    assert "attempt 1" in err and "attempt 2" in err and "retrying once" in err and "--layout allgather" in err
     for rank in (0, 1):
         assert err.count("---- rank %d (exit code" % rank) == 2
     assert "SeekrHipError" in err or "out of range" in err
