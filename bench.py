@@ -62,6 +62,8 @@ def parse(argv=None):
     ap.add_argument("--rows", type=int, default=0, help="total transcripts (default 50000*sqrt(gpus))")
     ap.add_argument("--length", type=int, default=2000)
     ap.add_argument("-k", "--k", type=int, default=6, dest="k")
+    ap.add_argument("--alphabet", default="AGTC", help="any string the reference accepts (kmer_counts.py:120-122); other than four "
+                    "distinct letters the step counts with the any-alphabet kernel from resident ASCII (len^k columns)")
     ap.add_argument("--precision", default=os.environ.get("SEEKR_PRECISION", "f16x3"),
                     choices=["fp32", "bf16x3", "bf16x4", "f16x3"],
                     help="Pearson contraction arithmetic; every choice is inside the parity bar "
@@ -174,7 +176,11 @@ def launch(args, argv):
     size = args.gpus
     symmetric = args.layout == "symmetric" and args.precision != "fp32" and not args.no_symmetry
     with tempfile.TemporaryDirectory(prefix="seekr_bench_") as log_dir:
-        ok, payload, report = _run_rank_set(argv, size, args.launch_timeout, {}, log_dir, 1)
+        # first attempt: the column sums travel over send/recv (the transport that has run); the peer-mailbox chain is
+        # measured next to it AFTER the timed region (chain_ab in the line).  Not under the test hooks by default: several
+        # ranks on one GPU need SEEKR_CHAIN_HOST_WAIT for the mailbox wait, which the tests that want it set themselves.
+        ab = os.environ.get("SEEKR_BENCH_CHAIN_AB", "0" if os.environ.get("SEEKR_TEST_HOOKS") == "1" else "1")
+        ok, payload, report = _run_rank_set(argv, size, args.launch_timeout, {"SEEKR_BENCH_CHAIN_AB": ab}, log_dir, 1)
         if not ok and symmetric:
             print(report, file=sys.stderr, flush=True)
             why = ("the half-ring schedule's self-test failed" if payload == "selftest"
@@ -189,7 +195,8 @@ def launch(args, argv):
             argv2 = [a for a in argv2 if not a.startswith("--layout=")] + ["--layout", "allgather"]
             # the retry is the most conservative configuration: row blocks, and the column-sum chain over send/recv
             ok, payload, report = _run_rank_set(argv2, size, args.launch_timeout,
-                                                {"SEEKR_BENCH_FALLBACK": "symmetric layout abandoned: " + why, "SEEKR_CHAIN": "rccl"},
+                                                {"SEEKR_BENCH_FALLBACK": "symmetric layout abandoned: " + why, "SEEKR_CHAIN": "rccl",
+                                                 "SEEKR_BENCH_CHAIN_AB": "0"},
                                                 log_dir, 2)
         if ok:
             print(payload, flush=True)
@@ -374,7 +381,9 @@ def symmetric_selftest(ctx, comm, engine, k, grouped):
     for which, br, bc, nr, nc, gr, gc in blocks:
         if which == "row":
             got, want = row[br:br + nr, bc:bc + nc], rb[br:br + nr, gc:gc + nc]
-            if not np.array_equal(got.view(np.uint32), want.view(np.uint32)) and not np.allclose(got, want, rtol=1e-6, atol=1e-6):
+            # same kernel, same operands in the same roles: the same bits, nothing less (a ticket that let a block read a
+            # partly written shard could hide inside any tolerance)
+            if not np.array_equal(got.view(np.uint32), want.view(np.uint32)):
                 reason = "rank {}: block rows {}+{} x cols {}+{} differs from the row-block result (max |d| {:.3g})".format(
                     rank, gr, nr, gc, nc, float(np.nanmax(np.abs(got - want))))
                 break
@@ -386,11 +395,52 @@ def symmetric_selftest(ctx, comm, engine, k, grouped):
     if os.environ.get("SEEKR_TEST_HOOKS") == "1" and os.environ.get("SEEKR_BENCH_FAIL_SELFTEST") == str(rank):
         reason = "rank {}: failure injected by the test hook".format(rank)  # tests/test_gpu_multirank_mock.py
     bad = comm.allreduce([1.0 if reason else 0.0], "max")[0]
-    for m in (r_row, r_col, r_rb, x):
+    for m in (r_row, r_col, r_rb, x, z, packed, *recv):
         m.free()
     if bad and not reason:
         reason = "rank {}: passed here, failed on another rank".format(rank)
     return reason
+
+
+def column_chain_ab(ctx, comm, engine, x, n_cols, reps=5):
+    """After the timed region (VERDICT r3 #3a): one column-sum pass over all ranks' rows, timed over send/recv and over
+    the peer-mailbox chain (set up here, collectively; its own self-test decides whether it is used at all), the two
+    results compared bit for bit.  Returns the dict that goes into the line as `chain_ab`."""
+    from seekr_amd.distributed import _chain_colsum
+    saved_env, saved_chain, saved_note = os.environ.get("SEEKR_CHAIN"), comm._chain, comm._chain_note
+    out, vecs = {}, {}
+    for name in ("rccl", "mailbox"):
+        os.environ["SEEKR_CHAIN"] = name
+        if comm._chain:
+            comm._chain.free()
+        comm._chain = None  # the transport is chosen (and the mailboxes set up) on the next pass, by every rank
+        v = _chain_colsum(engine, comm, x, n_cols)  # set-up + warm-up
+        ctx.sync()
+        comm.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            v.free()
+            v = _chain_colsum(engine, comm, x, n_cols)
+        ctx.sync()
+        comm.barrier()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        gave_up = comm.allreduce([1.0 if comm.chain_gave_up() else 0.0], "max")[0] > 0
+        out[name] = {"ms_per_pass": round(comm.allreduce([ms], "max")[0], 4), "transport": comm._chain_note or "send/recv",
+                     "a_link_gave_up_waiting": bool(gave_up)}
+        vecs[name] = v.vector().view(np.uint32).copy()
+        v.free()
+    same = np.array_equal(vecs["rccl"], vecs["mailbox"])
+    out["bit_identical"] = bool(comm.allreduce([0.0 if same else 1.0], "max")[0] == 0)
+    out["note"] = ("one float32 column-sum pass over all ranks' rows (a step has three), wall time between barriers, max over "
+                   "ranks; the timed region above used SEEKR_CHAIN=" + (saved_env or "rccl"))
+    if comm._chain:
+        comm._chain.free()
+    comm._chain, comm._chain_note = (None if saved_chain else saved_chain), saved_note
+    if saved_env is None:
+        os.environ.pop("SEEKR_CHAIN", None)
+    else:
+        os.environ["SEEKR_CHAIN"] = saved_env
+    return out
 
 
 def run_rank(args):
@@ -404,7 +454,8 @@ def run_rank(args):
         raise SystemExit("--gpus {} but WORLD_SIZE={}".format(args.gpus, size))
     ctx, comm = skr_launch.init()
     k, length = args.k, args.length
-    n_cols = 4 ** k
+    generic = not (len(args.alphabet) == 4 and len(set(args.alphabet)) == 4)
+    n_cols = len(args.alphabet) ** k
     n_total = args.rows or int(round(50_000 * math.sqrt(size) / size)) * size
     bounds = shard_bounds(n_total, size)
     lo, hi = bounds[rank], bounds[rank + 1]
@@ -420,7 +471,13 @@ def run_rank(args):
 
     # ---- synthetic input, packed and resident in HBM before the timed region
     blob, offsets = synthetic_ascii(SEED, n_loc, length, start=lo)
-    packed = _lib.PackedSeqs.from_buffer(ctx, blob, offsets, "AGTC")
+    if generic:
+        # letters drawn uniformly from the alphabet given (the 4-letter generator has no N): resident ASCII, one byte per base
+        letters = np.frombuffer(args.alphabet.encode("latin-1"), dtype=np.uint8)
+        blob = letters[np.random.default_rng([SEED, lo]).integers(0, len(letters), size=blob.size)]
+        packed = _lib.AsciiSeqs(ctx, blob, offsets)
+    else:
+        packed = _lib.PackedSeqs.from_buffer(ctx, blob, offsets, args.alphabet)
     del blob
     x = ctx.empty(n_loc, n_cols)
     z = engine.empty_operand(n_loc, n_cols)  # row-standardised shard in the contraction's operand layout
@@ -433,7 +490,10 @@ def run_rank(args):
     gathered = engine.empty_operand(n_total, n_cols) if use_allgather else None  # every rank's operand rows, kept between steps
 
     def step():
-        _lib.count_per_kb(ctx, packed, k, out=x)
+        if generic:
+            _lib.count_generic_dev(ctx, packed, args.alphabet, k, out=x)
+        else:
+            _lib.count_per_kb(ctx, packed, k, out=x)
         # column statistics (rank-chained), then ONE pass: normalised counts -> x, standardised rows -> z
         zz = sharded_normalize_prepare(engine, comm, x, n_total, "Log2.post", True, True, keep_counts=True, op=z)[3]
         if symmetric_layout:
@@ -514,10 +574,13 @@ def run_rank(args):
             worst = worst if np.isfinite(worst) else 1e9
             del x_loc
         multi_verified = comm.allreduce([worst], "max")[0]
+    chain_ab = None
+    if size > 1 and os.environ.get("SEEKR_BENCH_CHAIN_AB") == "1":
+        chain_ab = column_chain_ab(ctx, comm, engine, x, n_cols)
     gemm_name = {"fp32": "pearson_gemm_f32", "bf16x3": "pearson_gemm_bf16x3", "bf16x4": "pearson_gemm_bf16x4",
                  "f16x3": "pearson_gemm_f16x3"}[args.precision]
     gemm = kern.get(gemm_name, {"ms_total": 0.0, "launches": 0})
-    count = kern.get("count_kmers_f32", {"ms_total": 0.0, "launches": 0})
+    count = kern.get("count_generic" if generic else "count_kmers_f32", {"ms_total": 0.0, "launches": 0})
 
     if rank != 0:
         return
@@ -545,9 +608,10 @@ def run_rank(args):
     # PMC traffic: from the committed summary of this very workload, taken with this library's kernel set — else null
     gemm_key = {"fp32": "pearson_gemm_f32_kernel", "bf16x3": "split16_kernelIDF16bLi3", "bf16x4": "split16_kernelIDF16bLi4",
                 "f16x3": "split16_kernelIDF16_Li3"}[args.precision]
-    wl = workload_key(n_total, length, k, args.precision, size)
+    wl = workload_key(n_total, length, k, args.precision, size) + (" alphabet=" + args.alphabet if generic else "")
     gemm_traffic, gemm_why = (None, "--no-symmetry") if args.no_symmetry else pmc_traffic(gemm_key, wl, _lib.LIB_PATH)
-    count_traffic, count_why = pmc_traffic("count_rows_kernel<0", wl, _lib.LIB_PATH)  # <0, ...>: the float32, non-Log2.pre instantiation
+    count_traffic, count_why = pmc_traffic("count_generic_lds_kernel<float, false>" if generic else "count_rows_kernel<0", wl,
+                                           _lib.LIB_PATH)  # <0, ...>: the float32, non-Log2.pre instantiation
     roofline = {"kernel": gemm_name, "bound": "mfma", "achieved": round(achieved_tf, 2), "peak": peak_tf,
                 "unit": "TFLOP/s", "frac": round(achieved_tf / peak_tf, 4),
                 "traffic": round(gemm_traffic["bytes"] / 1e9, 2) if gemm_traffic else None,
@@ -564,12 +628,13 @@ def run_rank(args):
                         "delivers (multiplied_*), and the split path issues {} 16-bit MFMA products per multiplication "
                         "(mfma_executed_* = what the matrix cores really run, against the same dense peak)".format(
                             exec_pairs, delivered_pairs, nprod)}
-    # counting kernel: HBM bound, 0.25 B/base packed in + 4*4^k B per sequence out
+    # counting kernel: HBM bound, 0.25 B/base packed in (1 B/base ASCII for the any-alphabet kernel: SURVEY 8d) + 4 A^k B per
+    # sequence out
     count_avg_ms = count["ms_total"] / max(count["launches"], 1)
-    count_bytes = n_loc * (length * 0.25 + 8 + 4.0 * n_cols)
+    count_bytes = n_loc * (length * (1.0 if generic else 0.25) + 8 + 4.0 * n_cols)
     count_gbs = count_bytes / (count_avg_ms * 1e-3) / 1e9 if count_avg_ms > 0 else 0.0
     mbases = n_loc * length / (count_avg_ms * 1e-3) / 1e6 if count_avg_ms > 0 else 0.0
-    roofline_count = {"kernel": "count_kmers_f32", "bound": "hbm", "achieved": round(count_gbs, 1),
+    roofline_count = {"kernel": "count_generic (ASCII in, any alphabet)" if generic else "count_kmers_f32", "bound": "hbm", "achieved": round(count_gbs, 1),
                       "peak": PEAK["hbm_gbs"], "unit": "GB/s", "frac": round(count_gbs / PEAK["hbm_gbs"], 4),
                       "traffic": round(count_traffic["bytes"] / 1e9, 3) if count_traffic else None,
                       "traffic_unit": "GB per launch", "traffic_detail": count_traffic if count_traffic else {"unavailable": count_why},
@@ -587,7 +652,8 @@ def run_rank(args):
         "data": "synthetic",
         "config": {"workload": "{} synthetic {} nt transcripts, k={}, counts + Log2.post normalisation + "
                                "self Pearson ({} x {} r matrix, row-sharded)".format(n_total, length, k, n_total, n_total),
-                   "rows_total": n_total, "rows_per_gpu": n_loc, "length": length, "k": k,
+                   "rows_total": n_total, "rows_per_gpu": n_loc, "length": length, "k": k, "alphabet": args.alphabet,
+                   "columns": n_cols,
                    "precision": args.precision, "sharding": "rows x{}".format(size),
                    "layout": ("symmetric half-ring: each ordered pair on one GPU" if symmetric_layout else
                               "row blocks after one all-gather of the operands" if use_allgather else "row blocks")},
@@ -599,6 +665,8 @@ def run_rank(args):
     if size > 1:
         out["n_ranks_seen"] = n_ranks_seen
         out["per_rank"] = per_rank
+        if chain_ab is not None:
+            out["chain_ab"] = chain_ab
         out["selftest"] = ("skipped" if args.no_selftest or not symmetric_layout
                            else "half-ring schedule == row-block schedule on a small set, on every rank")
         out["verified"] = bool(multi_verified <= 1.0)
@@ -614,7 +682,7 @@ def run_rank(args):
         out["verified"] = bool(ok)
         out["verified_detail"] = {"rows": min(32, n_loc), "columns": n_total, "worst_error_over_bar": round(worst, 4),
                                   "bar": "|dr| <= 2e-6 + 1e-5 |r| against oracle.pearson (pearson.py:35-41)"}
-    if size == 1 and not args.no_cpu_baseline:
+    if size == 1 and not args.no_cpu_baseline and not generic:
         head = x_host[:min(12000 if k <= 6 else 4000, n_loc)]
         cb = cpu_baseline(k, length, head)
         t_cpu = n_total * length / cb["rate_bases"] + pairs_per_step / cb["rate_pairs"]

@@ -70,6 +70,8 @@ int skr_device_count(int* count);
 int skr_ctx_create(int device, skr_ctx** out);
 int skr_ctx_destroy(skr_ctx* ctx);
 int skr_ctx_sync(skr_ctx* ctx);
+/* Free and total device memory of the ctx's GPU in bytes (hipMemGetInfo): callers size stripes and tests against it. */
+int skr_ctx_mem_info(skr_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);
 int skr_ctx_device(const skr_ctx* ctx, int* device);
 /* The SEEKR_GEMM_* / SEEKR_COUNT_* A/B switches are read from the environment when the ctx is created;
  * this reads them again (bench tools that interleave variants in one process).  No launch calls getenv.            */
@@ -135,6 +137,16 @@ int skr_count_per_kb(skr_ctx* ctx, const skr_seqs* s, int k, int log2_pre, skr_m
  * skr_count_per_kb are the fast path for 4 distinct letters; this one serves everything else.   */
 int skr_count_generic(skr_ctx* ctx, const char* bases, const int64_t* offsets, int64_t n, const char* alphabet,
                       int alen, int k, int log2_pre, skr_mat* out);
+
+/* The same from ASCII sequences RESIDENT on the device (`skr_aseqs`: one upload, any number of counting calls — what a
+ * pipeline that re-counts, and bench.py's timed region, use).  Up to 16 384 columns (5 letters to k = 6, 20 to k = 3)
+ * the histogram lives in the LDS and the row write is the only device traffic; wider rows count into a uint32 scratch
+ * histogram in HBM.  skr_count_generic above = skr_aseqs_create + skr_count_generic_dev + skr_aseqs_free.             */
+typedef struct skr_aseqs skr_aseqs;
+int skr_aseqs_create(skr_ctx* ctx, const char* bases, const int64_t* offsets, int64_t n, skr_aseqs** out);
+int skr_aseqs_free(skr_aseqs* a);
+int skr_count_generic_dev(skr_ctx* ctx, const skr_aseqs* a, const char* alphabet, int alen, int k, int log2_pre,
+                          skr_mat* out);
 
 /* ---------------------------------------------------------------- normalisation (K4+K5) - */
 /* Sequential float32 column sums in row order, continuing from `acc` (1 x cols, SKR_F32):
@@ -295,6 +307,11 @@ int skr_edges(skr_ctx* ctx, const skr_mat* r, int64_t nrows, int64_t col_begin, 
 int skr_pearson_gemm_edges(skr_ctx* ctx, const skr_operand* a, const skr_operand* b, skr_mat* scratch, int64_t row_global0,
                            int64_t col_global0, float cutoff, int upper_only, skr_mat* out_rows, skr_mat* out_cols,
                            skr_mat* out_vals, int64_t* count);
+
+/* *needs = 1 when skr_pearson_gemm_edges(a, b, ...) must be given a scratch block, i.e. when the rows span more than
+ * one accumulator restart of the contraction — the library's own rule (4 096 columns; 2 048 for operands flagged by
+ * skr_operand_coherent; the A/B knob SEEKR_GEMM_CHUNK_TILES as the ctx read it), so that a caller never re-derives it.   */
+int skr_pearson_gemm_edges_needs_scratch(skr_ctx* ctx, const skr_operand* a, const skr_operand* b, int* needs);
 /* Per-row top-k of the block r[0:nrows, col_begin:col_end]: out_idx[i, t] / out_val[i, t] = global
  * column and value of the t-th largest cell of row i (descending, ties to the smaller column,
  * NaN last: np.argsort(-row, kind="stable")[:k]), the row's own diagonal cell (global column ==

@@ -36,6 +36,7 @@ SIGNATURES = {
     "skr_ctx_create": (_int, [_int, C.POINTER(_p)]),
     "skr_ctx_destroy": (_int, [_p]),
     "skr_ctx_sync": (_int, [_p]),
+    "skr_ctx_mem_info": (_int, [_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "skr_ctx_device": (_int, [_p, C.POINTER(_int)]),
     "skr_ctx_reload_knobs": (_int, [_p]),
     "skr_prof_enable": (_int, [_p, _int]),
@@ -76,6 +77,9 @@ SIGNATURES = {
     "skr_pearson_gemm": (_int, [_p, _p, _p, _int, _int, _p, _i64, _i64]),
     "skr_pearson": (_int, [_p, _p, _p, _int, _int, _p]),
     "skr_count_generic": (_int, [_p, _p, _p, _i64, C.c_char_p, _int, _int, _int, _p]),
+    "skr_aseqs_create": (_int, [_p, _p, _p, _i64, C.POINTER(_p)]),
+    "skr_aseqs_free": (_int, [_p]),
+    "skr_count_generic_dev": (_int, [_p, _p, C.c_char_p, _int, _int, _int, _p]),
     "skr_host_get_counts": (_int, [_p, _p, _int, _int, _int, _p, _int, _int, _p, _int, _p, _p, _p, C.POINTER(_int)]),
     "skr_host_pearson": (_int, [_p, _p, _i64, _p, _i64, _i64, _int, _int, _int, _p]),
     "skr_operand_create": (_int, [_p, _i64, _i64, _int, C.POINTER(_p)]),
@@ -95,6 +99,7 @@ SIGNATURES = {
     "skr_parametric_pvalues": (_int, [_p, _p, C.c_char_p, C.POINTER(C.c_double), _int, _p]),
     "skr_edges": (_int, [_p, _p, _i64, _i64, _i64, _i64, _i64, C.c_float, _int, _p, _p, _p, C.POINTER(_i64)]),
     "skr_pearson_gemm_edges": (_int, [_p, _p, _p, _p, _i64, _i64, C.c_float, _int, _p, _p, _p, C.POINTER(_i64)]),
+    "skr_pearson_gemm_edges_needs_scratch": (_int, [_p, _p, _p, C.POINTER(_int)]),
     "skr_topk_rows": (_int, [_p, _p, _i64, _i64, _i64, _i64, _i64, _int, _p, _p]),
     "skr_mat_save_npy": (_int, [_p, _p, _int, C.c_char_p]),
     "skr_mat_save_csv": (_int, [_p, _p, _int, _int, C.c_char_p]),
@@ -213,6 +218,12 @@ class Context:
 
     def sync(self):
         check(lib().skr_ctx_sync(self._h))
+
+    def mem_info(self):
+        """(free, total) bytes of device memory."""
+        f, t = C.c_uint64(0), C.c_uint64(0)
+        check(lib().skr_ctx_mem_info(self._h, C.byref(f), C.byref(t)))
+        return f.value, t.value
 
     def reload_knobs(self):
         """Re-read the SEEKR_GEMM_* / SEEKR_COUNT_* A/B switches from os.environ (they are otherwise read once, at creation)."""
@@ -501,6 +512,38 @@ def count_generic(ctx, seqs, alphabet, k, dtype=np.float32, log2_pre=False):
     out = ctx.empty(len(seqs), len(alpha) ** k, dtype)
     check(lib().skr_count_generic(ctx._h, C.cast(C.c_char_p(blob), _p), offsets.ctypes.data_as(_p), len(seqs), alpha,
                                   len(alpha), int(k), 1 if log2_pre else 0, out._h))
+    return out
+
+
+class AsciiSeqs:
+    """ASCII sequences resident on the device (skr_aseqs): count_generic_dev counts from them any number of times."""
+
+    def __init__(self, ctx, blob, offsets):
+        self.ctx = ctx
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        self.n = len(offsets) - 1
+        self.total_bases = int(offsets[-1] - offsets[0]) if self.n > 0 else 0
+        self._h = _p()
+        buf = blob if isinstance(blob, (bytes, bytearray)) else np.ascontiguousarray(blob, dtype=np.uint8).tobytes()
+        check(lib().skr_aseqs_create(ctx._h, C.cast(C.c_char_p(bytes(buf)), _p), offsets.ctypes.data_as(_p), self.n, C.byref(self._h)))
+
+    def free(self):
+        if getattr(self, "_h", None) and not _shutdown and getattr(self.ctx, "_h", None):
+            lib().skr_aseqs_free(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def count_generic_dev(ctx, aseqs, alphabet, k, dtype=np.float32, log2_pre=False, out=None):
+    """count_generic from resident sequences (AsciiSeqs); `out`: an existing [n, len(alphabet)^k] matrix to fill."""
+    alpha = alphabet.encode("latin-1", "replace")
+    out = ctx.empty(aseqs.n, len(alpha) ** k, dtype) if out is None else out
+    check(lib().skr_count_generic_dev(ctx._h, aseqs._h, alpha, len(alpha), int(k), 1 if log2_pre else 0, out._h))
     return out
 
 

@@ -137,9 +137,11 @@ class FusedEdges:
         buffers start at 2e-3 entries per cell; a block with more edges is run again with room (retry=True) or reported
         as None (retry=False: the caller has a cheaper way for lists that dense)."""
         ctx = self.ctx
-        # columns per accumulator restart of the contraction (skr_gemm_chunk_tiles; the A/B knob moves it)
-        chunk_cols = 32 * (int(os.environ.get("SEEKR_GEMM_CHUNK_TILES", "0") or 0) or (64 if (a.coherent or b.coherent) else 128))
-        if a.cols > chunk_cols and scratch is None:
+        # more than one accumulator restart per row?  the library's own rule, knob included (ADVICE r3: not re-derived here)
+        needs = C.c_int(0)
+        _lib.check(_lib.lib().skr_pearson_gemm_edges_needs_scratch(ctx._h, a._h, b._h, C.byref(needs)))
+        needs = bool(needs.value)
+        if needs and scratch is None:
             if self._scratch is None or self._scratch.rows < a.rows or self._scratch.cols < b.rows:
                 if self._scratch is not None:
                     self._scratch.free()
@@ -149,7 +151,7 @@ class FusedEdges:
         while True:
             o_r, o_c, o_v = self._buffers()
             count = C.c_int64(0)
-            _lib.check(_lib.lib().skr_pearson_gemm_edges(ctx._h, a._h, b._h, _lib._h(scratch) if a.cols > chunk_cols else None,
+            _lib.check(_lib.lib().skr_pearson_gemm_edges(ctx._h, a._h, b._h, _lib._h(scratch) if needs else None,
                                                          int(row_global0), int(col_global0), C.c_float(cutoff),
                                                          1 if upper_only else 0, o_r._h, o_c._h, o_v._h, C.byref(count)))
             n = count.value

@@ -237,7 +237,11 @@ __device__ __forceinline__ void lds_add_u32(uint32_t* lds_base, uint32_t byte_ad
                                  __HIP_MEMORY_SCOPE_WORKGROUP);  // result unused: ds_add_u32
 }
 
-template <int OUT, int WPS, bool TILES>
+// FLUSH (A/B, tools/count_bench.py): 0 = a lane step stores the lo piece (bins w4..w4+3) and the hi piece (the same words'
+// upper halves, 2 * 4^k bytes further on) back to back — two interleaved 1-KiB streams per row; 1 = the row strictly in
+// ascending address order: the hi pieces wait in registers (at most 8 steps x 4) until the lo half of the row is out;
+// 2 = as 1 with ordinary instead of nontemporal stores.
+template <int OUT, int WPS, bool TILES, int FLUSH = 0>
 __global__ __launch_bounds__(WPS * 64) void count_rows_kernel(const CountArgs a) {
     constexpr int T = WPS * 64;
     constexpr int P = WPS == 1 ? 2 : 1;  // sweeps of packed words prefetched one item ahead (2 048 / 4 096 bases)
@@ -389,6 +393,36 @@ __global__ __launch_bounds__(WPS * 64) void count_rows_kernel(const CountArgs a)
             const size_t row = (size_t)(TILES ? it : seq) * nbins;
             typedef float f4 __attribute__((ext_vector_type(4)));
             typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+            if (FLUSH != 0 && (OUT == OUT_F32 || OUT == OUT_F32_LOG2) && nwords >= 4 && nwords <= (uint32_t)T * 32) {
+                f4 parked[8];
+                float* rowp = reinterpret_cast<float*>(a.out) + row;
+#pragma unroll
+                for (int s8 = 0; s8 < 8; s8++) {
+                    const uint32_t w4 = (uint32_t)(s8 * T + tid) * 4;
+                    if (w4 < nwords) {
+                        const uint4 c = *reinterpret_cast<const uint4*>(&hist[w4]);
+                        *reinterpret_cast<uint4*>(&hist[w4]) = make_uint4(0, 0, 0, 0);
+                        f4 lo4;
+                        if (((c.x | c.y | c.z | c.w) & 0xFFF0FFF0u) == 0) {  // all eight counts below 16: table
+                            lo4 = f4{tab[c.x & 15u], tab[c.y & 15u], tab[c.z & 15u], tab[c.w & 15u]};
+                            parked[s8] = f4{tab[c.x >> 16], tab[c.y >> 16], tab[c.z >> 16], tab[c.w >> 16]};
+                        } else {
+                            lo4 = f4{value_of(c.x & 0xFFFFu), value_of(c.y & 0xFFFFu), value_of(c.z & 0xFFFFu), value_of(c.w & 0xFFFFu)};
+                            parked[s8] = f4{value_of(c.x >> 16), value_of(c.y >> 16), value_of(c.z >> 16), value_of(c.w >> 16)};
+                        }
+                        if (FLUSH == 2) *reinterpret_cast<f4*>(rowp + w4) = lo4;
+                        else __builtin_nontemporal_store(lo4, reinterpret_cast<f4*>(rowp + w4));
+                    }
+                }
+#pragma unroll
+                for (int s8 = 0; s8 < 8; s8++) {
+                    const uint32_t w4 = (uint32_t)(s8 * T + tid) * 4;
+                    if (w4 < nwords) {
+                        if (FLUSH == 2) *reinterpret_cast<f4*>(rowp + nwords + w4) = parked[s8];
+                        else __builtin_nontemporal_store(parked[s8], reinterpret_cast<f4*>(rowp + nwords + w4));
+                    }
+                }
+            } else
             for (uint32_t w4 = tid * 4; w4 < nwords; w4 += T * 4) {
                 const uint4 c = *reinterpret_cast<const uint4*>(&hist[w4]);
                 *reinterpret_cast<uint4*>(&hist[w4]) = make_uint4(0, 0, 0, 0);
@@ -506,7 +540,11 @@ int launch_rows(skr_ctx* ctx, const skr_seqs* s, int k, void* out) {
     };
     CountArgs a{s->d_packed, s->d_word_off, s->d_len, s->d_mask, s->d_mask_off, nullptr, nullptr, s->n, out, k};
     unsigned grid = 1;
-    auto kern = count_rows_kernel<OUT, WPS, false>;
+    void (*kern)(const CountArgs) = count_rows_kernel<OUT, WPS, false>;
+    if constexpr (OUT == OUT_F32 || OUT == OUT_F32_LOG2) {
+        if (ctx->knobs.count_flush == 1) kern = count_rows_kernel<OUT, WPS, false, 1>;  // A/B knob
+        if (ctx->knobs.count_flush == 2) kern = count_rows_kernel<OUT, WPS, false, 2>;
+    }
     SKR_TRY(grid_for_kernel(reinterpret_cast<const void*>(kern), WPS * 64, s->n, &grid));
     // One wave per sequence (k <= 6): NOT persistent — one workgroup per sequence, dispatched by the hardware in order, as
     // many resident as the LDS allows (19 per CU at k = 6).  The rows being written then form a compact front that
@@ -516,7 +554,12 @@ int launch_rows(skr_ctx* ctx, const skr_seqs* s, int k, void* out) {
     // k = 5: 0.100 vs 0.108.  Four waves per sequence (k = 7) measure the same either way and stay persistent.
     const bool persistent = WPS > 1 || ctx->knobs.count_persist;  // A/B knob
     if (!persistent) grid = (unsigned)std::min<int64_t>(s->n, 0x7fffffff);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WPS * 64), lds, ctx->stream, a);
+    size_t lds_launch = lds;
+    if (!persistent && ctx->knobs.count_occ > 0) {  // A/B knob: at most this many one-wave workgroups (= row streams) per CU
+        lds_launch = std::max(lds, ((size_t)160 * 1024 / (size_t)ctx->knobs.count_occ) & ~(size_t)255);
+        SKR_TRY(skr_kernel_lds(ctx, reinterpret_cast<const void*>(kern), lds_launch));
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WPS * 64), lds_launch, ctx->stream, a);
     SKR_HIP(hipGetLastError());
     if (s->max_len - k + 1 <= kItemWindows) return SKR_OK;
 
@@ -589,7 +632,10 @@ int launch_rows(skr_ctx* ctx, const skr_seqs* s, int k, void* out) {
 
 template <int OUT>
 int launch_count(skr_ctx* ctx, const skr_seqs* s, int k, void* out, const char* name) {
-    if (k > 7) {  // histogram in the output row itself
+    // k = 8 on the LDS path (round 4): 65 536 sixteen-bit bins packed two to a word are 128 KiB — one 4-wave workgroup per
+    // CU — and an item never has more than 8 192 windows; SEEKR_COUNT_K8_GLOBAL=1 keeps the round-1 path for the A/B
+    const bool lds_k8 = k == 8 && OUT != OUT_F64 && !ctx->knobs.count_k8_global;
+    if (k > 7 && !lds_k8) {  // histogram in the output row itself
         if (s->n < 1) return SKR_OK;
         SKR_HIP(hipMemsetAsync(out, 0, (size_t)s->n * ((size_t)4 << (2 * k)), ctx->stream));
         const int64_t grid = std::min<int64_t>(s->n, (int64_t)ctx->num_cu * 8);
@@ -603,7 +649,7 @@ int launch_count(skr_ctx* ctx, const skr_seqs* s, int k, void* out, const char* 
     const bool legacy = ctx->knobs.count_legacy && s->max_len - k + 1 <= 65535;  // A/B knob (tools/count_bench.py): the round-1 kernel
     if (OUT != OUT_F64 && !legacy) {
         SkrProfScope prof(ctx, name);
-        // k <= 6: one wave per sequence (8 KiB of bins at k = 6); k = 7: 32 KiB of bins shared by four waves
+        // k <= 6: one wave per sequence (8 KiB of bins at k = 6); k = 7 / 8: 32 / 128 KiB of bins shared by four waves
         const int wps = ctx->knobs.count_wps ? ctx->knobs.count_wps : (k <= 6 ? 1 : 4);  // A/B knob
         constexpr int O = OUT == OUT_F64 ? OUT_F32 : OUT;  // (never instantiated for float64)
         return wps == 1 ? launch_rows<O, 1>(ctx, s, k, out) : launch_rows<O, 4>(ctx, s, k, out);
@@ -689,76 +735,224 @@ __global__ __launch_bounds__(kThreads) void convert_generic_kernel(const uint32_
     }
 }
 
+
+// ---- round 4: A^k <= 16 384 columns (5 letters up to k = 6, 20 amino acids up to k = 3) count in the LDS -------------
+// One 256-thread workgroup per sequence, persistent grid.  The sequence goes through the LDS in chunks of kGenChunk
+// characters, translated to letter codes ONCE per character (lookup table in the LDS; -1 = not in the alphabet) instead
+// of k times per window; a thread takes every 256th window of the chunk, builds its column from k code bytes and adds
+// to a uint32 bin (ds_add_u32; uint32, so a sequence of any length is one item).  The flush converts with the reference's
+// per-kb arithmetic (16-entry table per sequence, per_kb_value above), zeroes the bins and streams the row out with
+// nontemporal stores — coalesced dwords: rows of A^k floats are 4- but not 16-byte aligned.  Against the round-1 form
+// (memset of a uint32 histogram in HBM + L2 atomics + a conversion pass: >= 3 x the row bytes, plus the upload inside the
+// call) the device traffic is the row write alone: 1 + 4 A^k / L bytes per base (SURVEY 8d's ASCII figure).
+constexpr int kGenChunk = 4096;
+constexpr int64_t kGenLdsBins = 16384;
+
+template <typename OutT, bool LOG2>
+__global__ __launch_bounds__(kThreads) void count_generic_lds_kernel(const unsigned char* __restrict__ bases,
+                                                                     const int64_t* __restrict__ offsets, int64_t n_seqs, int k,
+                                                                     int alen, uint32_t nbins, GenericLut lut,
+                                                                     OutT* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t glds[];
+    const uint32_t bins_pad = (nbins + 3u) & ~3u;
+    uint32_t* bins = glds;                                                // [bins_pad]
+    float* tab = reinterpret_cast<float*>(glds + bins_pad);               // [16]
+    int8_t* lutb = reinterpret_cast<int8_t*>(glds + bins_pad + kTabSize);  // [256]
+    int8_t* codes = lutb + 256;                                           // [kGenChunk + 64]
+    const int tid = threadIdx.x;
+    for (uint32_t b = tid; b < bins_pad; b += kThreads) bins[b] = 0;
+    lutb[tid] = lut.code[tid];
+    __syncthreads();
+    for (int64_t s = blockIdx.x; s < n_seqs; s += gridDim.x) {
+        const unsigned char* seq = bases + offsets[s];
+        const int64_t len = offsets[s + 1] - offsets[s];
+        const int64_t W = len - k + 1;  // windows, counting every character (kmer_counts.py:143-144)
+        const double inc = W > 0 ? 1000.0 / (double)W : 0.0;
+        if (!std::is_same<OutT, uint32_t>::value && sizeof(OutT) == 4 && tid < kTabSize) {
+            float t = per_kb_value((uint32_t)tid, inc);
+            if (LOG2) t = skr_log2_cr(t + 1.0f);
+            tab[tid] = t;
+        }
+        for (int64_t c0 = 0; c0 < W; c0 += kGenChunk) {
+            const int64_t n_char = std::min<int64_t>(len - c0, kGenChunk + k - 1);
+            for (int64_t i = tid; i < n_char; i += kThreads) codes[i] = lutb[seq[c0 + i]];
+            __syncthreads();
+            const int64_t n_win = std::min<int64_t>(W - c0, kGenChunk);
+            for (int64_t w = tid; w < n_win; w += kThreads) {
+                uint32_t idx = 0;
+                int bad = 0;
+                for (int p = 0; p < k; p++) {
+                    const int c = codes[w + p];
+                    bad |= c;  // the sign bit survives: any letter outside the alphabet
+                    idx = idx * (uint32_t)alen + (uint32_t)(c & 127);
+                }
+                if (bad >= 0) (void)__hip_atomic_fetch_add(&bins[idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            __syncthreads();
+        }
+        OutT* row = out + (size_t)s * nbins;
+        for (uint32_t b = tid; b < nbins; b += kThreads) {
+            const uint32_t n = bins[b];
+            bins[b] = 0;
+            if (std::is_same<OutT, uint32_t>::value) {
+                __builtin_nontemporal_store((OutT)n, row + b);
+            } else if (sizeof(OutT) == 8) {
+                __builtin_nontemporal_store((OutT)per_kb_value_f64(n, inc), row + b);
+            } else {
+                float t;
+                if (n < (uint32_t)kTabSize) {
+                    t = tab[n];
+                } else {
+                    t = per_kb_value(n, inc);
+                    if (LOG2) t = skr_log2_cr(t + 1.0f);
+                }
+                __builtin_nontemporal_store((OutT)t, row + b);
+            }
+        }
+        __syncthreads();  // zeroed bins and the table are settled before the next sequence
+    }
+}
+
 }  // namespace
 
-extern "C" int skr_count_generic(skr_ctx* ctx, const char* bases, const int64_t* offsets, int64_t n, const char* alphabet,
-                                 int alen, int k, int log2_pre, skr_mat* out) {
-    SKR_REQUIRE(ctx && alphabet && out && out->ctx == ctx, "NULL or foreign argument");
+// ASCII sequences resident on the device (any alphabet): what skr_count_generic_dev counts from, any number of times.
+struct skr_aseqs {
+    skr_ctx* ctx = nullptr;
+    int64_t n = 0;
+    size_t total = 0;
+    unsigned char* d_bases = nullptr;
+    int64_t* d_off = nullptr;  // [n + 1], relative to d_bases
+    std::vector<int64_t> h_len;
+};
+
+extern "C" int skr_aseqs_create(skr_ctx* ctx, const char* bases, const int64_t* offsets, int64_t n, skr_aseqs** out) {
+    SKR_REQUIRE(ctx && out, "NULL argument");
+    *out = nullptr;
     SKR_REQUIRE(n >= 0 && (n == 0 || offsets), "bad sequence count / offsets");
+    for (int64_t i = 0; i < n; i++) SKR_REQUIRE(offsets[i + 1] >= offsets[i], "offsets must be non-decreasing (at %lld)", (long long)i);
+    SKR_REQUIRE(n == 0 || bases || offsets[n] == offsets[0], "bases is NULL");
+    SKR_TRY(skr_activate(ctx));
+    skr_aseqs* a = new skr_aseqs();
+    a->ctx = ctx;
+    a->n = n;
+    a->total = n ? (size_t)(offsets[n] - offsets[0]) : 0;
+    a->h_len.resize((size_t)n);
+    std::vector<int64_t> rel((size_t)n + 1, 0);
+    for (int64_t i = 0; i < n; i++) {
+        a->h_len[(size_t)i] = offsets[i + 1] - offsets[i];
+        rel[(size_t)i + 1] = offsets[i + 1] - offsets[0];
+    }
+    hipError_t e = hipMalloc((void**)&a->d_bases, std::max<size_t>(a->total, 1));
+    if (e == hipSuccess) e = hipMalloc((void**)&a->d_off, (size_t)(n + 1) * sizeof(int64_t));
+    if (e == hipSuccess && a->total) e = hipMemcpyAsync(a->d_bases, bases + offsets[0], a->total, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(a->d_off, rel.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // `rel` and the caller's buffers may go
+    if (e != hipSuccess) {
+        if (a->d_bases) (void)hipFree(a->d_bases);
+        if (a->d_off) (void)hipFree(a->d_off);
+        delete a;
+        return skr_set_error(e == hipErrorOutOfMemory ? SKR_ERR_NOMEM : SKR_ERR_HIP, "uploading %lld ASCII sequences: %s", (long long)n,
+                             hipGetErrorString(e));
+    }
+    *out = a;
+    return SKR_OK;
+}
+
+extern "C" int skr_aseqs_free(skr_aseqs* a) {
+    if (!a) return SKR_OK;
+    (void)skr_activate(a->ctx);
+    (void)hipStreamSynchronize(a->ctx->stream);
+    if (a->d_bases) (void)hipFree(a->d_bases);
+    if (a->d_off) (void)hipFree(a->d_off);
+    delete a;
+    return SKR_OK;
+}
+
+extern "C" int skr_count_generic_dev(skr_ctx* ctx, const skr_aseqs* a, const char* alphabet, int alen, int k, int log2_pre,
+                                     skr_mat* out) {
+    SKR_REQUIRE(ctx && a && alphabet && out && out->ctx == ctx && a->ctx == ctx, "NULL or foreign argument");
     SKR_REQUIRE(alen >= 1 && alen <= 127 && k >= 1, "alphabet of 1..127 letters and k >= 1 expected");
     double bins_d = 1.0;
     for (int p = 0; p < k; p++) bins_d *= alen;
     if (bins_d > (double)(1 << 26))
         return skr_set_error(SKR_ERR_UNSUPPORTED, "%d^%d columns: rows are supported up to 2^26 columns", alen, k);
-    const int64_t nbins = (int64_t)bins_d;
+    const int64_t nbins = (int64_t)bins_d, n = a->n;
     SKR_REQUIRE(out->rows == n && out->cols == nbins, "output must be [%lld, %lld], got [%lld, %lld]", (long long)n,
                 (long long)nbins, (long long)out->rows, (long long)out->cols);
     SKR_REQUIRE(!(log2_pre && out->dtype != SKR_F32), "log2_pre is implemented for SKR_F32 output only");
     if (n == 0) return SKR_OK;
-    SKR_REQUIRE(bases || offsets[n] == offsets[0], "bases is NULL");
-    for (int64_t i = 0; i < n; i++) {
-        SKR_REQUIRE(offsets[i + 1] >= offsets[i], "offsets must be non-decreasing (at %lld)", (long long)i);
-        if (out->dtype != SKR_U32 && offsets[i + 1] - offsets[i] == k - 1)  // kmer_counts.py:144
-            return skr_set_error(SKR_ERR_ZERODIV, "division by zero (a sequence has length k-1 = %d)", k - 1);
-    }
+    if (out->dtype != SKR_U32)
+        for (int64_t L : a->h_len)
+            if (L == k - 1)  // kmer_counts.py:144
+                return skr_set_error(SKR_ERR_ZERODIV, "division by zero (a sequence has length k-1 = %d)", k - 1);
     GenericLut lut;
     memset(lut.code, -1, sizeof(lut.code));
     // a repeated letter keeps its LAST position, as the reference's dict {kmer: index} does (:122)
     for (int c = 0; c < alen; c++) lut.code[(unsigned char)alphabet[c]] = (int8_t)c;
     SKR_TRY(skr_activate(ctx));
-    const size_t total = (size_t)(offsets[n] - offsets[0]);
-    unsigned char* d_bases = nullptr;
-    int64_t* d_off = nullptr;
+    if (nbins <= kGenLdsBins && k <= 64 && !ctx->knobs.count_generic_global) {
+        // the histogram fits the LDS: one pass, the row write is the only traffic (kernel comment above)
+        const size_t lds = (size_t)((nbins + 3) & ~(int64_t)3) * 4 + kTabSize * 4 + 256 + kGenChunk + 64;
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, ((size_t)160 * 1024) / lds));
+        const unsigned grid = (unsigned)std::min<int64_t>(n, (int64_t)ctx->num_cu * per_cu);
+        SkrProfScope prof(ctx, "count_generic");
+#define SKR_GEN_LAUNCH(T, LG)                                                                                              \
+    do {                                                                                                                   \
+        auto kern = count_generic_lds_kernel<T, LG>;                                                                       \
+        SKR_TRY(skr_kernel_lds(ctx, reinterpret_cast<const void*>(kern), lds));                                            \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, ctx->stream, a->d_bases, a->d_off, n, k, alen, (uint32_t)nbins, \
+                           lut, (T*)out->data);                                                                            \
+    } while (0)
+        if (out->dtype == SKR_U32) SKR_GEN_LAUNCH(uint32_t, false);
+        else if (out->dtype == SKR_F64) SKR_GEN_LAUNCH(double, false);
+        else if (log2_pre) SKR_GEN_LAUNCH(float, true);
+        else SKR_GEN_LAUNCH(float, false);
+#undef SKR_GEN_LAUNCH
+        SKR_HIP(hipGetLastError());
+        return SKR_OK;
+    }
+    // wider rows: uint32 scratch histogram in HBM, a batch of sequences at a time (L2 atomics), then the conversion pass
     uint32_t* d_hist = nullptr;
     const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(n, ((int64_t)256 << 20) / (nbins * 4)));
-    auto cleanup = [&] {
-        (void)hipStreamSynchronize(ctx->stream);
-        if (d_bases) (void)hipFree(d_bases);
-        if (d_off) (void)hipFree(d_off);
-        if (d_hist) (void)hipFree(d_hist);
-    };
-    hipError_t e = hipMalloc((void**)&d_bases, std::max<size_t>(total, 1));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_off, (size_t)(n + 1) * sizeof(int64_t));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_hist, (size_t)batch * nbins * 4);
-    std::vector<int64_t> rel((size_t)n + 1);
-    for (int64_t i = 0; i <= n; i++) rel[i] = offsets[i] - offsets[0];
-    if (e == hipSuccess && total) e = hipMemcpyAsync(d_bases, bases + offsets[0], total, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_off, rel.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e = hipMalloc((void**)&d_hist, (size_t)batch * nbins * 4);
     for (int64_t s0 = 0; s0 < n && e == hipSuccess; s0 += batch) {
         const int64_t ns = std::min(batch, n - s0);
         e = hipMemsetAsync(d_hist, 0, (size_t)ns * nbins * 4, ctx->stream);
         if (e != hipSuccess) break;
         SkrProfScope prof(ctx, "count_generic");
         hipLaunchKernelGGL(count_generic_kernel, dim3((unsigned)std::min<int64_t>(ns, (int64_t)ctx->num_cu * 8)), dim3(kThreads),
-                           0, ctx->stream, d_bases, d_off, s0, ns, k, alen, nbins, lut, d_hist);
+                           0, ctx->stream, a->d_bases, a->d_off, s0, ns, k, alen, nbins, lut, d_hist);
         const dim3 cgrid((unsigned)std::min<int64_t>((nbins + kThreads - 1) / kThreads, 64), (unsigned)std::min<int64_t>(ns, 4096));
         if (out->dtype == SKR_U32)
-            hipLaunchKernelGGL((convert_generic_kernel<uint32_t, false>), cgrid, dim3(kThreads), 0, ctx->stream, d_hist, d_off, s0,
+            hipLaunchKernelGGL((convert_generic_kernel<uint32_t, false>), cgrid, dim3(kThreads), 0, ctx->stream, d_hist, a->d_off, s0,
                                ns, k, nbins, (uint32_t*)out->data);
         else if (out->dtype == SKR_F64)
-            hipLaunchKernelGGL((convert_generic_kernel<double, false>), cgrid, dim3(kThreads), 0, ctx->stream, d_hist, d_off, s0, ns,
+            hipLaunchKernelGGL((convert_generic_kernel<double, false>), cgrid, dim3(kThreads), 0, ctx->stream, d_hist, a->d_off, s0, ns,
                                k, nbins, (double*)out->data);
         else if (log2_pre)
-            hipLaunchKernelGGL((convert_generic_kernel<float, true>), cgrid, dim3(kThreads), 0, ctx->stream, d_hist, d_off, s0, ns,
+            hipLaunchKernelGGL((convert_generic_kernel<float, true>), cgrid, dim3(kThreads), 0, ctx->stream, d_hist, a->d_off, s0, ns,
                                k, nbins, (float*)out->data);
         else
-            hipLaunchKernelGGL((convert_generic_kernel<float, false>), cgrid, dim3(kThreads), 0, ctx->stream, d_hist, d_off, s0, ns,
+            hipLaunchKernelGGL((convert_generic_kernel<float, false>), cgrid, dim3(kThreads), 0, ctx->stream, d_hist, a->d_off, s0, ns,
                                k, nbins, (float*)out->data);
         e = hipGetLastError();
     }
-    cleanup();
+    (void)hipStreamSynchronize(ctx->stream);
+    if (d_hist) (void)hipFree(d_hist);
     if (e != hipSuccess) return skr_set_error(SKR_ERR_HIP, "generic-alphabet counting failed: %s", hipGetErrorString(e));
     return SKR_OK;
+}
+
+// Host buffers in: upload, count, release (the drop-in API's path: BasicCounter with an alphabet the 2-bit kernels do not
+// cover).  Callers that count the same sequences again keep a skr_aseqs instead.
+extern "C" int skr_count_generic(skr_ctx* ctx, const char* bases, const int64_t* offsets, int64_t n, const char* alphabet,
+                                 int alen, int k, int log2_pre, skr_mat* out) {
+    SKR_REQUIRE(ctx && alphabet && out && out->ctx == ctx, "NULL or foreign argument");
+    skr_aseqs* a = nullptr;
+    SKR_TRY(skr_aseqs_create(ctx, bases, offsets, n, &a));
+    const int rc = skr_count_generic_dev(ctx, a, alphabet, alen, k, log2_pre, out);
+    (void)skr_aseqs_free(a);
+    return rc;
 }
 
 extern "C" int skr_count_u32(skr_ctx* ctx, const skr_seqs* s, int k, skr_mat* out) {

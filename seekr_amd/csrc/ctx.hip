@@ -55,6 +55,10 @@ extern "C" int skr_ctx_reload_knobs(skr_ctx* c) {
     kn.count_persist = env_int("SEEKR_COUNT_PERSIST", 0) != 0;
     kn.count_legacy = env_int("SEEKR_COUNT_LEGACY", 0) != 0;
     kn.count_wps = env_int("SEEKR_COUNT_WPS", 0);
+    kn.count_flush = env_int("SEEKR_COUNT_FLUSH", 0);
+    kn.count_generic_global = env_int("SEEKR_COUNT_GENERIC_GLOBAL", 0) != 0;
+    kn.count_k8_global = env_int("SEEKR_COUNT_K8_GLOBAL", 0) != 0;
+    kn.count_occ = std::max(0, env_int("SEEKR_COUNT_OCC", 0));
     kn.chain_host_wait = env_int("SEEKR_TEST_HOOKS", 0) == 1 && env_int("SEEKR_CHAIN_HOST_WAIT", 0) != 0;
     return SKR_OK;
 }
@@ -116,6 +120,16 @@ extern "C" int skr_ctx_destroy(skr_ctx* ctx) {
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
     delete ctx;
+    return SKR_OK;
+}
+
+extern "C" int skr_ctx_mem_info(skr_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes) {
+    SKR_REQUIRE(ctx && free_bytes && total_bytes, "NULL argument");
+    SKR_TRY(skr_activate(ctx));
+    size_t f = 0, t = 0;
+    SKR_HIP(hipMemGetInfo(&f, &t));
+    *free_bytes = f;
+    *total_bytes = t;
     return SKR_OK;
 }
 

@@ -220,6 +220,12 @@ SortPlan plan_sort(const skr_ctx* ctx, int64_t n) {
 
 }  // namespace
 
+extern "C" int skr_pearson_gemm_edges_needs_scratch(skr_ctx* ctx, const skr_operand* a, const skr_operand* b, int* needs) {
+    SKR_REQUIRE(ctx && a && b && needs, "NULL argument");
+    *needs = a->kind != 0 && a->kt > skr_gemm_chunk_tiles(ctx, a->coherent || b->coherent);
+    return SKR_OK;
+}
+
 extern "C" int skr_pearson_gemm_edges(skr_ctx* ctx, const skr_operand* a, const skr_operand* b, skr_mat* scratch,
                                       int64_t row_global0, int64_t col_global0, float cutoff, int upper_only,
                                       skr_mat* out_rows, skr_mat* out_cols, skr_mat* out_vals, int64_t* count) {

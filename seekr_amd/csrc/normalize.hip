@@ -80,15 +80,21 @@ struct ChainLink {
     uint32_t* err = nullptr;  // set when a wait gave up (a peer died): the host raises instead of the kernel hanging
 };
 
-constexpr long kChainSpinMax = 1L << 25;  // polls of ~1 us each: half a minute
+// The wait is bounded in TIME, not in polls: s_memrealtime counts at 100 MHz whatever the shader clock does, so a wait
+// gives up after kChainWaitTicks = 10 s — long enough for a peer that is still packing its FASTA, short enough that a
+// dead peer is an error and not a hang.  A link that gave up raises `err`; the host folds that flag into the step's
+// verdict all-reduce, so EVERY rank raises together (the sums a timed-out link passes on are garbage).
+constexpr unsigned long long kChainWaitTicks = 1000000000ull;
 __device__ __forceinline__ void chain_wait(const uint32_t* flag, uint32_t epoch, uint32_t* err) {
     // relaxed polls (an acquire per poll would invalidate the caches under the staging waves), one acquire at the end
-    for (long i = 0; i < kChainSpinMax; i++) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
         const uint32_t v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if ((int32_t)(v - epoch) >= 0) {
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
             return;
         }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > kChainWaitTicks) break;
         __builtin_amdgcn_s_sleep(4);
     }
     if (err) atomicOr(err, 1u);

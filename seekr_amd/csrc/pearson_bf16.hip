@@ -255,7 +255,42 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
     if (DIAG) st[2] = __builtin_amdgcn_s_memtime();
     const bool no_dma = DIAG && (diag[1] & 1);  // diagnostic only: k loop without its staging traffic (results meaningless)
     const bool same_tile = DIAG && (diag[1] & 2);  // diagnostic only: every stage re-loads k tile 0 (served by the nearest cache)
-    if constexpr (WAVES == 8) {
+    const bool two_units = DIAG && (diag[1] & 8);  // diagnostic only: TIMING CEILING of a two-product-unit split (results meaningless)
+    if (DIAG && WAVES == 8 && two_units) {
+        // VERDICT r3 #5, measured before anything is built around it: the two cross products (lo x hi, hi x lo: two
+        // 16-bit MFMAs per k tile and accumulator tile) replaced by ONE v_mfma_i32_16x16x64_i8 — the cycles of one 16-bit
+        // MFMA (MI355X_MICROARCH.md: I8 16x16x64 = the cycles of the BF16 form at twice the K) — fed with the bytes of
+        // the lo fragments, into the same accumulator registers.  Same staging, same LDS reads, same register
+        // pressure as an fp8-cross variant would have, 64 instead of 96 MFMA slots per wave and k tile: what the k
+        // loop would cost with 2 instead of 3 product-units per k.
+        typedef int i32x4v __attribute__((ext_vector_type(4)));
+        for (int64_t t = 0; t < kt; t++) {
+            if (t + 1 < kt) stage(cur ^ 1, t + 1);
+            const char* base = smem + cur * kStageBytes;
+            vec8<T> ahi[MT], bhi[NT];
+            i32x4v a8[MT], b8[NT];
+#pragma unroll
+            for (int i = 0; i < NT; i++) {
+                bhi[i] = *reinterpret_cast<const vec8<T>*>(base + b_off[i] + ((q ^ b_swz[i]) << 4));
+                b8[i] = *reinterpret_cast<const i32x4v*>(base + b_off[i] + (((4 + q) ^ b_swz[i]) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MT; i++) {
+                ahi[i] = *reinterpret_cast<const vec8<T>*>(base + a_off[i] + ((q ^ a_swz[i]) << 4));
+                a8[i] = *reinterpret_cast<const i32x4v*>(base + a_off[i] + (((4 + q) ^ a_swz[i]) << 4));
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    i32x4v ci = __builtin_bit_cast(i32x4v, acc[mt][nt]);
+                    ci = __builtin_amdgcn_mfma_i32_16x16x64_i8(a8[mt], b8[nt], ci, 0, 0, 0);
+                    acc[mt][nt] = mfma16x16(ahi[mt], bhi[nt], __builtin_bit_cast(f32x4v, ci));
+                }
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else if constexpr (WAVES == 8) {
         for (int64_t t = 0; t < kt; t++) {
             if (t + 1 < kt && !no_dma) stage(cur ^ 1, same_tile ? 0 : t + 1);
             const char* base = smem + cur * kStageBytes;
@@ -566,9 +601,11 @@ int launch_chunk(skr_ctx* ctx, const T* Ac, const T* Bc, const SplitOut& o, int6
             SKR_TRY(skr_ctx_workspace(ctx, (size_t)(8 + 8 * 65536) * 8, &ws));
             diag = (unsigned long long*)ws;
             SKR_HIP(hipMemsetAsync(diag, 0, 64, ctx->stream));
-            // experiments: 2 = k loop without staging, 3 = every stage re-loads k tile 0, 4 = self mode without the mirror stores
+            // experiments: 2 = k loop without staging, 3 = every stage re-loads k tile 0, 4 = self mode without the mirror
+            // stores, 5 = two product-units per k (one int8 MFMA in place of the two cross products: timing ceiling)
             const int dmode = ctx->diag_mode;
-            if (dmode >= 2 && dmode <= 4) SKR_HIP(hipMemsetAsync(diag + 1, dmode == 2 ? 1 : (dmode == 3 ? 2 : 4), 1, ctx->stream));
+            if (dmode >= 2 && dmode <= 5)
+                SKR_HIP(hipMemsetAsync(diag + 1, dmode == 2 ? 1 : (dmode == 3 ? 2 : (dmode == 4 ? 4 : 8)), 1, ctx->stream));
             kern = pearson_gemm_split16_kernel<T, NPROD, (MODE == SELF ? SELF : PLAIN), true, true>;
         }
 #endif
@@ -697,9 +734,9 @@ extern "C" int skr_gemm_diag_read(skr_ctx* ctx, unsigned long long* out, int64_t
     return SKR_OK;
 }
 
-// 0 = production kernels; 1 = stamps only (r stays valid); 2-4 = timing experiments that make r meaningless (above)
+// 0 = production kernels; 1 = stamps only (r stays valid); 2-5 = timing experiments that make r meaningless (above)
 extern "C" int skr_gemm_diag_mode(skr_ctx* ctx, int mode) {
-    SKR_REQUIRE(ctx && mode >= 0 && mode <= 4, "mode 0..4");
+    SKR_REQUIRE(ctx && mode >= 0 && mode <= 5, "mode 0..5");
     ctx->diag_mode = mode;
     return SKR_OK;
 }

@@ -142,16 +142,17 @@ class RcclComm:
         self._chain_note = ""
 
     def chain_for(self, engine, n_cols):
-        """The peer-mailbox chain for the column sums (skr_chain), set up collectively on first use: every rank exports
-        its mailbox, the 64-byte IPC handles are all-gathered, every rank opens the others', and one small chained pass is
-        checked against the send/recv chain.  Any failure on any rank — IPC refused, a store that never becomes visible
-        (the waits are bounded) — and ALL ranks stay with send/recv.  SEEKR_CHAIN=rccl|mailbox forces the choice; under
-        SEEKR_TEST_HOOKS=1 (several ranks sharing one GPU: a kernel that waits for another process's kernel can keep it
-        from ever being scheduled) the default is rccl."""
+        """The peer-mailbox chain for the column sums (skr_chain), OPT-IN (SEEKR_CHAIN=mailbox; the default is the
+        send/recv chain, `rccl`, until the in-kernel wait has run between two real GPUs: ADVICE r3).  Set up
+        collectively on first use: every rank exports its mailbox, the 64-byte IPC handles are all-gathered, every rank
+        opens the others', and one small chained pass is checked against the send/recv chain.  Any failure on any rank —
+        IPC refused, a store that never becomes visible (the waits are bounded) — and ALL ranks stay with send/recv.
+        Every collective of the set-up (all-gather, the send/recv reference pass, the two verdict all-reduces) is entered
+        by every rank whatever happened to it before: errors are recorded locally and compared at the end."""
         import os
         if self._chain is not None and (self._chain is False or self._chain.cols_cap >= n_cols):
             return self._chain or None
-        want = os.environ.get("SEEKR_CHAIN", "rccl" if os.environ.get("SEEKR_TEST_HOOKS") == "1" else "mailbox")
+        want = os.environ.get("SEEKR_CHAIN", "rccl")
         if self.size < 2 or self.size > 16 or want != "mailbox":
             self._chain, self._chain_note = False, "not requested"
             return None
@@ -176,17 +177,20 @@ class RcclComm:
                 why = "connect: {}".format(e)
         bad = self.allreduce([1.0 if why else 0.0], "max")[0]
         if not bad:
-            # self-test: a small chained pass must equal the same pass over send/recv, bit for bit, on every rank
+            # self-test: a small chained pass must equal the same pass over send/recv, bit for bit, on every rank.  The
+            # send/recv reference runs FIRST and outside the try: it is a collective, and a rank whose chained pass
+            # fails must not leave the others alone in it (that was a hang, not a fallback).
+            rows = 5 + self.rank
+            x = ctx.from_numpy((np.arange(rows * 48, dtype=np.float32).reshape(rows, 48) % 7 + self.rank) * np.float32(0.37))
+            self._chain = False  # the reference pass takes the send/recv path
+            want_vec = _chain_colsum(engine, self, x, 48)
+            ctx.sync()
+            self._chain = None
             try:
-                rows = 5 + self.rank
-                x = ctx.from_numpy((np.arange(rows * 48, dtype=np.float32).reshape(rows, 48) % 7 + self.rank) * np.float32(0.37))
                 got = engine.zeros_vec(48)
                 engine.colsum_chain(chain, x, got)
                 if chain.timed_out():
                     raise _lib.SeekrHipError("a peer's store never became visible")
-                self._chain = False  # the reference pass below must take the send/recv path
-                want_vec = _chain_colsum(engine, self, x, 48)
-                ctx.sync()
                 if not np.array_equal(got.vector().view(np.uint32), want_vec.vector().view(np.uint32)):
                     raise _lib.SeekrHipError("the mailbox chain and the send/recv chain disagree")
             except Exception as e:  # noqa: BLE001
@@ -199,6 +203,11 @@ class RcclComm:
             return None
         self._chain, self._chain_note = chain, "peer mailboxes over HIP IPC"
         return chain
+
+    def chain_gave_up(self):
+        """True when a link of the mailbox chain on THIS rank gave up waiting since the last call (its sums are garbage).
+        Synchronises the stream; _verdicts() all-reduces it so that every rank raises together."""
+        return bool(self._chain) and self._chain.timed_out()
 
     def send_vec(self, v, dst, want_ticket=True):
         """Returns a ticket: the compute stream must wait on it before it overwrites `v`.  want_ticket=False: fire
@@ -332,11 +341,6 @@ def sharded_stats(engine, comm, x, n_total, log2="Log2.post", mean=True, std=Tru
             gmin, neg_flag = comm.allreduce([float(local_min) if not local_nan else float("inf"), -1.0 if local_nan else 0.0], "min")
             local_min = np.float32(np.nan) if neg_flag < 0 else np.float32(gmin)
         shift = float(np.abs(local_min))  # NaN stays NaN (np.abs(np.min(...)), :208)
-        # the minimum came back to the host, i.e. the stream is drained: the moment to ask whether a link of the mailbox
-        # chain gave up waiting for a peer (its waits are bounded; the sums would be garbage) — an error, not a hang
-        chain = getattr(comm, "_chain", None)
-        if chain and chain.timed_out():
-            raise _lib.SeekrHipError("rank {}: the column-sum chain gave up waiting for a peer's mailbox store".format(comm.rank))
     return center, scale, post, shift
 
 
@@ -347,12 +351,21 @@ def _any_rank(comm, flag):
 
 
 def _verdicts(comm, fell_back, coherent, has_nan):
-    """The three per-step verdicts of the normalisation as ONE host all-reduce (a stream drain and a round trip each,
-    were they separate): did any rank's operand fall back to the float32 layout, is any rank's shard 'mostly one repeated
-    value', did any rank see a NaN.  sharded_normalize and sharded_normalize_prepare both end with it, so that ranks may
-    mix the two entry points (tests/dist_worker.py does)."""
+    """The per-step verdicts of the normalisation as ONE host all-reduce (a stream drain and a round trip each, were they
+    separate): did any rank's operand fall back to the float32 layout, is any rank's shard 'mostly one repeated value',
+    did any rank see a NaN — and did a link of the mailbox chain give up waiting on ANY rank (the sums behind
+    such a link are garbage on every later rank, in every log2 mode; all ranks raise together instead of one rank raising
+    and the others hanging in the next collective).  sharded_normalize and sharded_normalize_prepare both end with it, so
+    that ranks may mix the two entry points (tests/dist_worker.py does)."""
     if comm.size > 1:
-        return tuple(v > 0 for v in comm.allreduce([1.0 if fell_back else 0.0, 1.0 if coherent else 0.0, 1.0 if has_nan else 0.0], "max"))
+        gave_up = bool(getattr(comm, "chain_gave_up", lambda: False)())
+        out = comm.allreduce([1.0 if fell_back else 0.0, 1.0 if coherent else 0.0, 1.0 if has_nan else 0.0,
+                              1.0 if gave_up else 0.0], "max")
+        if out[3] > 0:
+            raise _lib.SeekrHipError("rank {}: a link of the column-sum chain gave up waiting for a peer's mailbox store "
+                                     "({}): the column statistics of this step are invalid on every rank".format(
+                                         comm.rank, "this rank" if gave_up else "another rank"))
+        return tuple(v > 0 for v in out[:3])
     return bool(fell_back), bool(coherent), bool(has_nan)
 
 

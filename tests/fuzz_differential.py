@@ -62,33 +62,42 @@ def dump_case(seed, n_cases, seqs, tag):
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from strict_tally import StrictTally  # noqa: E402
+import parity_rule  # noqa: E402
 
 TALLY = StrictTally()
 
+def gen_case(r):
+    """One random pipeline case: (seqs, k, alphabet, log2, mean, std, tag)."""
+    global rng
+    rng = r
+    k = int(rng.integers(1, 8))
+    alphabet = "".join(rng.permutation(list("AGTC")))
+    if rng.integers(0, 4) == 0:  # an alphabet the 2-bit path does not cover: the general counting kernel
+        alphabet = str(rng.choice(["ACGTN", "AT", "AGTA", "GCA", "ACGTRYN", "NNA", "T"]))
+        while len(alphabet) ** k > 4096:
+            k -= 1
+    n = int(rng.integers(2, 60))
+    seqs = [random_seq(k) for _ in range(n)]
+    for i in range(1, n):  # mutated copies: pairs with r close to 1, where the bar is relative
+        if rng.integers(0, 4) == 0 and len(seqs[i - 1]) > k + 2:
+            parent = np.array(list(seqs[int(rng.integers(0, i))]))
+            if len(parent) > k + 2:
+                hits = rng.random(len(parent)) < rng.choice([0.0, 0.01, 0.05, 0.2])
+                parent[hits] = LETTERS[rng.integers(0, 4, int(hits.sum()))]
+                seqs[i] = "".join(parent[: int(rng.integers(k + 2, len(parent) + 1))])
+    log2 = str(rng.choice(["Log2.none", "Log2.pre", "Log2.post"]))
+    mean, std = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    tag = dict(k=k, alphabet=alphabet, n=n, log2=log2, mean=mean, std=std)
+    return seqs, k, alphabet, log2, mean, std, tag
+
+
 def fuzz(seed, budget_s=60.0, max_cases=10 ** 9, replay=None):
-  global rng
-  rng = np.random.default_rng(seed)
+  rng_ = np.random.default_rng(seed)
   t0, n_cases = time.time(), 0
   while time.time() - t0 < budget_s and n_cases < max_cases:
    try:
-        k = int(rng.integers(1, 8))
-        alphabet = "".join(rng.permutation(list("AGTC")))
-        if rng.integers(0, 4) == 0:  # an alphabet the 2-bit path does not cover: the general counting kernel
-            alphabet = str(rng.choice(["ACGTN", "AT", "AGTA", "GCA", "ACGTRYN", "NNA", "T"]))
-            while len(alphabet) ** k > 4096:
-                k -= 1
-        n = int(rng.integers(2, 60))
-        seqs = [random_seq(k) for _ in range(n)]
-        for i in range(1, n):  # mutated copies: pairs with r close to 1, where the bar is relative
-            if rng.integers(0, 4) == 0 and len(seqs[i - 1]) > k + 2:
-                parent = np.array(list(seqs[int(rng.integers(0, i))]))
-                if len(parent) > k + 2:
-                    hits = rng.random(len(parent)) < rng.choice([0.0, 0.01, 0.05, 0.2])
-                    parent[hits] = LETTERS[rng.integers(0, 4, int(hits.sum()))]
-                    seqs[i] = "".join(parent[: int(rng.integers(k + 2, len(parent) + 1))])
-        log2 = str(rng.choice(["Log2.none", "Log2.pre", "Log2.post"]))
-        mean, std = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
-        tag = dict(k=k, alphabet=alphabet, n=n, log2=log2, mean=mean, std=std)
+        seqs, k, alphabet, log2, mean, std, tag = gen_case(rng_)
+        n = len(seqs)
         raw = orc.raw_counts(seqs, k, alphabet=alphabet)
         got = run(seqs, k=k, alphabet=alphabet, mean=False, std=False, log2="Log2.none").counts
         assert np.array_equal(bits(got), bits(raw)), ("raw", tag)
@@ -142,23 +151,18 @@ def fuzz(seed, budget_s=60.0, max_cases=10 ** 9, replay=None):
             i, j = np.argwhere(np.isnan(r) != np.isnan(want))[0]
             print("NaN mismatch at", i, j, "ours", r[i, j], "numpy", want[i, j], "\nrow i", ref[i][:24], "\nrow j", ref[j][:24])
         assert np.array_equal(np.isnan(r), np.isnan(want)), ("pearson nan", tag)
-        # Rows of 4 or 16 near-equal values make row standardisation ill-conditioned: the float32 result
-        # then depends on the order of every addition, for numpy as for the device.  The yardstick is
-        # float64: our error may exceed the bar only by a small multiple of the reference's own error on
-        # the same row / column.
+        # Strict against the reference's float32 result; a cell may leave it only where the float32 inner product is
+        # order-sensitive — an input property (tests/parity_rule.py) — and must then be within the bar of float64.
         with np.errstate(all="ignore"):
             truth = orc.pearson_f64_truth(ref, ref)
         ok = ~np.isnan(want) & ~np.isnan(truth)
-        TALLY.add(r, want, truth, ok, tag)
-        e_ref = np.where(ok, np.abs(want - truth), 0.0)
-        e_ours = np.where(ok, np.abs(r - truth), 0.0)
-        slack = 4.0 * np.maximum(e_ref.max(axis=1, keepdims=True), e_ref.max(axis=0, keepdims=True))
-        bad = e_ours > 2e-6 + 1e-5 * np.abs(np.where(ok, truth, 0.0)) + slack
-        if bad.any():
-            i, j = np.unravel_index(np.argmax(np.where(bad, e_ours, 0)), bad.shape)
-            print("worst pair", i, j, "ours", r[i, j], "numpy", want[i, j], "truth", truth[i, j])
+        verdict = parity_rule.judge(r, want, truth, ok, ref, ref)
+        TALLY.add(verdict, tag)
+        if verdict["failures"]:
+            i, j, why, numbers = verdict["failures"][0]
+            print(why, "at", i, j, numbers)
             print("row i", ref[i][:16], "\nrow j", ref[j][:16])
-        assert not bad.any(), ("pearson", tag, float(e_ours[bad].max()), float(e_ref.max()))
+        assert not verdict["failures"], ("pearson", tag, verdict["failures"][:3])
         n_cases += 1
    except AssertionError:
       dump_case(seed, n_cases, seqs, tag)

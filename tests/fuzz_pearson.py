@@ -14,50 +14,58 @@ from seekr_amd.pearson import pearson  # noqa: E402
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from strict_tally import StrictTally  # noqa: E402
+import parity_rule  # noqa: E402
 
 TALLY = StrictTally()
+
+def gen_case(rng):
+    """One random case of the pearson() API: (a, b, row_standardize, tag)."""
+    K = int(rng.choice([1, 2, 3, 4, 5, 16, 31, 32, 33, 64, 100, 255, 256, 257, 625, 729, 1000, 1023, 1024, 1025, 1500, 2048, 3125,
+                        4096, 4100, 16384]))
+    M, N = int(rng.integers(1, 70)), int(rng.integers(1, 70))
+    dt = rng.choice(["f32", "f32", "f32", "f64", "i64"])
+    same = bool(rng.integers(0, 3) == 0)
+    rs = bool(rng.integers(0, 4) != 0)
+    kind = rng.integers(0, 6)
+    def make(rows):
+        if kind == 0:
+            x = rng.standard_normal((rows, K)) * rng.uniform(0.1, 50)
+        elif kind == 1:
+            x = rng.binomial(20, 0.2, size=(rows, K)).astype(np.float64) * 1.5
+        elif kind == 2:
+            x = np.abs(rng.standard_normal((rows, K))) ** 3
+        elif kind == 3:
+            x = rng.standard_normal((rows, K)); x[rng.integers(0, rows)] = 3.25  # a constant row
+        elif kind == 4:
+            # count-like and sparse: one-hot rows (homopolymers), a few hot columns, and rows repeated
+            # exactly or scaled — pairs with r = 1 whose products are dominated by one column
+            x = np.zeros((rows, K))
+            for i in range(rows):
+                hot = rng.integers(0, K, size=int(rng.choice([1, 1, 2, 3, 8])))
+                x[i, hot] = rng.uniform(1, 12, size=len(hot))
+                if rng.integers(0, 3) == 0:
+                    x[i] += rng.binomial(3, 0.1, K) * 0.5
+            for i in range(1, rows):
+                if rng.integers(0, 4) == 0:
+                    x[i] = x[rng.integers(0, i)] * rng.choice([1.0, 2.0, 0.37])
+        else:
+            base = rng.standard_normal((1, K)) * 3
+            x = base + rng.standard_normal((rows, K)) * rng.choice([1e-3, 1e-2, 0.3])  # near-duplicates: r ~ 1
+        if dt == "i64":
+            return np.rint(x * 4).astype(np.int64)
+        return x.astype(np.float32 if dt == "f32" else np.float64)
+    a = make(M)
+    b = a if same else make(N)
+    tag = dict(K=K, M=a.shape[0], N=b.shape[0], dt=str(dt), same=same, rs=rs, kind=int(kind))
+    return a, b, rs, tag
+
 
 def fuzz(seed, budget_s=60.0, max_cases=10 ** 9):
     rng = np.random.default_rng(seed)
     t0, n_cases = time.time(), 0
     while time.time() - t0 < budget_s and n_cases < max_cases:
-        K = int(rng.choice([1, 2, 3, 4, 5, 16, 31, 32, 33, 64, 100, 255, 256, 257, 625, 729, 1000, 1023, 1024, 1025, 1500, 2048, 3125,
-                            4096, 4100, 16384]))
-        M, N = int(rng.integers(1, 70)), int(rng.integers(1, 70))
-        dt = rng.choice(["f32", "f32", "f32", "f64", "i64"])
-        same = bool(rng.integers(0, 3) == 0)
-        rs = bool(rng.integers(0, 4) != 0)
-        kind = rng.integers(0, 6)
-        def make(rows):
-            if kind == 0:
-                x = rng.standard_normal((rows, K)) * rng.uniform(0.1, 50)
-            elif kind == 1:
-                x = rng.binomial(20, 0.2, size=(rows, K)).astype(np.float64) * 1.5
-            elif kind == 2:
-                x = np.abs(rng.standard_normal((rows, K))) ** 3
-            elif kind == 3:
-                x = rng.standard_normal((rows, K)); x[rng.integers(0, rows)] = 3.25  # a constant row
-            elif kind == 4:
-                # count-like and sparse: one-hot rows (homopolymers), a few hot columns, and rows repeated
-                # exactly or scaled — pairs with r = 1 whose products are dominated by one column
-                x = np.zeros((rows, K))
-                for i in range(rows):
-                    hot = rng.integers(0, K, size=int(rng.choice([1, 1, 2, 3, 8])))
-                    x[i, hot] = rng.uniform(1, 12, size=len(hot))
-                    if rng.integers(0, 3) == 0:
-                        x[i] += rng.binomial(3, 0.1, K) * 0.5
-                for i in range(1, rows):
-                    if rng.integers(0, 4) == 0:
-                        x[i] = x[rng.integers(0, i)] * rng.choice([1.0, 2.0, 0.37])
-            else:
-                base = rng.standard_normal((1, K)) * 3
-                x = base + rng.standard_normal((rows, K)) * rng.choice([1e-3, 1e-2, 0.3])  # near-duplicates: r ~ 1
-            if dt == "i64":
-                return np.rint(x * 4).astype(np.int64)
-            return x.astype(np.float32 if dt == "f32" else np.float64)
-        a = make(M)
-        b = a if same else make(N)
-        tag = dict(K=K, M=a.shape[0], N=b.shape[0], dt=str(dt), same=same, rs=rs, kind=int(kind))
+        a, b, rs, tag = gen_case(rng)
+        same = tag["same"]
         try:
             with np.errstate(all="ignore"):
                 want = orc.pearson(a, b, rs)
@@ -75,18 +83,22 @@ def fuzz(seed, budget_s=60.0, max_cases=10 ** 9):
             live = ~bad_rows(a)[:, None] & ~bad_rows(b)[None, :]
             assert not np.isnan(g[live]).any() or np.isnan(w[live]).any(), ("unexpected NaN", tag)
             ok = live & ~np.isnan(w) & ~np.isnan(truth)
-            e_ref = np.where(ok, np.abs(w - truth), 0.0)
             e_ours = np.where(ok, np.abs(g - truth), 0.0)
             scale = np.maximum(np.abs(np.where(ok, truth, 0.0)), 1e-300)
-            if got.dtype == np.float32 and rs:
-                TALLY.add(g, w, truth, ok, tag)
             if got.dtype == np.float64:
-                limit = 1e-12 * np.maximum(scale, 1.0) + 8 * e_ref.max()
+                # float64 inputs: oracle.pearson IS the float64 evaluation; only the summation order differs
+                limit = 1e-12 * np.maximum(scale, 1.0)
+                bad = e_ours > limit
+                assert not bad.any(), ("value", tag, float(e_ours[bad].max()))
             else:
-                slack = 4.0 * np.maximum(e_ref.max(axis=1, keepdims=True), e_ref.max(axis=0, keepdims=True))
-                limit = (2e-6 + 1e-5 * scale) * (np.maximum(scale.max(), 1.0) if not rs else 1.0) + slack
-            bad = e_ours > limit
-            assert not bad.any(), ("value", tag, float(e_ours[bad].max()), float(e_ref.max()))
+                # float32: strict against the reference's float32 result; a cell may leave it only where the float32
+                # inner product is order-sensitive (an input property, tests/parity_rule.py), and must then be within
+                # the bar of float64.  Without row standardisation r scales with the operands: so does the bar.
+                unit = 1.0 if rs else float(np.maximum(scale.max(), 1.0))
+                verdict = parity_rule.judge(g, w, truth, ok, a, b, row_standardize=rs, unit=unit)
+                if rs:
+                    TALLY.add(verdict, tag)
+                assert not verdict["failures"], ("value", tag, verdict["failures"][:3])
         except AssertionError:
             d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
             os.makedirs(d, exist_ok=True)

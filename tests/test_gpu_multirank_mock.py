@@ -207,6 +207,45 @@ def test_bench_starts_its_own_rank_processes(mock_lib):
     assert {"comm_xfer", "comm_wait", "comm_vec", "comm_wait_vec"} <= set(out["kernels_ms_per_step"])
 
 
+def _gpu_and_shm_room():
+    """(free HBM in GB, free /dev/shm in GB) — the full-size 8-rank test below needs 8 x 21 GB of HBM and room for
+    the mock transport's message files."""
+    from seekr_amd import _lib
+    ctx = _lib.default_context()
+    free_hbm = ctx.mem_info()[0] / 1e9 if hasattr(ctx, "mem_info") else 0.0
+    st = os.statvfs("/dev/shm")
+    return free_hbm, st.f_bavail * st.f_frsize / 1e9
+
+
+@pytest.mark.parametrize("layout", ["symmetric", "rowblock", "allgather"])
+def test_eight_ranks_at_the_drivers_weak_scaling_size(layout, mock_lib):
+    """VERDICT r3 #3b: `bench.py --gpus 8` exactly at the size the driver's 8-GPU run uses (141 424 rows, 17 678-row
+    shards, r_row + r_col = 20 GB per rank: 160 GB of the 288 on this one GPU), eight rank processes over the mock
+    transport, each of the three layouts: real buffer sizes, ticket recycling and 64-bit offsets through the whole
+    stack; every rank verified against the oracle, all eight seen; the column-sum chain's A/B (send/recv against the
+    peer mailboxes, host-side wait because the ranks share a GPU) runs after the timed region and must agree bit for bit."""
+    import json
+    free_hbm, free_shm = _gpu_and_shm_room()
+    if free_hbm < 200 or free_shm < 24:
+        pytest.skip("needs 200 GB of free HBM and 24 GB of /dev/shm (have %.0f / %.0f)" % (free_hbm, free_shm))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--layout", layout,
+           "--launch-timeout", "900"]
+    env = _launcher_env(mock_lib, SEEKR_BENCH_CHAIN_AB="1", SEEKR_CHAIN_HOST_WAIT="1")
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-6000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert "layout_fallback" not in out, out.get("layout_fallback")
+    assert out["n_gpus"] == 8 and out["n_ranks_seen"] == 8
+    assert out["config"]["rows_total"] == 141424 and out["config"]["rows_per_gpu"] == 17678
+    assert out["verified"] is True and out["verified_detail"]["worst_error_over_bar"] <= 1.0
+    want = {"symmetric": "symmetric half-ring", "rowblock": "row blocks", "allgather": "row blocks after one all-gather"}[layout]
+    assert out["config"]["layout"].startswith(want)
+    ab = out["chain_ab"]
+    assert ab["bit_identical"] is True and "peer mailboxes" in ab["mailbox"]["transport"], ab
+    assert not ab["mailbox"]["a_link_gave_up_waiting"] and ab["rccl"]["transport"] in ("not requested", "send/recv")
+    assert len(out["per_rank"]["gemm_ms"]) == 8 and min(out["per_rank"]["gemm_ms"]) > 0
+
+
 def test_bench_falls_back_to_row_blocks_when_the_selftest_fails(mock_lib):
     """The half-ring self-test fails on rank 1 of 3 (test hook): every rank leaves with the self-test's exit code, and the
     launcher starts a NEW set of rank processes with --layout allgather; the line says so."""

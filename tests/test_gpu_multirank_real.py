@@ -42,6 +42,42 @@ def test_more_ranks_over_real_rccl_equal_single_gpu(size, tmp_path):
 
 
 @needs2
+def test_mailbox_chain_between_two_real_gpus(tmp_path):
+    """the peer-mailbox column-sum chain WITHOUT the host-side wait — rank 1's kernel is resident on its
+    own GPU and polls, inside the kernel, the epoch words rank 0's kernel stores over xGMI into rank 1's uncached mailbox.
+    This is the first place that wait runs against a live peer; statistics must equal the single-GPU run bit for bit
+    and both ranks must report the mailbox transport (a failed set-up or self-test would say why instead)."""
+    import numpy as np
+    from test_gpu_multirank_mock import check_ranks, single_gpu_reference
+    check_ranks(2, 0, None, single_gpu_reference(1101, 600, 6), tmp_path, extra_env={"SEEKR_CHAIN": "mailbox"})
+    notes = [str(np.load(str(tmp_path / ("rank%d.npz" % rank)))["chain_note"]) for rank in range(2)]
+    assert all("peer mailboxes" in n for n in notes), notes
+
+
+@needs4
+def test_mailbox_chain_between_four_real_gpus(tmp_path):
+    import numpy as np
+    from test_gpu_multirank_mock import check_ranks, single_gpu_reference
+    check_ranks(4, 0, None, single_gpu_reference(1101, 600, 6), tmp_path, extra_env={"SEEKR_CHAIN": "mailbox"})
+    notes = [str(np.load(str(tmp_path / ("rank%d.npz" % rank)))["chain_note"]) for rank in range(4)]
+    assert all("peer mailboxes" in n for n in notes), notes
+
+
+@needs2
+def test_bench_reports_the_chain_ab_between_two_real_gpus():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR",
+                                                               "SEEKR_TEST_HOOKS", "SEEKR_RCCL_LIB", "SEEKR_FORCE_DEVICE", "SEEKR_CHAIN")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "12000",
+           "--length", "500"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    ab = out["chain_ab"]  # the launcher's first attempt measures both transports after the timed region
+    assert ab["bit_identical"] is True and ab["rccl"]["ms_per_pass"] > 0 and ab["mailbox"]["ms_per_pass"] > 0
+    assert "peer mailboxes" in ab["mailbox"]["transport"] and not ab["mailbox"]["a_link_gave_up_waiting"], ab
+
+
+@needs2
 def test_k7_over_real_rccl(tmp_path):
     from test_gpu_multirank_mock import check_ranks, single_gpu_reference
     check_ranks(2, 0, None, single_gpu_reference(520, 900, 7), tmp_path)

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--precision", default="f16x3")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--diag-lib", action="store_true", help="run on libseekr_hip_diag.so (holds the 4-wave arm, SEEKR_GEMM_WAVE_TILE=1)")
+    ap.add_argument("--tile-operand", action="store_true", help="make one random 8 192-row chunk and reuse it, columns rotated, for every other chunk (large shapes under the profiler: the host generator would dominate the run)")
     ap.add_argument("--lib", default="", help="another build of the library to run on (A/B across source versions, one process each)")
     ap.add_argument("variants", nargs="*")
     args = ap.parse_args()
@@ -43,9 +44,14 @@ def main():
         # binomial counts -> Log2-like values: what the pipeline feeds the contraction
         chunk = 8192
         op = _lib.Operand(ctx, rows, args.cols, prec)
+        base = None
         for r0 in range(0, rows, chunk):
             nr = min(chunk, rows - r0)
-            x = np.log2(rng.binomial(1995, 1.0 / 4096, size=(nr, args.cols)).astype(np.float32) * np.float32(0.5) + 1.0)
+            if args.tile_operand and base is not None:
+                x = np.roll(base[:nr], 32 * (r0 // chunk) + seed, axis=1)
+            else:
+                x = np.log2(rng.binomial(1995, 1.0 / 4096, size=(nr, args.cols)).astype(np.float32) * np.float32(0.5) + 1.0)
+                base = x
             d = ctx.from_numpy(x.astype(np.float32))
             _lib.operand_fill(ctx, d, op=op.view(r0, nr), precision=prec)
             d.free()

@@ -27,6 +27,7 @@ ap.add_argument("--data", default="counts", choices=["counts", "zeros", "ones"],
                 help="operand values: normalised-count-like (default), all zero, or all one (constant rows standardise to NaN -> use raw fill)")
 ap.add_argument("--no-dma", action="store_true", help="k loop without its LDS-DMA staging (timing experiment; r is garbage)")
 ap.add_argument("--same-tile", action="store_true", help="every stage re-loads k tile 0: the staging traffic stays, its source is the nearest cache (timing experiment; r is garbage)")
+ap.add_argument("--two-units", action="store_true", help="TIMING CEILING of a two-product-unit split (VERDICT r3 #5): one v_mfma_i32_16x16x64_i8 in place of the two cross products, same staging and LDS reads; r is garbage.  Printed next to a stamps-only launch of the same process")
 ap.add_argument("--no-mirror", action="store_true", help="self mode without the mirror stores (timing experiment; the lower triangle stays unwritten)")
 args = ap.parse_args()
 ctx = _lib.default_context()
@@ -52,22 +53,40 @@ while time.time() < t_end:  # warm the chip up to its steady clock
     _lib.pearson_gemm_op(ctx, op, b, r, symmetric=sym)
     ctx.sync()
     n += 1
-_lib.check(_lib.lib().skr_gemm_diag_mode(ctx._h, 2 if args.no_dma else (3 if args.same_tile else (4 if args.no_mirror else 1))))
-_lib.pearson_gemm_op(ctx, op, b, r, symmetric=sym)
-ctx.sync()
-_lib.check(_lib.lib().skr_gemm_diag_mode(ctx._h, 0))
-rec = np.zeros((65536, 8), dtype=np.uint64)
-cnt = C.c_int64(0)
-_lib.check(_lib.lib().skr_gemm_diag_read(ctx._h, rec.ctypes.data_as(C.c_void_p), 65536, C.byref(cnt)))
-rec = rec[:min(cnt.value, 65536)].astype(np.float64)
-t0, rt0, k0, k1, t1, rt1 = (rec[:, i] for i in range(6))
-clock = (t1 - t0) / (rt1 - rt0) * 100e6 / 1e9
-print("%d warm-up launches; %d tile records" % (n, len(rec)))
-print("in-kernel clock: median %.3f GHz (5-95 %%: %.3f - %.3f)" % (np.median(clock), *np.percentile(clock, [5, 95])))
-for name, v in (("tile total", t1 - t0), ("prologue (slot + first stage)", k0 - t0), ("k loop", k1 - k0), ("epilogue + store drain", t1 - k1)):
-    print("%-30s median %8.0f cycles = %6.1f us   (5-95 %%: %.0f - %.0f)"
-          % (name, np.median(v), np.median(v) / np.median(clock) / 1e3, *np.percentile(v, [5, 95])))
-kt = (args.cols + 31) // 32
-mfma = kt * 2 * 96 * 16
-print("MFMA cycles per tile and SIMD (2 waves x 96 MFMA x 16 cycles x %d k tiles): %d = %.3f of the k loop, %.3f of the tile"
-      % (kt, mfma, mfma / np.median(k1 - k0), mfma / np.median(t1 - t0)))
+def one_launch(mode, label):
+    _lib.check(_lib.lib().skr_gemm_diag_mode(ctx._h, mode))
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    _lib.pearson_gemm_op(ctx, op, b, r, symmetric=sym)
+    ctx.sync()
+    ctx.prof_enable(False)
+    ms = sum(ctx.prof_query(nm)[0] for nm in ctx.prof_names() if nm.startswith("pearson_gemm"))
+    _lib.check(_lib.lib().skr_gemm_diag_mode(ctx._h, 0))
+    rec = np.zeros((65536, 8), dtype=np.uint64)
+    cnt = C.c_int64(0)
+    _lib.check(_lib.lib().skr_gemm_diag_read(ctx._h, rec.ctypes.data_as(C.c_void_p), 65536, C.byref(cnt)))
+    rec = rec[:min(cnt.value, 65536)].astype(np.float64)
+    t0, rt0, k0, k1, t1, rt1 = (rec[:, i] for i in range(6))
+    clock = (t1 - t0) / (rt1 - rt0) * 100e6 / 1e9
+    print("---- %s: launch %.3f ms (HIP events); %d tile records" % (label, ms, len(rec)))
+    print("in-kernel clock: median %.3f GHz (5-95 %%: %.3f - %.3f)" % (np.median(clock), *np.percentile(clock, [5, 95])))
+    for name, v in (("tile total", t1 - t0), ("prologue (slot + first stage)", k0 - t0), ("k loop", k1 - k0), ("epilogue + store drain", t1 - k1)):
+        print("%-30s median %8.0f cycles = %6.1f us   (5-95 %%: %.0f - %.0f)"
+              % (name, np.median(v), np.median(v) / np.median(clock) / 1e3, *np.percentile(v, [5, 95])))
+    kt = (args.cols + 31) // 32
+    units = 64 if mode == 5 else 96
+    mfma = kt * 2 * units * 16
+    print("MFMA cycles per tile and SIMD (2 waves x %d MFMA x 16 cycles x %d k tiles): %d = %.3f of the k loop, %.3f of the tile"
+          % (units, kt, mfma, mfma / np.median(k1 - k0), mfma / np.median(t1 - t0)))
+    return ms
+
+
+print("%d warm-up launches" % n)
+mode = 2 if args.no_dma else (3 if args.same_tile else (4 if args.no_mirror else (5 if args.two_units else 1)))
+if mode == 5:
+    for rep in range(3):  # alternate in one process: stamps only / two product-units
+        a_ms = one_launch(1, "three product-units (shipped arithmetic, stamps only)")
+        b_ms = one_launch(5, "two product-units (timing ceiling)")
+        print("==== launch %.3f -> %.3f ms: %+.1f %%" % (a_ms, b_ms, (b_ms / a_ms - 1) * 100))
+else:
+    one_launch(mode, "diag mode %d" % mode)

@@ -15,11 +15,19 @@ is_bench = prec in ("fp32", "bf16x3", "bf16x4", "f16x3")  # else: the passes ran
 b_args = bench.parse(["--precision", prec] + extra) if is_bench else None
 rows = (b_args.rows or 50000) if is_bench else 0
 acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+# PMC_CYCLE=n: a call is n dispatches of one kernel (the k chunks of a k = 7 contraction): keep them apart as name#i
+cycle = int(os.environ.get("PMC_CYCLE", "0"))
 for path in sorted(glob.glob(os.path.join(out_dir, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
     with open(path, newline="") as fh:
-        for row in csv.DictReader(fh):
+        seen = defaultdict(int)
+        rows_in_order = sorted(csv.DictReader(fh), key=lambda r: int(r.get("Dispatch_Id", 0) or 0))
+        for row in rows_in_order:
             name = re.sub(r"^void ", "", row["Kernel_Name"]).replace("(anonymous namespace)::", "")
             name = re.sub(r"\(.*$", "", name)  # drop the argument list of demangled names
+            if cycle and "gemm" in name:
+                key = (name, row["Counter_Name"])
+                name = "%s#chunk%d" % (name, seen[key] % cycle)
+                seen[key] += 1
             cell = acc[name][row["Counter_Name"]]
             cell[0] += float(row["Counter_Value"])
             cell[1] += 1
