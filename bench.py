@@ -65,7 +65,7 @@ def parse(argv=None):
     ap.add_argument("--alphabet", default="AGTC", help="any string the reference accepts (kmer_counts.py:120-122); other than four "
                     "distinct letters the step counts with the any-alphabet kernel from resident ASCII (len^k columns)")
     ap.add_argument("--precision", default=os.environ.get("SEEKR_PRECISION", "f16x3"),
-                    choices=["fp32", "bf16x3", "bf16x4", "f16x3"],
+                    choices=["fp32", "bf16x3", "bf16x4", "f16x3", "f16f8"],
                     help="Pearson contraction arithmetic; every choice is inside the parity bar "
                          "|dr| <= 2e-6 + 1e-5|r| (tests/test_gpu_parity.py) on the bench data; f16x3 carries float32-grade operands, bf16x3 is ~5 % faster")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -578,7 +578,7 @@ def run_rank(args):
     if size > 1 and os.environ.get("SEEKR_BENCH_CHAIN_AB") == "1":
         chain_ab = column_chain_ab(ctx, comm, engine, x, n_cols)
     gemm_name = {"fp32": "pearson_gemm_f32", "bf16x3": "pearson_gemm_bf16x3", "bf16x4": "pearson_gemm_bf16x4",
-                 "f16x3": "pearson_gemm_f16x3"}[args.precision]
+                 "f16x3": "pearson_gemm_f16x3", "f16f8": "pearson_gemm_f16f8"}[args.precision]
     gemm = kern.get(gemm_name, {"ms_total": 0.0, "launches": 0})
     count = kern.get("count_generic" if generic else "count_kmers_f32", {"ms_total": 0.0, "launches": 0})
 
@@ -603,11 +603,11 @@ def run_rank(args):
     delivered_pairs = float(n_loc) * n_total
     achieved_tf = 2.0 * n_cols * delivered_pairs / (gemm_ms_step * 1e-3) / 1e12 if gemm_ms_step > 0 else 0.0
     multiplied_tf = 2.0 * n_cols * exec_pairs / (gemm_ms_step * 1e-3) / 1e12 if gemm_ms_step > 0 else 0.0
-    nprod = {"fp32": 1, "bf16x3": 3, "bf16x4": 4, "f16x3": 3}[args.precision]
+    nprod = {"fp32": 1, "bf16x3": 3, "bf16x4": 4, "f16x3": 3, "f16f8": 2}[args.precision]
     peak_tf = PEAK["fp32_mfma_tflops"] if args.precision == "fp32" else PEAK["bf16_mfma_tflops"]
     # PMC traffic: from the committed summary of this very workload, taken with this library's kernel set — else null
     gemm_key = {"fp32": "pearson_gemm_f32_kernel", "bf16x3": "split16_kernelIDF16bLi3", "bf16x4": "split16_kernelIDF16bLi4",
-                "f16x3": "split16_kernelIDF16_Li3"}[args.precision]
+                "f16x3": "split16_kernelIDF16_Li3", "f16f8": "split16_kernelIDF16_Li2"}[args.precision]
     wl = workload_key(n_total, length, k, args.precision, size) + (" alphabet=" + args.alphabet if generic else "")
     gemm_traffic, gemm_why = (None, "--no-symmetry") if args.no_symmetry else pmc_traffic(gemm_key, wl, _lib.LIB_PATH)
     count_traffic, count_why = pmc_traffic("count_generic_lds_kernel<float, false>" if generic else "count_rows_kernel<0", wl,
@@ -647,8 +647,9 @@ def run_rank(args):
         "n_gpus": size, "steps": steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.precision == "fp32" else "f32 as {} split-{} MFMA products, f32 accumulate".format(
-            nprod, "fp16" if args.precision == "f16x3" else "bf16"),
+        "dtype": ("f32" if args.precision == "fp32" else
+                  "f32 as 1 fp16 (hi x hi) + 1 block-scaled fp8 (both cross terms) MFMA product, f32 accumulate" if args.precision == "f16f8"
+                  else "f32 as {} split-{} MFMA products, f32 accumulate".format(nprod, "fp16" if args.precision == "f16x3" else "bf16")),
         "data": "synthetic",
         "config": {"workload": "{} synthetic {} nt transcripts, k={}, counts + Log2.post normalisation + "
                                "self Pearson ({} x {} r matrix, row-sharded)".format(n_total, length, k, n_total, n_total),

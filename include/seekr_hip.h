@@ -54,6 +54,10 @@ enum {
     SKR_PREC_BF16X3 = 1, /* split-bf16: hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16       */
     SKR_PREC_F64 = 2,    /* v_mfma_f64_16x16x4_f64 (float64 inputs: CSV / integer count files)   */
     SKR_PREC_BF16X4 = 3, /* split-bf16 with the lo*lo term as well                                */
+    SKR_PREC_F16F8 = 5,  /* opt-in (round 4): hi*hi on v_mfma_f32_16x16x32_f16, the two cross terms as ONE block-scaled
+                          * fp8 product (v_mfma_scale_f32_16x16x128_f8f6f4): 2 product-units per k instead of 3; for
+                          * row-standardised rows of 1 024 / 4 096 / 16 384 columns, any other shape and rows flagged as
+                          * few-valued fall back to SKR_PREC_F16X3 by themselves                       */
     SKR_PREC_F16X3 = 4   /* split-fp16 (11-bit halves: float32-grade operands), 3 products on    */
                          /* v_mfma_f32_16x16x32_f16.  The host API's default for row-standardised */
                          /* rows; values must fit fp16 (|z| <= sqrt(K) always does)              */

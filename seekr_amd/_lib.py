@@ -18,9 +18,10 @@ DIAG_LIB_PATH = os.path.join(_HERE, "libseekr_hip_diag.so")
 SKR_OK = 0
 F32, F64, U32 = 0, 1, 2
 LOG2_NONE, LOG2_PRE, LOG2_POST = 0, 1, 2
-PREC_FP32, PREC_BF16X3, PREC_F64, PREC_BF16X4, PREC_F16X3 = 0, 1, 2, 3, 4
+PREC_FP32, PREC_BF16X3, PREC_F64, PREC_BF16X4, PREC_F16X3, PREC_F16F8 = 0, 1, 2, 3, 4, 5
 LOG2_CODES = {"Log2.none": LOG2_NONE, "Log2.pre": LOG2_PRE, "Log2.post": LOG2_POST}
-PRECISIONS = {"fp32": PREC_FP32, "bf16x3": PREC_BF16X3, "bf16x4": PREC_BF16X4, "f16x3": PREC_F16X3, "f64": PREC_F64}
+PRECISIONS = {"fp32": PREC_FP32, "bf16x3": PREC_BF16X3, "bf16x4": PREC_BF16X4, "f16x3": PREC_F16X3, "f64": PREC_F64,
+              "f16f8": PREC_F16F8}  # f16f8: opt-in, two product-units per k; degrades to f16x3 by itself
 _NP_OF = {F32: np.float32, F64: np.float64, U32: np.uint32}
 _CODE_OF = {np.dtype(np.float32): F32, np.dtype(np.float64): F64, np.dtype(np.uint32): U32}
 
@@ -364,7 +365,8 @@ class Operand:
 
     @property
     def kind(self):
-        """0 = float32 layout (fp32 kernel), 1 = bf16 halves, 2 = fp16 halves (see skr_operand_kind)."""
+        """0 = float32 layout (fp32 kernel), 1 = bf16 halves, 2 = fp16 halves, 3 = fp16 hi lines + fp8 cross lines (f16f8)
+        (see skr_operand_kind)."""
         k = _int(0)
         check(lib().skr_operand_kind(self._h, C.byref(k)))
         return k.value

@@ -20,7 +20,7 @@ struct SkrKnobs {
     int gemm_subtile = 4;        // SEEKR_GEMM_SUBTILE: order in which an XCD's CUs take the tiles of a super-tile (pearson_bf16.hip: tile_of_block)
     int gemm_wave_tile = 0;      // SEEKR_GEMM_WAVE_TILE=1: the 4-wave 128 x 128 wave-tile arm (libseekr_hip_diag.so only; tools/gemm_bench.py --diag-lib)
     int count_percu = 0;         // SEEKR_COUNT_PERCU: cap on resident workgroups per CU (0 = none)
-    bool count_persist = false;  // SEEKR_COUNT_PERSIST=1: persistent grid at k <= 6
+    int count_persist = 0;       // SEEKR_COUNT_PERSIST=1: persistent grid at k <= 6; 2: one workgroup per sequence at k = 7 too
     bool count_legacy = false;   // SEEKR_COUNT_LEGACY=1: the round-1 counting kernel
     int count_wps = 0;           // SEEKR_COUNT_WPS: waves per sequence (0 = by k)
     bool count_generic_global = false;  // SEEKR_COUNT_GENERIC_GLOBAL=1: any-alphabet counting on the round-1 path (histogram in HBM)

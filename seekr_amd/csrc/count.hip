@@ -551,12 +551,20 @@ int launch_rows(skr_ctx* ctx, const skr_seqs* s, int k, void* out) {
     // moves through the matrix, which is what the HBM writes fastest (tools/micro/store_pattern.hip); a persistent
     // grid whose waves stride through the sequences drifts apart.  Measured behind a contraction, 50 000 x 2 kb:
     // 0.146 ms against 0.165 for the persistent grid of 12 waves per CU (which needs the cap: 19 are slower still),
-    // k = 5: 0.100 vs 0.108.  Four waves per sequence (k = 7) measure the same either way and stay persistent.
-    const bool persistent = WPS > 1 || ctx->knobs.count_persist;  // A/B knob
+    // k = 5: 0.100 vs 0.108.
+    // k = 7 (four waves per sequence): one workgroup per sequence as well since round 4 — 0.323 against 0.340 ms for the
+    // persistent grid (30 000 x 5 kb behind a contraction: 0.775 against 0.737 of 8 TB/s); SEEKR_COUNT_PERSIST=1 restores it
+    const bool persistent = ctx->knobs.count_persist == 1;  // A/B knob
     if (!persistent) grid = (unsigned)std::min<int64_t>(s->n, 0x7fffffff);
     size_t lds_launch = lds;
-    if (!persistent && ctx->knobs.count_occ > 0) {  // A/B knob: at most this many one-wave workgroups (= row streams) per CU
-        lds_launch = std::max(lds, ((size_t)160 * 1024 / (size_t)ctx->knobs.count_occ) & ~(size_t)255);
+    // Round 4: at k = 6 the LDS would let 19 one-wave workgroups share a CU; SIXTEEN (four per SIMD, enforced by asking for
+    // 10 KiB of LDS each) write the rows 7-8 % faster behind a contraction — 0.138-0.140 ms against 0.149-0.150 for
+    // 50 000 x 2 kb, 0.76 against 0.70 of 8 TB/s, two runs of tools/count_bench.py --pre gemm (profiles/r4_count_occupancy.log:
+    // 18 and 19 per CU 0.150, 17 and 16 0.139, 15 and 14 0.146, 12 0.160, 8 0.187) — fewer row streams, and none of the
+    // SIMDs holds a fifth wave.  Smaller k (2 KiB of bins and less) are fastest unrestricted.  SEEKR_COUNT_OCC overrides.
+    const int occ = ctx->knobs.count_occ > 0 ? ctx->knobs.count_occ : (WPS == 1 && k == 6 ? 16 : 0);
+    if (!persistent && occ > 0) {
+        lds_launch = std::max(lds, ((size_t)160 * 1024 / (size_t)occ) & ~(size_t)255);
         SKR_TRY(skr_kernel_lds(ctx, reinterpret_cast<const void*>(kern), lds_launch));
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WPS * 64), lds_launch, ctx->stream, a);
@@ -748,8 +756,11 @@ __global__ __launch_bounds__(kThreads) void convert_generic_kernel(const uint32_
 constexpr int kGenChunk = 4096;
 constexpr int64_t kGenLdsBins = 16384;
 
+constexpr int kGenThreads = 1024;  // two workgroups of 16 waves per CU at 62.5 KiB of bins: the flush is a latency-bound loop of
+                                   // dword stores, so what counts is how many of them are in flight (256 threads: 1.32 ms for
+                                   // 50 000 x 5^6 rows = 0.31 of HBM)
 template <typename OutT, bool LOG2>
-__global__ __launch_bounds__(kThreads) void count_generic_lds_kernel(const unsigned char* __restrict__ bases,
+__global__ __launch_bounds__(kGenThreads) void count_generic_lds_kernel(const unsigned char* __restrict__ bases,
                                                                      const int64_t* __restrict__ offsets, int64_t n_seqs, int k,
                                                                      int alen, uint32_t nbins, GenericLut lut,
                                                                      OutT* __restrict__ out) {
@@ -760,8 +771,8 @@ __global__ __launch_bounds__(kThreads) void count_generic_lds_kernel(const unsig
     int8_t* lutb = reinterpret_cast<int8_t*>(glds + bins_pad + kTabSize);  // [256]
     int8_t* codes = lutb + 256;                                           // [kGenChunk + 64]
     const int tid = threadIdx.x;
-    for (uint32_t b = tid; b < bins_pad; b += kThreads) bins[b] = 0;
-    lutb[tid] = lut.code[tid];
+    for (uint32_t b = tid; b < bins_pad; b += kGenThreads) bins[b] = 0;
+    if (tid < 256) lutb[tid] = lut.code[tid];
     __syncthreads();
     for (int64_t s = blockIdx.x; s < n_seqs; s += gridDim.x) {
         const unsigned char* seq = bases + offsets[s];
@@ -773,12 +784,14 @@ __global__ __launch_bounds__(kThreads) void count_generic_lds_kernel(const unsig
             if (LOG2) t = skr_log2_cr(t + 1.0f);
             tab[tid] = t;
         }
+        __syncthreads();  // the table is read by every wave's flush — also for a sequence without a single window (W <= 0:
+                          // no chunk, hence no other barrier in between; found by the differential fuzzer)
         for (int64_t c0 = 0; c0 < W; c0 += kGenChunk) {
             const int64_t n_char = std::min<int64_t>(len - c0, kGenChunk + k - 1);
-            for (int64_t i = tid; i < n_char; i += kThreads) codes[i] = lutb[seq[c0 + i]];
+            for (int64_t i = tid; i < n_char; i += kGenThreads) codes[i] = lutb[seq[c0 + i]];
             __syncthreads();
             const int64_t n_win = std::min<int64_t>(W - c0, kGenChunk);
-            for (int64_t w = tid; w < n_win; w += kThreads) {
+            for (int64_t w = tid; w < n_win; w += kGenThreads) {
                 uint32_t idx = 0;
                 int bad = 0;
                 for (int p = 0; p < k; p++) {
@@ -791,22 +804,45 @@ __global__ __launch_bounds__(kThreads) void count_generic_lds_kernel(const unsig
             __syncthreads();
         }
         OutT* row = out + (size_t)s * nbins;
-        for (uint32_t b = tid; b < nbins; b += kThreads) {
-            const uint32_t n = bins[b];
-            bins[b] = 0;
-            if (std::is_same<OutT, uint32_t>::value) {
-                __builtin_nontemporal_store((OutT)n, row + b);
-            } else if (sizeof(OutT) == 8) {
-                __builtin_nontemporal_store((OutT)per_kb_value_f64(n, inc), row + b);
+        auto value_of = [&](uint32_t n) -> OutT {
+            if (std::is_same<OutT, uint32_t>::value) return (OutT)n;
+            if (sizeof(OutT) == 8) return (OutT)per_kb_value_f64(n, inc);
+            float t;
+            if (n < (uint32_t)kTabSize) {
+                t = tab[n];
             } else {
-                float t;
-                if (n < (uint32_t)kTabSize) {
-                    t = tab[n];
-                } else {
-                    t = per_kb_value(n, inc);
-                    if (LOG2) t = skr_log2_cr(t + 1.0f);
+                t = per_kb_value(n, inc);
+                if (LOG2) t = skr_log2_cr(t + 1.0f);
+            }
+            return (OutT)t;
+        };
+        if (sizeof(OutT) == 4) {
+            // 16-byte stores: rows of A^k four-byte cells start on a 4-byte boundary only, so the first `head` cells and the
+            // last few go out one by one and the body in aligned groups of four (four ds_read_b32: the group's bins are
+            // not 16-byte aligned in the LDS)
+            typedef OutT v4 __attribute__((ext_vector_type(4)));
+            const uint32_t head = std::min<uint32_t>(nbins, (4u - (uint32_t)((reinterpret_cast<uintptr_t>(row) >> 2) & 3u)) & 3u);
+            const uint32_t groups = (nbins - head) >> 2;
+            for (uint32_t g = tid; g < groups; g += kGenThreads) {
+                const uint32_t b = head + 4 * g;
+                const uint32_t n0 = bins[b], n1 = bins[b + 1], n2 = bins[b + 2], n3 = bins[b + 3];
+                bins[b] = 0, bins[b + 1] = 0, bins[b + 2] = 0, bins[b + 3] = 0;
+                __builtin_nontemporal_store(v4{value_of(n0), value_of(n1), value_of(n2), value_of(n3)}, reinterpret_cast<v4*>(row + b));
+            }
+            const uint32_t tail0 = head + 4 * groups;  // cells [0, head) and [tail0, nbins): at most six
+            if (tid < 8) {
+                const uint32_t b = (uint32_t)tid < head ? (uint32_t)tid : tail0 + ((uint32_t)tid - head);
+                if (((uint32_t)tid < head) || b < nbins) {
+                    const uint32_t n = bins[b];
+                    bins[b] = 0;
+                    row[b] = value_of(n);
                 }
-                __builtin_nontemporal_store((OutT)t, row + b);
+            }
+        } else {
+            for (uint32_t b = tid; b < nbins; b += kGenThreads) {
+                const uint32_t n = bins[b];
+                bins[b] = 0;
+                __builtin_nontemporal_store(value_of(n), row + b);
             }
         }
         __syncthreads();  // zeroed bins and the table are settled before the next sequence
@@ -893,14 +929,14 @@ extern "C" int skr_count_generic_dev(skr_ctx* ctx, const skr_aseqs* a, const cha
     if (nbins <= kGenLdsBins && k <= 64 && !ctx->knobs.count_generic_global) {
         // the histogram fits the LDS: one pass, the row write is the only traffic (kernel comment above)
         const size_t lds = (size_t)((nbins + 3) & ~(int64_t)3) * 4 + kTabSize * 4 + 256 + kGenChunk + 64;
-        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, ((size_t)160 * 1024) / lds));
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / kGenThreads, ((size_t)160 * 1024) / lds));
         const unsigned grid = (unsigned)std::min<int64_t>(n, (int64_t)ctx->num_cu * per_cu);
         SkrProfScope prof(ctx, "count_generic");
 #define SKR_GEN_LAUNCH(T, LG)                                                                                              \
     do {                                                                                                                   \
         auto kern = count_generic_lds_kernel<T, LG>;                                                                       \
         SKR_TRY(skr_kernel_lds(ctx, reinterpret_cast<const void*>(kern), lds));                                            \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, ctx->stream, a->d_bases, a->d_off, n, k, alen, (uint32_t)nbins, \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kGenThreads), lds, ctx->stream, a->d_bases, a->d_off, n, k, alen, (uint32_t)nbins, \
                            lut, (T*)out->data);                                                                            \
     } while (0)
         if (out->dtype == SKR_U32) SKR_GEN_LAUNCH(uint32_t, false);

@@ -52,7 +52,7 @@ extern "C" int skr_ctx_reload_knobs(skr_ctx* c) {
     kn.gemm_subtile = env_int("SEEKR_GEMM_SUBTILE", 4);
     kn.gemm_wave_tile = env_int("SEEKR_GEMM_WAVE_TILE", 0);
     kn.count_percu = std::max(0, env_int("SEEKR_COUNT_PERCU", 0));
-    kn.count_persist = env_int("SEEKR_COUNT_PERSIST", 0) != 0;
+    kn.count_persist = env_int("SEEKR_COUNT_PERSIST", 0);
     kn.count_legacy = env_int("SEEKR_COUNT_LEGACY", 0) != 0;
     kn.count_wps = env_int("SEEKR_COUNT_WPS", 0);
     kn.count_flush = env_int("SEEKR_COUNT_FLUSH", 0);

@@ -510,15 +510,20 @@ using vec4h = T __attribute__((ext_vector_type(4)));
 // RW = waves that share a row (1: a wave per row; 4: the workgroup's four waves take 4^7 columns
 // together, wave w owning the 256-column pieces w, w + 4, ... and the row sums crossing the waves
 // through 16 bytes of LDS and one barrier each).
-template <typename T, int VPL, int MODE, int RW, bool HASY>
+// X8 (T = _Float16 only; round 4, the opt-in SKR_PREC_F16F8): the "H / X lines" layout of the two-product-unit
+// contraction — per 64 columns one 128-byte line of the 64 fp16 hi halves, then one of 64 fp8 (e4m3) copies of hi / 128
+// followed by 64 fp8 copies of lo x 8 (pearson_bf16.hip, NPROD = 2) — and a flag for rows in which neighbouring cells
+// repeat each other (few-valued rows: the fp8 roundings of a repeated value are the same everywhere and add up).
+template <typename T, int VPL, int MODE, int RW, bool HASY, bool X8 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VPL == 16 ? 2 : 4))) void operand_fill_reg_kernel(FillArgs a) {
-    __shared__ float red[7][4];
+    static_assert(!X8 || std::is_same<T, _Float16>::value, "the fp8 cross layout pairs with fp16 hi halves");
+    __shared__ float red[8][4];
     const int lane = threadIdx.x & 63;
     // the wave index through readfirstlane: the compiler then KNOWS the row index is wave-uniform and keeps every row
     // base in scalar registers (derived from threadIdx it is 'divergent', and all addresses become 64-bit VGPR pairs)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), waves = blockDim.x >> 6;
     constexpr int64_t K = (int64_t)VPL * 256 * RW;
-    bool any_nan = false, overflow = false, outlier = false, coherent = false;
+    bool any_nan = false, overflow = false, outlier = false, coherent = false, repeats = false;
     // sum / max over the row; `slot` separates the reductions of one row so that one barrier each is enough
     auto row_sum = [&](float v, int slot) -> float {
         v = wave_sum(v);
@@ -657,6 +662,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VPL == 16 ?
             for (int i = 0; i < VPL; i++)
                 same += (float)((v[i].x == zmin) + (v[i].y == zmin) + (v[i].z == zmin) + (v[i].w == zmin));
             if (row_sum(same, 6) >= 0.85f * (float)K) coherent = true;
+            if (X8) {
+                float eq = 0.f;
+#pragma unroll
+                for (int i = 0; i < VPL; i++) eq += (float)((v[i].x == v[i].y) + (v[i].y == v[i].z) + (v[i].z == v[i].w));
+                if (row_sum(eq, 7) >= (float)K * (1.0f / 256.0f)) repeats = true;
+            }
         }
 #pragma unroll
         for (int i = 0; i < VPL; i++) {
@@ -673,9 +684,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VPL == 16 ?
                     hi[j] = hh;
                     lo[j] = (T)(zs - (float)hh);
                 }
-                T* dst = reinterpret_cast<T*>(a.out) + ((size_t)r * a.kt + (c >> 5)) * 64 + (c & 31);
-                *reinterpret_cast<vec4h<T>*>(dst) = hi;
-                *reinterpret_cast<vec4h<T>*>(dst + 32) = lo;
+                if constexpr (X8) {
+                    // line 2d: 64 fp16 hi halves of columns 64d .. 64d+63; line 2d+1: their fp8 copies hi / 128, then lo x 8
+                    char* line = reinterpret_cast<char*>(a.out) + ((size_t)r * a.kt + 2 * (size_t)(c >> 6)) * 128;
+                    const int j = (int)(c & 63);
+                    *reinterpret_cast<vec4h<T>*>(line + 2 * j) = hi;
+                    int h8 = 0, l8 = 0;
+                    h8 = __builtin_amdgcn_cvt_pk_fp8_f32((float)hi[0] * 0x1.0p-7f, (float)hi[1] * 0x1.0p-7f, h8, false);
+                    h8 = __builtin_amdgcn_cvt_pk_fp8_f32((float)hi[2] * 0x1.0p-7f, (float)hi[3] * 0x1.0p-7f, h8, true);
+                    l8 = __builtin_amdgcn_cvt_pk_fp8_f32((float)lo[0] * 8.f, (float)lo[1] * 8.f, l8, false);
+                    l8 = __builtin_amdgcn_cvt_pk_fp8_f32((float)lo[2] * 8.f, (float)lo[3] * 8.f, l8, true);
+                    *reinterpret_cast<int*>(line + 128 + j) = h8;
+                    *reinterpret_cast<int*>(line + 192 + j) = l8;
+                } else {
+                    T* dst = reinterpret_cast<T*>(a.out) + ((size_t)r * a.kt + (c >> 5)) * 64 + (c & 31);
+                    *reinterpret_cast<vec4h<T>*>(dst) = hi;
+                    *reinterpret_cast<vec4h<T>*>(dst + 32) = lo;
+                }
                 if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -684,6 +709,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VPL == 16 ?
     if (overflow) atomicOr(&a.flags[3], 1u);
     if (outlier) atomicOr(&a.flags[4], 1u);
     if (coherent) atomicOr(&a.flags[5], 1u);
+    if (repeats) atomicOr(&a.flags[6], 1u);
 }
 
 // r[i, i] of a self-comparison = <z_i, z_i> / K.  The contraction adds 4 096 squares into one float32
@@ -724,7 +750,7 @@ __global__ void recip64_kernel(const float* __restrict__ v, double* __restrict__
 }
 
 bool is_f32_precision(int p) {
-    return p == SKR_PREC_FP32 || p == SKR_PREC_BF16X3 || p == SKR_PREC_BF16X4 || p == SKR_PREC_F16X3;
+    return p == SKR_PREC_FP32 || p == SKR_PREC_BF16X3 || p == SKR_PREC_BF16X4 || p == SKR_PREC_F16X3 || p == SKR_PREC_F16F8;
 }
 
 // launches the fill kernel that suits the row width and the operand's storage kind
@@ -766,23 +792,24 @@ int launch_fill(skr_ctx* ctx, const skr_operand* op, const FillArgs& a_in) {
         SKR_REQUIRE(all_wgs <= 0x7fffffff, "too many rows for one fill launch (%lld)", (long long)a.rows);
         const unsigned rgrid = (unsigned)std::max<int64_t>(1, all_wgs);
         SkrProfScope prof(ctx, "operand_fill");
-#define LAUNCH_REG2(T, V, RW)                                                                                              \
+#define LAUNCH_REG2(T, V, RW, X)                                                                                           \
     do {                                                                                                                   \
-        if (reg_mode == 0) hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 0, RW, false>), dim3(rgrid), dim3(256), 0, ctx->stream, a);      \
-        else if (reg_mode == 1 && a.y) hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 1, RW, true>), dim3(rgrid), dim3(256), 0, ctx->stream, a); \
-        else if (reg_mode == 1) hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 1, RW, false>), dim3(rgrid), dim3(256), 0, ctx->stream, a); \
-        else if (a.y) hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 2, RW, true>), dim3(rgrid), dim3(256), 0, ctx->stream, a);             \
-        else hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 2, RW, false>), dim3(rgrid), dim3(256), 0, ctx->stream, a);                    \
+        if (reg_mode == 0) hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 0, RW, false, X>), dim3(rgrid), dim3(256), 0, ctx->stream, a);      \
+        else if (reg_mode == 1 && a.y) hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 1, RW, true, X>), dim3(rgrid), dim3(256), 0, ctx->stream, a); \
+        else if (reg_mode == 1) hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 1, RW, false, X>), dim3(rgrid), dim3(256), 0, ctx->stream, a); \
+        else if (a.y) hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 2, RW, true, X>), dim3(rgrid), dim3(256), 0, ctx->stream, a);             \
+        else hipLaunchKernelGGL((operand_fill_reg_kernel<T, V, 2, RW, false, X>), dim3(rgrid), dim3(256), 0, ctx->stream, a);                    \
     } while (0)
-#define LAUNCH_REG(T)                                  \
-    do {                                               \
-        if (a.cols == 16384) LAUNCH_REG2(T, 16, 4);    \
-        else if (a.cols == 4096) LAUNCH_REG2(T, 16, 1); \
-        else LAUNCH_REG2(T, 4, 1);                      \
+#define LAUNCH_REG(T, X)                                  \
+    do {                                                  \
+        if (a.cols == 16384) LAUNCH_REG2(T, 16, 4, X);    \
+        else if (a.cols == 4096) LAUNCH_REG2(T, 16, 1, X); \
+        else LAUNCH_REG2(T, 4, 1, X);                      \
     } while (0)
-        if (op->kind == 0) LAUNCH_REG(float);
-        else if (op->kind == 1) LAUNCH_REG(__bf16);
-        else LAUNCH_REG(_Float16);
+        if (op->kind == 0) LAUNCH_REG(float, false);
+        else if (op->kind == 1) LAUNCH_REG(__bf16, false);
+        else if (op->kind == 3) LAUNCH_REG(_Float16, true);
+        else LAUNCH_REG(_Float16, false);
 #undef LAUNCH_REG
 #undef LAUNCH_REG2
         SKR_HIP(hipGetLastError());
@@ -857,15 +884,18 @@ extern "C" int skr_operand_create(skr_ctx* ctx, int64_t rows, int64_t cols, int 
     // Above 16 384 columns (k >= 8) one float32 accumulator per cell over the whole of K drifts
     // past the bar (1e-5 at K = 65 536 measured), so those shapes also take the fp32 kernel, whose
     // accumulation is blocked.
+    // SKR_PREC_F16F8 (opt-in): the H / X line layout exists for the three register-resident widths; any other shape is
+    // served by the split-fp16 operand it degrades to
+    if (precision == SKR_PREC_F16F8 && !(cols == 1024 || cols == 4096 || cols == 16384)) op->precision = precision = SKR_PREC_F16X3;
     const int64_t split_min = precision == SKR_PREC_F16X3 ? 64 : 1024;
     if (precision == SKR_PREC_FP32 || cols < split_min || cols > 16384) op->kind = 0;
-    else op->kind = precision == SKR_PREC_F16X3 ? 2 : 1;
+    else op->kind = precision == SKR_PREC_F16F8 ? 3 : (precision == SKR_PREC_F16X3 ? 2 : 1);
     // fp16 halves: rows are stored times a power of two chosen so that sqrt(K) — the largest value a
     // row-standardised row can hold — lands just below 2^15.  The lo half of a small z then stays a
     // normal fp16 number (without the scale it is subnormal for |z| < 0.125 and z keeps only 3e-8
     // absolute precision); the contraction divides by K s^2.  A function of K alone, so shards
     // exchanged between GPUs agree on it.
-    if (op->kind == 2) op->scale = std::exp2f(std::floor(std::log2(32768.0f / std::sqrt((float)cols))));
+    if (op->kind == 2 || op->kind == 3) op->scale = std::exp2f(std::floor(std::log2(32768.0f / std::sqrt((float)cols))));
     const size_t body = ((size_t)rows * op->row_bytes() + 255) & ~(size_t)255;
     const size_t bytes = body + std::max<size_t>((size_t)rows * sizeof(float), 16);  // rows, then diag[rows]
     hipError_t e = hipMalloc(&op->data, bytes);
@@ -951,12 +981,22 @@ extern "C" int skr_operand_fill(skr_ctx* ctx, const skr_mat* x, const skr_mat* c
     // flags: [1] NaN seen, [3] fp16 range exceeded, [4] a row needs more dynamic range than one float32
     // accumulator per cell has, [5] a row is mostly one repeated value ([2] belongs to the counting kernel)
     SKR_HIP(hipMemsetAsync(ctx->d_flags + 1, 0, 4, ctx->stream));
-    SKR_HIP(hipMemsetAsync(ctx->d_flags + 3, 0, 12, ctx->stream));
+    SKR_HIP(hipMemsetAsync(ctx->d_flags + 3, 0, 16, ctx->stream));  // [6]: neighbouring cells repeat each other (f16f8 only)
     op->coherent = false;
+    if (op->kind == 3) {
+        // the H / X line layout is written by the register kernels alone: float32 vectors computed on the device (or none),
+        // rows standardised here (their values are then bounded by sqrt(K): the fp8 copies cannot overflow)
+        const bool reg_path = (a.ck == 0 && a.sk == 0 && !a.post && !a.y) || (a.ck == 1 && a.sk == 1);
+        if (!reg_path || !a.row_standardize) {
+            op->kind = 2;
+            op->precision = SKR_PREC_F16X3;
+        }
+    }
     SKR_TRY(launch_fill(ctx, op, a));
     op->diag_valid = true;
     // values are only bounded by sqrt(K) when the rows were standardised here: check the fp16 range otherwise
     const bool check_range = op->kind == 2 && !row_standardize;
+    const bool was_x8 = op->kind == 3;
     const bool split = op->kind != 0;
     if (has_nan || check_range || split) {
         SKR_HIP(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -979,6 +1019,29 @@ extern "C" int skr_operand_fill(skr_ctx* ctx, const skr_mat* x, const skr_mat* c
                 b.post = 0;
             }
             SKR_TRY(launch_fill(ctx, op, b));
+            return SKR_OK;
+        }
+        if (was_x8 && (ctx->h_flags[5] != 0 || ctx->h_flags[6] != 0)) {
+            // rows that are mostly one repeated value, or whose neighbouring cells repeat each other (raw counts, 0/1 rows):
+            // the fp8 copies of a repeated value carry the same rounding everywhere — the three-product split serves them
+            if (!op->owner)
+                return skr_set_error(SKR_ERR_UNSUPPORTED, "these rows need the three-product split, and a VIEW cannot change the layout "
+                                                          "of the operand it belongs to: fill whole operands with SKR_PREC_F16F8");
+            op->kind = 2;
+            op->precision = SKR_PREC_F16X3;
+            FillArgs b = a;
+            if (a.y) {  // the normalised counts are already in y: refill from them as they are
+                b.x = a.y;
+                b.y = nullptr;
+                b.ck = b.sk = 0;
+                b.center = b.scale = nullptr;
+                b.post = 0;
+            }
+            SKR_HIP(hipMemsetAsync(ctx->d_flags + 5, 0, 4, ctx->stream));
+            SKR_TRY(launch_fill(ctx, op, b));
+            SKR_HIP(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            SKR_HIP(hipStreamSynchronize(ctx->stream));
+            op->coherent = ctx->h_flags[5] != 0;
             return SKR_OK;
         }
         if (check_range && ctx->h_flags[3] != 0)
@@ -1023,7 +1086,7 @@ extern "C" int skr_pearson_gemm_op(skr_ctx* ctx, const skr_operand* a, const skr
                                    int64_t row0, int64_t col0) {
     SKR_REQUIRE(ctx && a && b && r, "NULL argument");
     SKR_REQUIRE(a->ctx == ctx && b->ctx == ctx && r->ctx == ctx, "handle belongs to a different ctx");
-    SKR_REQUIRE(a->cols == b->cols && a->kind == b->kind && a->precision == b->precision,
+    SKR_REQUIRE(a->cols == b->cols && a->kind == b->kind && (a->kind == 0 || a->precision == b->precision),
                 "operands were prepared for different shapes or precisions");
     SKR_REQUIRE(r->dtype == SKR_F32, "result matrix must be float32");
     SKR_REQUIRE(row0 >= 0 && col0 >= 0 && row0 + a->rows <= r->rows && col0 + b->rows <= r->cols,
@@ -1055,7 +1118,7 @@ extern "C" int skr_pearson_gemm_op_mirror(skr_ctx* ctx, const skr_operand* a, co
                                           int64_t row0, int64_t col0, skr_mat* rt, int64_t trow0, int64_t tcol0) {
     SKR_REQUIRE(ctx && a && b && r && rt, "NULL argument");
     SKR_REQUIRE(a->ctx == ctx && b->ctx == ctx && r->ctx == ctx && rt->ctx == ctx, "handle belongs to a different ctx");
-    SKR_REQUIRE(a->cols == b->cols && a->kind == b->kind && a->precision == b->precision,
+    SKR_REQUIRE(a->cols == b->cols && a->kind == b->kind && (a->kind == 0 || a->precision == b->precision),
                 "operands were prepared for different shapes or precisions");
     SKR_REQUIRE(r->dtype == SKR_F32 && rt->dtype == SKR_F32, "result matrices must be float32");
     SKR_REQUIRE(row0 >= 0 && col0 >= 0 && row0 + a->rows <= r->rows && col0 + b->rows <= r->cols,
@@ -1091,6 +1154,12 @@ extern "C" int skr_pearson_gemm_op_mirror(skr_ctx* ctx, const skr_operand* a, co
 static int match_layouts(skr_ctx* ctx, const skr_mat* xa, skr_operand* oa, const skr_mat* xb, skr_operand* ob,
                          int row_standardize) {
     if (oa->kind == ob->kind) return SKR_OK;
+    if (oa->kind != 0 && ob->kind != 0) {  // one of two f16f8 operands degraded to the three-product split: so does the other
+        skr_operand* x8 = oa->kind == 3 ? oa : ob;
+        x8->kind = 2;
+        x8->precision = SKR_PREC_F16X3;
+        return skr_operand_fill(ctx, x8 == oa ? xa : xb, nullptr, nullptr, 0, 0.f, nullptr, row_standardize, x8, nullptr);
+    }
     skr_operand* split = oa->kind != 0 ? oa : ob;
     const skr_mat* src = oa->kind != 0 ? xa : xb;
     split->kind = 0;

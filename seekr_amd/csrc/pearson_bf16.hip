@@ -4,6 +4,13 @@
 // r = sum_k z1 z2 is then accumulated in float32 from NPROD bf16 products per k:
 //     NPROD = 3 : hi*hi + hi*lo + lo*hi            (|error| <= ~3e-6 on r ~ 1, ~2e-7 rms elsewhere)
 //     NPROD = 4 : ... + lo*lo                      (error ~4e-7 = what float32 BLAS gives)
+//     NPROD = 2 : "f16f8" (round 4, opt-in): hi*hi on the fp16 MFMA, and the two cross products hi*lo + lo*hi as ONE
+//                 block-scaled fp8 MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, e4m3) into the same accumulator: two
+//                 product-units per k instead of three.  Operand layout "H / X lines" (operand.hip, kind 3): per 64
+//                 columns one 128-byte line of 64 fp16 hi values and one of 64 + 64 fp8 copies of hi / 128 and lo x 8;
+//                 the k loop alternates H stages (two 16x16x32 fp16 MFMAs per accumulator tile) and X stages (one
+//                 16x16x128 fp8 MFMA: A = [hi8 | lo8], B = [lo8 | hi8], block scales 2^4 x 2^0 put it in the
+//                 accumulator's units).  Same staging, same 128 bytes per row and line, same LDS reads.
 // on v_mfma_f32_16x16x32_bf16 / _f16, which run 16x the f32-input MFMA rate; a single bf16
 // product (2.7e-4) is nowhere near the 1e-5 parity bar.
 //
@@ -146,6 +153,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
     unsigned long long* __restrict__ diag, const EdgeSink es) {
     const int accumulate = flags & 1;  // later k chunks add to what the earlier ones left in C; bits 8..: tile order shape
     static_assert(WAVES == 8 || (WAVES == 4 && NPROD == 3), "4-wave geometry: three products only");
+    static_assert(NPROD != 2 || (std::is_same<T, _Float16>::value && WAVES == 8), "f16f8: fp16 hi lines, 8-wave geometry");
     constexpr int WN = WAVES == 8 ? 4 : 2, MT = 8, NT = WAVES == 8 ? 4 : 8, PP = 32 / WAVES;  // waves as 2 x WN, wave tile 128 x 16 NT
     constexpr int WTN = NT * 16;                                                                // wave tile width
     constexpr bool SYM = MODE == SELF;
@@ -289,6 +297,65 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
                 }
             __syncthreads();
             cur ^= 1;
+        }
+    } else if constexpr (WAVES == 8 && NPROD == 2) {
+        // f16f8: lines alternate H (64 fp16 hi values of 64 columns) and X ([64 x hi8 | 64 x lo8] of the same columns); kt
+        // (lines) is even for every width this layout exists for.  Per accumulator: hi*hi of columns 0-31, of 32-63, then
+        // the 128 cross products of the 64 columns in one instruction.
+        typedef int i32x8v __attribute__((ext_vector_type(8)));
+        typedef int i32x4v __attribute__((ext_vector_type(4)));
+        constexpr int kScaleA = 0x83838383, kScaleB = 0x7f7f7f7f;  // E8M0 block scales 2^4 and 2^0, the same in every lane
+        for (int64_t t = 0; t < kt; t += 2) {
+            {   // H stage
+                if (t + 1 < kt) stage(cur ^ 1, t + 1);
+                const char* base = smem + cur * kStageBytes;
+                vec8<T> a0[MT], a1[MT], b0[NT], b1[NT];
+#pragma unroll
+                for (int i = 0; i < NT; i++) {
+                    b0[i] = *reinterpret_cast<const vec8<T>*>(base + b_off[i] + ((q ^ b_swz[i]) << 4));
+                    b1[i] = *reinterpret_cast<const vec8<T>*>(base + b_off[i] + (((4 + q) ^ b_swz[i]) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < MT; i++) {
+                    a0[i] = *reinterpret_cast<const vec8<T>*>(base + a_off[i] + ((q ^ a_swz[i]) << 4));
+                    a1[i] = *reinterpret_cast<const vec8<T>*>(base + a_off[i] + (((4 + q) ^ a_swz[i]) << 4));
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) {
+                        acc[mt][nt] = mfma16x16(a0[mt], b0[nt], acc[mt][nt]);
+                        acc[mt][nt] = mfma16x16(a1[mt], b1[nt], acc[mt][nt]);
+                    }
+                __syncthreads();
+                cur ^= 1;
+            }
+            if (t + 1 < kt) {   // X stage
+                if (t + 2 < kt) stage(cur ^ 1, t + 2);
+                const char* base = smem + cur * kStageBytes;
+                i32x8v a8[MT], b8[NT];
+                const int qa = 2 * q, qb = 2 * (q ^ 2);  // A lane group q reads bytes 32q.., B the other half of the line
+#pragma unroll
+                for (int i = 0; i < NT; i++) {
+                    const i32x4v lo4 = *reinterpret_cast<const i32x4v*>(base + b_off[i] + ((qb ^ b_swz[i]) << 4));
+                    const i32x4v hi4 = *reinterpret_cast<const i32x4v*>(base + b_off[i] + (((qb + 1) ^ b_swz[i]) << 4));
+                    b8[i] = i32x8v{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                }
+#pragma unroll
+                for (int i = 0; i < MT; i++) {
+                    const i32x4v lo4 = *reinterpret_cast<const i32x4v*>(base + a_off[i] + ((qa ^ a_swz[i]) << 4));
+                    const i32x4v hi4 = *reinterpret_cast<const i32x4v*>(base + a_off[i] + (((qa + 1) ^ a_swz[i]) << 4));
+                    a8[i] = i32x8v{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8[mt], b8[nt], acc[mt][nt], 0, 0, 0, kScaleA, 0,
+                                                                                       kScaleB);
+                __syncthreads();
+                cur ^= 1;
+            }
         }
     } else if constexpr (WAVES == 8) {
         for (int64_t t = 0; t < kt; t++) {
@@ -694,6 +761,9 @@ int skr_launch_gemm_split(skr_ctx* ctx, int precision, const void* As, const voi
         case SKR_PREC_F16X3:
             return gemm_split<_Float16, 3>(ctx, (const _Float16*)As, (const _Float16*)Bs, o, M, N, kt, K, mode,
                                            "pearson_gemm_f16x3", coherent);
+        case SKR_PREC_F16F8:
+            return gemm_split<_Float16, 2>(ctx, (const _Float16*)As, (const _Float16*)Bs, o, M, N, kt, K, mode,
+                                           "pearson_gemm_f16f8", coherent);
         default: return skr_set_error(SKR_ERR_INVALID, "not a split precision: %d", precision);
     }
 }
@@ -713,6 +783,9 @@ int skr_launch_gemm_edges(skr_ctx* ctx, int precision, const void* As, const voi
         case SKR_PREC_F16X3:
             return gemm_split<_Float16, 3>(ctx, (const _Float16*)As, (const _Float16*)Bs, o, M, N, kt, K, EDGES,
                                            "pearson_gemm_f16x3", coherent, &sink);
+        case SKR_PREC_F16F8:
+            return gemm_split<_Float16, 2>(ctx, (const _Float16*)As, (const _Float16*)Bs, o, M, N, kt, K, EDGES,
+                                           "pearson_gemm_f16f8", coherent, &sink);
         default: return skr_set_error(SKR_ERR_INVALID, "not a split precision: %d", precision);
     }
 }

@@ -34,9 +34,9 @@ def _precision_for(dtype, row_standardize=True):
     if dtype == np.float64:
         return _lib.PREC_F64
     name = os.environ.get("SEEKR_PRECISION", "f16x3").lower()
-    if name not in ("fp32", "bf16x3", "bf16x4", "f16x3"):
-        raise ValueError("SEEKR_PRECISION must be fp32, bf16x3, bf16x4 or f16x3, got {!r}".format(name))
-    if name == "f16x3" and not row_standardize:
+    if name not in ("fp32", "bf16x3", "bf16x4", "f16x3", "f16f8"):
+        raise ValueError("SEEKR_PRECISION must be fp32, bf16x3, bf16x4, f16x3 or f16f8, got {!r}".format(name))
+    if name in ("f16x3", "f16f8") and not row_standardize:
         name = "fp32"  # arbitrary magnitudes: outside fp16's range / inside its subnormals
     return _lib.PRECISIONS[name]
 

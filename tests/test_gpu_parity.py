@@ -1234,3 +1234,159 @@ def test_rows_are_standardised_in_numpys_summation_order(L, ctx):
             worst = max(worst, ratio)
             assert ratio <= 1.0, (K, scale, ratio, ref_off)
     assert worst <= 1.0
+
+
+# ------------------------------------------------------------------ round 4: new counting paths
+def _with_knobs(ctx, env, fn):
+    """Run fn() with A/B knobs set (the ctx reads them once: reload before and after)."""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    ctx.reload_knobs()
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        ctx.reload_knobs()
+
+
+@pytest.mark.parametrize("alphabet,k", [("ACGTN", 6), ("ACGTN", 2), ("ARNDCQEGHILKMFPSTWYV", 3), ("AT", 7), ("AGTA", 5), ("T", 4),
+                                        ("ACGTRYN", 4)])
+def test_any_alphabet_counts_in_the_lds(alphabet, k, L, ctx):
+    """Round 4: up to 16 384 columns the any-alphabet counter keeps its histogram in the LDS (count_generic_lds_kernel) and
+    counts from sequences RESIDENT on the device (skr_aseqs).  Integer counts, float32 / float64 per-kb values and the
+    Log2.pre form bit-exact against the oracle (kmer_counts.py:120-122,140-151) — sequences longer than one LDS chunk
+    (4 096 characters), shorter than k, empty, with letters outside the alphabet, lower case — and identical to the
+    round-1 path (histogram in HBM, SEEKR_COUNT_GENERIC_GLOBAL=1)."""
+    rng = np.random.default_rng(len(alphabet) * 100 + k)
+    pool = np.array(sorted(set(alphabet + "Nxa")))
+    seqs = ["".join(rng.choice(pool, size=int(n))) for n in (0, 1, k - 2 if k > 2 else 3, k, k + 1, 77, 1999, 4095, 4096, 4097,
+                                                            4096 + k - 1, 9000, 20011)]
+    seqs = [s for s in seqs if len(s) != k - 1] + [alphabet[0] * 5000, (alphabet * 900)[:8200]]
+    want_n = orc.count_kmers_u32(seqs, k, alphabet)
+    assert np.array_equal(L.count_generic(ctx, seqs, alphabet, k, np.uint32).to_numpy(), want_n)
+    want = orc.raw_counts(seqs, k, alphabet)
+    assert_bits(L.count_generic(ctx, seqs, alphabet, k, np.float32).to_numpy(), want, "float32")
+    got64 = L.count_generic(ctx, seqs, alphabet, k, np.float64).to_numpy()
+    assert np.array_equal(got64, orc.per_kb_from_counts(want_n, [len(s) for s in seqs], k, dtype=np.float64))
+    # resident handle: several calls on one upload, into a matrix the caller owns
+    lengths = np.array([len(s) for s in seqs], dtype=np.int64)
+    offsets = np.concatenate([[0], np.cumsum(lengths)])
+    a = L.AsciiSeqs(ctx, "".join(seqs).encode("latin-1"), offsets)
+    out = ctx.empty(len(seqs), len(alphabet) ** k)
+    for _ in range(2):
+        L.count_generic_dev(ctx, a, alphabet, k, out=out)
+        assert_bits(out.to_numpy(), want, "resident")
+    pre = L.count_generic_dev(ctx, a, alphabet, k, log2_pre=True).to_numpy()
+    old = _with_knobs(ctx, {"SEEKR_COUNT_GENERIC_GLOBAL": "1"},
+                      lambda: (L.count_generic_dev(ctx, a, alphabet, k).to_numpy(), L.count_generic_dev(ctx, a, alphabet, k, log2_pre=True).to_numpy()))
+    assert_bits(old[0], want, "round-1 path")
+    assert_bits(pre, old[1], "Log2.pre: LDS path == round-1 path")
+    a.free()
+
+
+def test_any_alphabet_rows_without_a_window_after_other_work(L, ctx):
+    """Regression (round 4, found by the differential fuzzer 165 cases into a soak): a sequence shorter than k - 1 has no
+    window, hence no chunk and — before the fix — no barrier between the 16 lanes that build the per-sequence value
+    table and the waves that flush the row; as the FIRST sequence of its workgroup it read the table from whatever the
+    LDS held.  Every workgroup here gets exactly one such sequence, right after a launch that leaves the LDS dirty."""
+    alphabet, k = "ACGTRYN", 4
+    dirty = L.count_generic(ctx, ["ACGTRYN" * 600] * 600, alphabet, k, np.float32, log2_pre=True)
+    dirty.free()
+    seqs = ["AC", "", "A", "GT", "NN", "ac"] * 40
+    for log2_pre in (False, True):
+        got = L.count_generic(ctx, seqs, alphabet, k, np.float32, log2_pre=log2_pre).to_numpy()
+        assert not got.any(), (log2_pre, float(np.abs(got).max()))
+    assert not L.count_generic(ctx, seqs, alphabet, k, np.uint32).to_numpy().any()
+
+
+def test_k8_counts_in_the_lds_like_the_round_1_path(L, ctx):
+    """Round 4: k = 8 on the tuned kernel (65 536 sixteen-bit bins = 128 KiB of LDS, one 4-wave workgroup per CU); the
+    same bits as the histogram-in-HBM path it replaces, incl. N runs, a homopolymer and a sequence cut into 8 192-window
+    tiles."""
+    k = 8
+    seqs = orc.codes_to_seqs(orc.synthetic_codes(8, 40, 3000)) + ["ACGTN" * 900, "G" * 6000, "ACGT" * 3, "AC", "ACGTAC",
+                                                                 "".join(orc.codes_to_seqs(orc.synthetic_codes(9, 1, 30000)))]
+    packed = ctx.pack(seqs)
+    n_new = L.count_u32(ctx, packed, k).to_numpy()
+    x_new = L.count_per_kb(ctx, packed, k).to_numpy()
+    n_old, x_old = _with_knobs(ctx, {"SEEKR_COUNT_K8_GLOBAL": "1"},
+                               lambda: (L.count_u32(ctx, packed, k).to_numpy(), L.count_per_kb(ctx, packed, k).to_numpy()))
+    assert np.array_equal(n_new, n_old) and np.array_equal(n_new, orc.count_kmers_u32(seqs, k))
+    assert_bits(x_new, x_old, "k = 8 per-kb")
+
+
+@pytest.mark.parametrize("k,length", [(6, 2000), (5, 900), (7, 5000), (3, 300)])
+def test_counting_kernel_ab_knobs_give_the_same_bits(k, length, L, ctx):
+    """The A/B arms of the row flush (tools/count_bench.py: SEEKR_COUNT_FLUSH 1 = row in ascending address order, 2 = the
+    same with ordinary stores; SEEKR_COUNT_OCC = fewer one-wave workgroups per CU) only move stores around."""
+    seqs = orc.codes_to_seqs(orc.synthetic_codes(k, 300, length)) + ["A" * (length + 7), "ACGTN" * 50, "AC" * 40]
+    packed = ctx.pack(seqs)
+    base = L.count_per_kb(ctx, packed, k).to_numpy()
+    assert_bits(base, orc.raw_counts(seqs, k), "base")
+    for env in ({"SEEKR_COUNT_FLUSH": "1"}, {"SEEKR_COUNT_FLUSH": "2"}, {"SEEKR_COUNT_OCC": "10"},
+                {"SEEKR_COUNT_FLUSH": "1", "SEEKR_COUNT_OCC": "12"}):
+        got = _with_knobs(ctx, env, lambda: L.count_per_kb(ctx, packed, k).to_numpy())
+        assert_bits(got, base, str(env))
+        pre = _with_knobs(ctx, env, lambda: L.count_per_kb(ctx, packed, k, log2_pre=True).to_numpy())
+        assert_bits(pre, L.count_per_kb(ctx, packed, k, log2_pre=True).to_numpy(), "log2 " + str(env))
+
+
+@pytest.mark.parametrize("K,rows,W", [(4096, 1500, 1995), (1024, 1200, 996), (16384, 500, 4993)])
+def test_two_product_unit_precision_f16f8(K, rows, W, L, ctx):
+    """Round 4, opt-in SKR_PREC_F16F8: hi x hi on the fp16 MFMA and both cross terms as ONE block-scaled fp8 MFMA (two
+    product-units per k instead of three).  On Log2.post-normalised counts (the pipeline's data) the operand keeps the
+    H / X line layout (kind 3) and r is inside the bar against the reference's float32 result AND against float64; raw
+    counts (few-valued rows: the fp8 roundings of a repeated value add up) are detected in the fill and served by the
+    three-product split, bit for bit what f16x3 gives; every other width degrades the same way."""
+    rng = np.random.default_rng(K)
+    raw = (rng.binomial(W, 1.0 / K, size=(rows, K)) * (1000.0 / W)).astype(np.float32)
+    with np.errstate(all="ignore"):
+        x = np.ascontiguousarray(orc.normalize(raw.copy(), True, True, "Log2.post")[0], dtype=np.float32)
+    assert np.isfinite(x).all()
+    with np.errstate(all="ignore"):
+        ref, truth = orc.pearson(x, x).astype(np.float64), orc.pearson_f64_truth(x, x)
+    dev = ctx.from_numpy(x)
+    op, _ = L.operand_fill(ctx, dev, precision=L.PREC_F16F8, row_standardize=True)
+    assert op.kind == 3
+    r = ctx.empty(rows, rows)
+    L.pearson_gemm_op(ctx, op, op, r, symmetric=True)
+    got = r.to_numpy().astype(np.float64)
+    strict = np.abs(got - ref) / (2e-6 + 1e-5 * np.abs(ref))
+    vs64 = np.abs(got - truth) / (2e-6 + 1e-5 * np.abs(truth))
+    assert strict.max() <= 1.0 and vs64.max() <= 1.0, (float(strict.max()), float(vs64.max()))
+    assert np.array_equal(got, got.T)                       # the mirrored triangle
+    # a plain (non-symmetric) block of the same operands: same values as the self block off the diagonal tiles
+    r2 = ctx.empty(rows, rows)
+    L.pearson_gemm_op(ctx, op, op.view(0, rows), r2, symmetric=False)
+    g2 = r2.to_numpy().astype(np.float64)
+    assert (np.abs(g2 - truth) / (2e-6 + 1e-5 * np.abs(truth))).max() <= 1.0
+    # few-valued rows: degraded to the three-product split by the fill's own flag
+    draw = ctx.from_numpy(raw)
+    op_raw, _ = L.operand_fill(ctx, draw, precision=L.PREC_F16F8, row_standardize=True)
+    op_x3, _ = L.operand_fill(ctx, draw, precision=L.PREC_F16X3, row_standardize=True)
+    assert op_raw.kind in (2, 0) and op_raw.kind == op_x3.kind
+    ra, rb = ctx.empty(rows, rows), ctx.empty(rows, rows)
+    L.pearson_gemm_op(ctx, op_raw, op_raw, ra, symmetric=True)
+    L.pearson_gemm_op(ctx, op_x3, op_x3, rb, symmetric=True)
+    assert np.array_equal(ra.to_numpy().view(np.uint32), rb.to_numpy().view(np.uint32))
+    for m in (dev, draw, r, r2, ra, rb, op, op_raw, op_x3):
+        m.free()
+
+
+def test_f16f8_degrades_on_other_widths_and_through_the_api(L, ctx, monkeypatch):
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((300, 729)).astype(np.float32)
+    op, _ = L.operand_fill(ctx, ctx.from_numpy(x), precision=L.PREC_F16F8, row_standardize=True)
+    assert op.kind == 2                                      # no H / X layout for 729 columns: split-fp16
+    from seekr_amd.pearson import pearson
+    y = rng.standard_normal((400, 4096)).astype(np.float32)
+    want = orc.pearson(y, y)
+    monkeypatch.setenv("SEEKR_PRECISION", "f16f8")
+    got = pearson(y, y)
+    assert np.allclose(got, want, rtol=RTOL, atol=ATOL_R)
+    got2 = pearson(y, y[:100] * np.float32(3.0) + np.float32(1.0))
+    assert np.allclose(got2, want[:, :100], rtol=RTOL, atol=ATOL_R)

@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--rows", type=int, default=1024)
     ap.add_argument("--json", default="")
     ap.add_argument("--cols", type=int, nargs="*", default=[256, 4096, 16384])
+    ap.add_argument("--f16f8", action="store_true", help="also run the opt-in two-product-unit precision (SKR_PREC_F16F8) and print "
+                    "the storage kind its operand ended with (3 = H / X lines, 2 = degraded to the three-product split, 0 = fp32)")
     args = ap.parse_args()
     ctx = _lib.default_context()
     table = []
@@ -73,13 +75,26 @@ def main():
                     strict, e_dev, e_ref = ratios(got, ref, truth)
                     row[prec] = {"strict": round(strict, 3), "vs_f64": round(e_dev, 3)}
                     row["ref_vs_f64"] = round(e_ref, 3)
+                if args.f16f8:
+                    op, _ = _lib.operand_fill(ctx, dev, precision=_lib.PREC_F16F8, row_standardize=True)
+                    r8 = ctx.empty(dev.rows, dev.rows)
+                    _lib.pearson_gemm_op(ctx, op, op, r8, symmetric=True)
+                    strict, e_dev, _ = ratios(r8.to_numpy(), ref, truth)
+                    row["f16f8"] = {"strict": round(strict, 3), "vs_f64": round(e_dev, 3), "operand_kind": op.kind}
+                    r8.free()
+                    op.free()
                 dev.free()
                 table.append(row)
                 print("%-22s %-9s %6d | %8.3f        (%6.3f)      | %8.3f        (%6.3f)      | %6.3f"
                       % (name, form, k, row["f16x3"]["strict"], row["f16x3"]["vs_f64"], row["fp32"]["strict"], row["fp32"]["vs_f64"],
-                         row["ref_vs_f64"]), flush=True)
+                         row["ref_vs_f64"])
+                      + ("   | f16f8: strict %.3f (vs f64 %.3f), operand kind %d" % (row["f16f8"]["strict"], row["f16f8"]["vs_f64"],
+                                                                                  row["f16f8"]["operand_kind"]) if args.f16f8 else ""), flush=True)
     worst = max(r["f16x3"]["strict"] for r in table)
     print("strict parity: worst f16x3 cell %.3f of the bar over %d grid points -> %s" % (worst, len(table), "ok" if worst <= 1 else "EXCEEDED"))
+    if args.f16f8:
+        w8 = max(r["f16f8"]["strict"] for r in table)
+        print("strict parity, f16f8 (routing included): worst cell %.3f of the bar -> %s" % (w8, "ok" if w8 <= 1 else "EXCEEDED"))
     if args.json:
         with open(args.json, "w") as fh:
             json.dump({"bar": "|got - oracle.pearson| <= 2e-6 + 1e-5 |ref|", "grid": table, "worst_f16x3": worst}, fh, indent=1)
