@@ -69,6 +69,8 @@ def parse(argv=None):
                     help="Pearson contraction arithmetic; every choice is inside the parity bar "
                          "|dr| <= 2e-6 + 1e-5|r| (tests/test_gpu_parity.py) on the bench data; f16x3 carries float32-grade operands, bf16x3 is ~5 % faster")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f16f8-arm", action="store_true", help="skip the opt-in two-product-unit contraction's extra measurement "
+                    "after the timed region (f16f8_arm in the line)")
     ap.add_argument("--no-symmetry", action="store_true",
                     help="compute both triangles of the self-comparison block instead of mirroring one")
     ap.add_argument("--grouped-shifts", action="store_true",
@@ -683,6 +685,42 @@ def run_rank(args):
         out["verified"] = bool(ok)
         out["verified_detail"] = {"rows": min(32, n_loc), "columns": n_total, "worst_error_over_bar": round(worst, 4),
                                   "bar": "|dr| <= 2e-6 + 1e-5 |r| against oracle.pearson (pearson.py:35-41)"}
+    if size == 1 and args.precision == "f16x3" and not generic and k in (6, 7) and not args.no_symmetry and not args.no_f16f8_arm:
+        # The opt-in two-product-unit contraction (SKR_PREC_F16F8), measured in the same run AFTER the timed
+        # region and never part of `value`: the same step with the other operand layout, the same number of steps,
+        # the same verification against the oracle.
+        engine8 = HipEngine(ctx, _lib.PRECISIONS["f16f8"])
+        z8 = engine8.empty_operand(n_loc, n_cols)
+
+        def step8():
+            _lib.count_per_kb(ctx, packed, k, out=x)
+            zz = sharded_normalize_prepare(engine8, comm, x, n_total, "Log2.post", True, True, keep_counts=True, op=z8)[3]
+            sharded_pearson_symmetric(engine8, comm, zz, bounds, r, None, [None, None])
+            return zz
+
+        for _ in range(max(1, args.warmup)):
+            zz8 = step8()
+        ctx.sync()
+        ctx.prof_reset()
+        ctx.prof_enable(True)
+        t8 = time.perf_counter()
+        for _ in range(steps):
+            zz8 = step8()
+        ctx.sync()
+        t8 = time.perf_counter() - t8
+        ctx.prof_enable(False)
+        kern8 = exclusive_kernel_times(ctx)
+        ok8, worst8 = verify_rows(ctx, r, x.to_numpy())
+        g8 = kern8.get("pearson_gemm_f16f8", {"ms_total": 0.0})["ms_total"] / steps
+        out["f16f8_arm"] = {
+            "value": round(pairs_per_step * steps / t8 / 1e6, 2), "unit": out["unit"], "ms_per_step": round(t8 / steps * 1e3, 3),
+            "pearson_kernel_ms": round(g8, 4), "operand_kind": zz8.kind,
+            "roofline_frac": round(2.0 * n_cols * float(n_loc) * n_total / (g8 * 1e-3) / 1e12 / peak_tf, 4) if g8 > 0 else None,
+            "verified": bool(ok8), "worst_error_over_bar": round(worst8, 4),
+            "note": "opt-in SEEKR_PRECISION=f16f8: hi x hi on the fp16 MFMA + both cross terms as one block-scaled fp8 MFMA (2 "
+                    "product-units per k instead of 3); measured after the timed region, never part of `value`; operand_kind 3 = "
+                    "the fp8 cross layout was kept, 2 = the fill routed these rows back to the three-product split"}
+        z8.free()
     if size == 1 and not args.no_cpu_baseline and not generic:
         head = x_host[:min(12000 if k <= 6 else 4000, n_loc)]
         cb = cpu_baseline(k, length, head)
@@ -708,6 +746,8 @@ def run_rank(args):
 def main():
     argv = sys.argv[1:]
     args = parse(argv)
+    if args.gpus > 1 and args.precision == "f16f8":
+        raise SystemExit("--precision f16f8 (opt-in) is implemented for one GPU")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch(args, argv))
     run_rank(args)

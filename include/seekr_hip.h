@@ -56,7 +56,7 @@ enum {
     SKR_PREC_BF16X4 = 3, /* split-bf16 with the lo*lo term as well                                */
     SKR_PREC_F16F8 = 5,  /* opt-in (round 4): hi*hi on v_mfma_f32_16x16x32_f16, the two cross terms as ONE block-scaled
                           * fp8 product (v_mfma_scale_f32_16x16x128_f8f6f4): 2 product-units per k instead of 3; for
-                          * row-standardised rows of 1 024 / 4 096 / 16 384 columns, any other shape and rows flagged as
+                          * row-standardised rows of 4 096 / 16 384 columns (k = 6, 7); any other shape and rows flagged as
                           * few-valued fall back to SKR_PREC_F16X3 by themselves                       */
     SKR_PREC_F16X3 = 4   /* split-fp16 (11-bit halves: float32-grade operands), 3 products on    */
                          /* v_mfma_f32_16x16x32_f16.  The host API's default for row-standardised */
@@ -251,7 +251,7 @@ int skr_operand_fill(skr_ctx* ctx, const skr_mat* x, const skr_mat* center, cons
 int skr_operand_kind(const skr_operand* op, int* kind);
 int skr_operand_adopt_layout(skr_operand* op, const skr_operand* like);
 /* get (set = 0) or set (set != 0, from *value) the "rows are mostly one repeated value" flag that makes the
- * split contraction restart its accumulators every 2 048 columns; skr_operand_fill computes it from the rows
+ * split contraction restart its accumulators every 1 024 columns; skr_operand_fill computes it from the rows
  * it sees, a multi-GPU caller all-reduces it so that every shard of a set carries the same value.            */
 int skr_operand_coherent(skr_operand* op, int set, int* value);
 /* r[row0 + i, col0 + j] = <a_i, b_j> / K on prepared operands (same meaning as skr_pearson_gemm) */
@@ -306,14 +306,14 @@ int skr_edges(skr_ctx* ctx, const skr_mat* r, int64_t nrows, int64_t col_begin, 
  * out_vals (U32, U32, F32; global indices = row_global0 + i, col_global0 + j).  Same values, bit for bit, as
  * skr_pearson_gemm_op followed by skr_edges.  *count = cells found; if it exceeds the outputs' capacity nothing is
  * written to them and the caller calls again with larger outputs.  `scratch` (float32, at least [a.rows, b.rows]) is
- * needed only for rows of more than 4 096 columns (2 048 for operands flagged by skr_operand_coherent): the earlier
+ * needed only for rows of more than 4 096 columns (1 024 for operands flagged by skr_operand_coherent): the earlier
  * k chunks leave their partial sums there.  Split-precision operands only (SKR_ERR_UNSUPPORTED otherwise).          */
 int skr_pearson_gemm_edges(skr_ctx* ctx, const skr_operand* a, const skr_operand* b, skr_mat* scratch, int64_t row_global0,
                            int64_t col_global0, float cutoff, int upper_only, skr_mat* out_rows, skr_mat* out_cols,
                            skr_mat* out_vals, int64_t* count);
 
 /* *needs = 1 when skr_pearson_gemm_edges(a, b, ...) must be given a scratch block, i.e. when the rows span more than
- * one accumulator restart of the contraction — the library's own rule (4 096 columns; 2 048 for operands flagged by
+ * one accumulator restart of the contraction — the library's own rule (4 096 columns; 1 024 for operands flagged by
  * skr_operand_coherent; the A/B knob SEEKR_GEMM_CHUNK_TILES as the ctx read it), so that a caller never re-derives it.   */
 int skr_pearson_gemm_edges_needs_scratch(skr_ctx* ctx, const skr_operand* a, const skr_operand* b, int* needs);
 /* Per-row top-k of the block r[0:nrows, col_begin:col_end]: out_idx[i, t] / out_val[i, t] = global

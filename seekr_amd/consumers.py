@@ -217,7 +217,7 @@ def pearson_edges(z, cutoff, stripe_rows=8192, upper_only=True, engine_gemm=None
         use_fused = fused is not None and (fuse is True or seen_edges <= FUSE_MAX_DENSITY * max(seen_cells, 1))
         part = None
         if use_fused:
-            if z.cols > 2048 and buf is None:
+            if z.cols > 1024 and buf is None:
                 buf = ctx.empty(stripe_rows, n)  # k = 7: the earlier k chunks need a block to leave their sums in
             part = fused.block(a, b, cutoff, row_global0=s0, col_global0=c0, upper_only=upper_only, scratch=buf,
                                retry=fuse is True)

@@ -162,11 +162,11 @@ int skr_launch_gemm_f64(skr_ctx* ctx, const double* A, const double* B, double* 
 int skr_launch_gemm_split(skr_ctx* ctx, int precision, const void* As, const void* Bs, float* C, int64_t M, int64_t N,
                           int64_t kt, int64_t ldc, float kdiv, int mode, float* Ct, int64_t ldct, bool coherent = false);
 
-// k tiles per accumulator restart of the split contraction (pearson_bf16.hip: launch16): 128 (4 096 columns), 64 for
+// k tiles per accumulator restart of the split contraction (pearson_bf16.hip: launch16): 128 (4 096 columns), 32 for
 // operands whose rows are mostly one repeated value; SEEKR_GEMM_CHUNK_TILES overrides both.  One rule for the
 // contraction and for every caller that must know whether a launch will have more than one k chunk (fused_edges.hip).
 inline int64_t skr_gemm_chunk_tiles(const skr_ctx* ctx, bool coherent) {
-    return ctx->knobs.gemm_chunk_tiles ? ctx->knobs.gemm_chunk_tiles : (coherent ? 64 : 128);
+    return ctx->knobs.gemm_chunk_tiles ? ctx->knobs.gemm_chunk_tiles : (coherent ? 32 : 128);
 }
 
 // Where the EDGES mode of the split contraction appends the cells that survive a threshold (pearson_bf16.hip).

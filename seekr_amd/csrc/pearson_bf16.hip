@@ -7,9 +7,9 @@
 //     NPROD = 2 : "f16f8" (round 4, opt-in): hi*hi on the fp16 MFMA, and the two cross products hi*lo + lo*hi as ONE
 //                 block-scaled fp8 MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, e4m3) into the same accumulator: two
 //                 product-units per k instead of three.  Operand layout "H / X lines" (operand.hip, kind 3): per 64
-//                 columns one 128-byte line of 64 fp16 hi values and one of 64 + 64 fp8 copies of hi / 128 and lo x 8;
+//                 columns one 128-byte line of 64 fp16 hi values and one of 64 + 64 fp8 copies of hi / 128 and lo x 16;
 //                 the k loop alternates H stages (two 16x16x32 fp16 MFMAs per accumulator tile) and X stages (one
-//                 16x16x128 fp8 MFMA: A = [hi8 | lo8], B = [lo8 | hi8], block scales 2^4 x 2^0 put it in the
+//                 16x16x128 fp8 MFMA: A = [hi8 | lo8], B = [lo8 | hi8], block scales 2^3 x 2^0 put it in the
 //                 accumulator's units).  Same staging, same 128 bytes per row and line, same LDS reads.
 // on v_mfma_f32_16x16x32_bf16 / _f16, which run 16x the f32-input MFMA rate; a single bf16
 // product (2.7e-4) is nowhere near the 1e-5 parity bar.
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
         // the 128 cross products of the 64 columns in one instruction.
         typedef int i32x8v __attribute__((ext_vector_type(8)));
         typedef int i32x4v __attribute__((ext_vector_type(4)));
-        constexpr int kScaleA = 0x83838383, kScaleB = 0x7f7f7f7f;  // E8M0 block scales 2^4 and 2^0, the same in every lane
+        constexpr int kScaleA = 0x82828282, kScaleB = 0x7f7f7f7f;  // E8M0 block scales 2^3 (= 128 / 16) and 2^0, the same in every lane
         for (int64_t t = 0; t < kt; t += 2) {
             {   // H stage
                 if (t + 1 < kt) stage(cur ^ 1, t + 1);
@@ -709,7 +709,7 @@ template <typename T, int NPROD, int MODE>
 int launch16(skr_ctx* ctx, const T* A, const T* B, const SplitOut& o, int64_t M, int64_t N, int64_t kt, float K,
              const char* name, bool coherent, const EdgeSink* sink = nullptr) {
     // One float32 accumulator per cell is restarted every 4 096 columns: the MFMA adder truncates each
-    // add at the accumulator's unit (~0.25 ulp lost per add, measured; `chunk_tiles` = 64, i.e. every 2 048 columns, for
+    // add at the accumulator's unit (~0.25 ulp lost per add, measured; `chunk_tiles` = 32, i.e. every 1 024 columns (64 until round 4: a soak case sat at 0.75 of the bar with 64, 0.20 with 32), for
     // operands whose rows are mostly one repeated value: tools/margin_probe.py), a bias that grows with the number
     // of adds and with the accumulator — 5e-6 relative on an r ~ 1 pair at K = 4 096, four times that at
     // 16 384 in one go.  Later chunks add their partial result to C in the epilogue (rounded float32 adds).

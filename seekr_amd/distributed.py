@@ -385,6 +385,10 @@ def sharded_normalize_prepare(engine, comm, x, n_total, log2="Log2.post", mean=T
     """sharded_normalize fused with the Pearson preparation: one pass writes the normalised
     counts (into `x`, when keep_counts) and the row-standardised operand.
     Returns (mean_vec, std_vec, has_nan, operand)."""
+    if comm.size > 1 and getattr(engine, "precision", None) == _lib.PREC_F16F8:
+        # a rank whose rows route back to the three-product split would have to make every other rank follow; the
+        # all-reduced layout flag exists for the float32 fallback only
+        raise NotImplementedError("SKR_PREC_F16F8 (opt-in) is implemented for one GPU; use f16x3 across ranks")
     center, scale, post, shift = sharded_stats(engine, comm, x, n_total, log2, mean, std)
     operand, has_nan = engine.prepare(x, center, scale, post, shift, keep_counts=keep_counts, op=op)
     # A rank whose rows need more dynamic range than the split contraction has (skr_operand_kind) comes
@@ -618,7 +622,7 @@ def sharded_pearson_edges(engine, comm, z, bounds, cutoff, stripe_rows=8192, upp
         use_fused = fused is not None and (fuse is True or seen_edges <= FUSE_MAX_DENSITY * max(seen_cells, 1))
         part = None
         if use_fused:
-            if engine.cols(full) > 2048 and buf is None:
+            if engine.cols(full) > 1024 and buf is None:
                 buf = engine.empty_block(stripe_rows, n_total)  # k = 7: the earlier k chunks leave their sums here
             part = fused.block(a, b, cutoff, row_global0=s0, col_global0=c0, upper_only=upper_only, scratch=buf,
                                retry=fuse is True)

@@ -87,3 +87,32 @@ def test_constructed_worst_case_k16384_through_the_block_fill_kernel():
     truth = orc.pearson_f64_truth(x, x)
     err = np.abs(r.to_numpy() - truth)
     assert (err <= 2e-6 + 1e-5 * np.abs(truth)).all(), float((err / (2e-6 + 1e-5 * np.abs(truth))).max())
+
+
+def test_regression_rows_that_repeat_a_value_other_than_their_minimum(golden_dir):
+    """Found 24 598 cases into round 4's soak under the strict rule: k = 4 over ACGTRYN (2 401 columns, 89 % of them
+    structurally empty), Log2.pre, centred only — every row is 89 % ZEROS, but zero is not its minimum, so the fill's
+    "mostly one repeated value" flag (share of the row MINIMUM) stayed down, the contraction kept 128-tile accumulator
+    chunks and r = -0.4623 came out 1.07 bars from float64 and from the reference (which was 0.01 from float64).  The
+    flag now also rises when 70 % of the neighbouring cells are equal, whatever the value."""
+    import contextlib
+    import io
+    import os
+    import numpy as np
+    from oracle import seekr_oracle as orc
+    from seekr_amd.kmer_counts import BasicCounter
+    from seekr_amd.pearson import pearson
+    d = np.load(os.path.join(golden_dir, "regress_r4_soak_k4_acgtryn.npz"), allow_pickle=True)
+    seqs, tag = list(d["seqs"]), eval(str(d["tag"][0]))
+    c = BasicCounter(silent=True, k=tag["k"], alphabet=tag["alphabet"], mean=tag["mean"], std=tag["std"], log2=tag["log2"])
+    c.seqs = seqs
+    with contextlib.redirect_stdout(io.StringIO()):
+        c.get_counts()
+    x = np.array(c.counts, dtype=np.float32)
+    assert x.shape == (12, 2401) and (x[2] == 0).mean() > 0.85 and x[2].min() < 0
+    with np.errstate(all="ignore"):
+        ref, truth = orc.pearson(x, x).astype(np.float64), orc.pearson_f64_truth(x, x)
+    got = pearson(x, x).astype(np.float64)
+    ok = np.isfinite(ref)
+    assert (np.abs(got - ref)[ok] <= (2e-6 + 1e-5 * np.abs(ref))[ok]).all()
+    assert (np.abs(got - truth)[ok] <= 0.5 * (2e-6 + 1e-5 * np.abs(truth))[ok]).all()

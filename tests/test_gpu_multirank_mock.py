@@ -285,7 +285,7 @@ def test_every_rank_switches_when_one_needs_the_fp32_kernel(mock_lib, tmp_path):
 
 def test_coherent_flag_is_global(mock_lib, tmp_path):
     """only the last rank holds rows that are mostly one repeated value.  Its flag (skr_operand_coherent)
-    is all-reduced, so every rank restarts the accumulators of every block every 2 048 columns; at K = 16 384 the
+    is all-reduced, so every rank restarts the accumulators of every block every 1 024 columns; at K = 16 384 the
     uncorrected accumulation of a cross block would sit at 1.04 x the bar (tools/margin_probe.py)."""
     from coherent_case import coherent_matrix
     from oracle import seekr_oracle as orc

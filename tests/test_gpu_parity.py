@@ -1335,7 +1335,7 @@ def test_counting_kernel_ab_knobs_give_the_same_bits(k, length, L, ctx):
         assert_bits(pre, L.count_per_kb(ctx, packed, k, log2_pre=True).to_numpy(), "log2 " + str(env))
 
 
-@pytest.mark.parametrize("K,rows,W", [(4096, 1500, 1995), (1024, 1200, 996), (16384, 500, 4993)])
+@pytest.mark.parametrize("K,rows,W", [(4096, 1500, 1995), (16384, 500, 4993)])
 def test_two_product_unit_precision_f16f8(K, rows, W, L, ctx):
     """Round 4, opt-in SKR_PREC_F16F8: hi x hi on the fp16 MFMA and both cross terms as ONE block-scaled fp8 MFMA (two
     product-units per k instead of three).  On Log2.post-normalised counts (the pipeline's data) the operand keeps the
@@ -1379,9 +1379,10 @@ def test_two_product_unit_precision_f16f8(K, rows, W, L, ctx):
 
 def test_f16f8_degrades_on_other_widths_and_through_the_api(L, ctx, monkeypatch):
     rng = np.random.default_rng(3)
-    x = rng.standard_normal((300, 729)).astype(np.float32)
-    op, _ = L.operand_fill(ctx, ctx.from_numpy(x), precision=L.PREC_F16F8, row_standardize=True)
-    assert op.kind == 2                                      # no H / X layout for 729 columns: split-fp16
+    for cols in (729, 1024):
+        x = rng.standard_normal((300, cols)).astype(np.float32)
+        op, _ = L.operand_fill(ctx, ctx.from_numpy(x), precision=L.PREC_F16F8, row_standardize=True)
+        assert op.kind == 2                                  # no H / X layout below 4 096 columns: split-fp16
     from seekr_amd.pearson import pearson
     y = rng.standard_normal((400, 4096)).astype(np.float32)
     want = orc.pearson(y, y)

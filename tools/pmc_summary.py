@@ -11,7 +11,7 @@ import bench  # noqa: E402  (stdlib + numpy only at import time)
 
 out_dir, prec = sys.argv[1], sys.argv[2]
 extra = sys.argv[3:]  # the extra bench.py arguments the passes ran with (tools/profile.sh)
-is_bench = prec in ("fp32", "bf16x3", "bf16x4", "f16x3")  # else: the passes ran another program (tools/pmc_gemm.sh)
+is_bench = prec in ("fp32", "bf16x3", "bf16x4", "f16x3", "f16f8")  # else: the passes ran another program (tools/pmc_gemm.sh)
 b_args = bench.parse(["--precision", prec] + extra) if is_bench else None
 rows = (b_args.rows or 50000) if is_bench else 0
 acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))

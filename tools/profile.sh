@@ -23,7 +23,7 @@ timeout -k 10 $T_TRACE rocprofv3 --kernel-trace --stats --output-format csv -d "
 i=0
 for group in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
              "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE" \
-             "SQ_INSTS_VALU_MFMA_MOPS_F16" \
+             "SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F8" \
              "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY"; do
     i=$((i + 1))
     # shellcheck disable=SC2086
