@@ -151,7 +151,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
     int64_t M, int64_t N, int64_t kt, int64_t ldc, int64_t ldct, float kdiv, int64_t tiles_m, int64_t tiles_n,
     int64_t super_n, uint32_t* __restrict__ queues, int64_t slots_per_queue, int64_t pitch_tiles, int flags,
     unsigned long long* __restrict__ diag, const EdgeSink es) {
-    const int accumulate = flags & 1;  // later k chunks add to what the earlier ones left in C; bits 8..: tile order shape
+    const int accumulate = flags & 1;  // later k chunks add to what the earlier ones left in C; bit 1: last chunk; bits 8..: tile order shape
     static_assert(WAVES == 8 || (WAVES == 4 && NPROD == 3), "4-wave geometry: three products only");
     static_assert(NPROD != 2 || (std::is_same<T, _Float16>::value && WAVES == 8), "f16f8: fp16 hi lines, 8-wave geometry");
     constexpr int WN = WAVES == 8 ? 4 : 2, MT = 8, NT = WAVES == 8 ? 4 : 8, PP = 32 / WAVES;  // waves as 2 x WN, wave tile 128 x 16 NT
@@ -556,7 +556,37 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
         if (!PERSIST) return;
         continue;
     }
-    const bool mirror = (MODE == CROSS || (SYM && tm != tn)) && !(DIAG && (diag[1] & 4));  // DIAG flag 4: timing without the mirror stores
+    // The mirror (SELF: the tile below the diagonal; CROSS: the transposed block in Ct) is written by the LAST k chunk only,
+    // as a copy of the finished value: the earlier chunks of a K > 4 096 call then neither store nor re-load it (round 4;
+    // counters had the accumulating chunks of a k = 7 self-comparison 16 % slower than the first one, the waves parked on
+    // the mirror's loads — 16 rows x 64 bytes per instruction — while a PLAIN block paid 1.7 %: DESIGN §4).
+    const bool last_chunk = (flags & 2) != 0;
+    const bool mirror = (MODE == CROSS || (SYM && tm != tn)) && last_chunk && !(DIAG && (diag[1] & 4));  // DIAG flag 4: timing without the mirror stores
+    auto quad_transpose = [&](float (&v)[4], int j) {  // 4 x 4 inside each quad of lanes; its own inverse
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+            const float send = (j & 1) ? v[e] : v[e + 1];
+            const float recv = __shfl_xor(send, 1, 64);
+            if (j & 1) v[e] = recv; else v[e + 1] = recv;
+        }
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const float send = (j & 2) ? v[e] : v[e + 2];
+            const float recv = __shfl_xor(send, 2, 64);
+            if (j & 2) v[e] = recv; else v[e + 2] = recv;
+        }
+    };
+    auto store_mirror = [&](const float (&v)[4], int64_t n, int64_t m0) {  // r[n, m0..m0+3]: the lane's 4 rows are contiguous in the mirror
+        if (n >= N) return;
+        float* dst = Ct + (size_t)n * ldct + m0;
+        if (m0 + 3 < M && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+            __builtin_nontemporal_store(f32x4v{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4v*>(dst));
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (m0 + e < M) dst[e] = v[e];
+        }
+    };
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
@@ -579,34 +609,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
                     }
                 }
             } else {
-                if (mirror && n < N) {  // r[n, m0..m0+3]: the lane's 4 rows are contiguous in the mirror
-                    float* dst = Ct + (size_t)n * ldct + m0;
-                    if (m0 + 3 < M && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
-                        f32x4v w{v[0], v[1], v[2], v[3]};
-                        if (accumulate) w += *reinterpret_cast<const f32x4v*>(dst);
-                        __builtin_nontemporal_store(w, reinterpret_cast<f32x4v*>(dst));
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; e++)
-                            if (m0 + e < M) dst[e] = accumulate ? dst[e] + v[e] : v[e];
-                    }
-                }
+                if (mirror && !accumulate) store_mirror(v, n, m0);  // a single-chunk call: the value is final as it stands
                 // direct tile: transpose 4x4 inside each quad of lanes (lane j of a quad ends up with
                 // row m0+j, columns c0..c0+3) so it is written with 16-byte stores too — the epilogue
                 // is store-issue bound and this quarters its instruction count
                 const int j = lane & 3;
-#pragma unroll
-                for (int e = 0; e < 4; e += 2) {
-                    const float send = (j & 1) ? v[e] : v[e + 1];
-                    const float recv = __shfl_xor(send, 1, 64);
-                    if (j & 1) v[e] = recv; else v[e + 1] = recv;
-                }
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    const float send = (j & 2) ? v[e] : v[e + 2];
-                    const float recv = __shfl_xor(send, 2, 64);
-                    if (j & 2) v[e] = recv; else v[e + 2] = recv;
-                }
+                quad_transpose(v, j);
                 const int64_t mrow = m0 + j, ncol = n - j;
                 float* dst = C + (size_t)mrow * ldc + ncol;
                 if (mrow < M) {
@@ -614,11 +622,20 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
                         f32x4v w{v[0], v[1], v[2], v[3]};
                         if (accumulate) w += *reinterpret_cast<const f32x4v*>(dst);
                         __builtin_nontemporal_store(w, reinterpret_cast<f32x4v*>(dst));
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = w[e];
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; e++)
-                            if (ncol + e < N) dst[e] = accumulate ? dst[e] + v[e] : v[e];
+                            if (ncol + e < N) {
+                                if (accumulate) v[e] = dst[e] + v[e];
+                                dst[e] = v[e];
+                            }
                     }
+                }
+                if (mirror && accumulate) {  // the last of several chunks: the finished values, back in the accumulator's layout
+                    quad_transpose(v, j);
+                    store_mirror(v, n, m0);
                 }
             }
         }
@@ -720,7 +737,7 @@ int launch16(skr_ctx* ctx, const T* A, const T* B, const SplitOut& o, int64_t M,
         const int64_t ktc = std::min(kChunkTiles, kt - t0);
         const T* Ac = A + t0 * 64;
         const T* Bc = B + t0 * 64;
-        const int accumulate = t0 > 0;
+        const int accumulate = (t0 > 0 ? 1 : 0) | (t0 + kChunkTiles >= kt ? 2 : 0);  // bit 0: add to C; bit 1: the last chunk (writes the mirror)
         if (MODE == EDGES && t0 + kChunkTiles < kt) {
             // not the last k chunk: its partial sums go to C like a plain block; only the last chunk thresholds
             if (!o.C) return skr_set_error(SKR_ERR_INVALID, "rows of %lld k tiles in chunks of %lld need a scratch block", (long long)kt, (long long)kChunkTiles);
