@@ -612,6 +612,12 @@ def run_rank(args):
                 "f16x3": "split16_kernelIDF16_Li3", "f16f8": "split16_kernelIDF16_Li2"}[args.precision]
     wl = workload_key(n_total, length, k, args.precision, size) + (" alphabet=" + args.alphabet if generic else "")
     gemm_traffic, gemm_why = (None, "--no-symmetry") if args.no_symmetry else pmc_traffic(gemm_key, wl, _lib.LIB_PATH)
+    if gemm_traffic and args.precision != "fp32" and n_cols > 4096:
+        # rows of more than 4 096 columns: one launch = one kernel dispatch per 4 096-column k chunk; the summary holds
+        # per-dispatch averages
+        chunks = -(-n_cols // 4096)
+        gemm_traffic = dict(gemm_traffic, bytes=gemm_traffic["bytes"] * chunks, fetch_bytes_corrected=gemm_traffic["fetch_bytes_corrected"] * chunks,
+                            write_bytes=gemm_traffic["write_bytes"] * chunks, dispatches_per_launch=chunks)
     count_traffic, count_why = pmc_traffic("count_generic_lds_kernel<float, false>" if generic else "count_rows_kernel<0", wl,
                                            _lib.LIB_PATH)  # <0, ...>: the float32, non-Log2.pre instantiation
     roofline = {"kernel": gemm_name, "bound": "mfma", "achieved": round(achieved_tf, 2), "peak": peak_tf,

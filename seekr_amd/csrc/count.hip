@@ -557,12 +557,13 @@ int launch_rows(skr_ctx* ctx, const skr_seqs* s, int k, void* out) {
     const bool persistent = ctx->knobs.count_persist == 1;  // A/B knob
     if (!persistent) grid = (unsigned)std::min<int64_t>(s->n, 0x7fffffff);
     size_t lds_launch = lds;
-    // Round 4: at k = 6 the LDS would let 19 one-wave workgroups share a CU; SIXTEEN (four per SIMD, enforced by asking for
-    // 10 KiB of LDS each) write the rows 7-8 % faster behind a contraction — 0.138-0.140 ms against 0.149-0.150 for
-    // 50 000 x 2 kb, 0.76 against 0.70 of 8 TB/s, two runs of tools/count_bench.py --pre gemm (profiles/r4_count_occupancy.log:
-    // 18 and 19 per CU 0.150, 17 and 16 0.139, 15 and 14 0.146, 12 0.160, 8 0.187) — fewer row streams, and none of the
-    // SIMDs holds a fifth wave.  Smaller k (2 KiB of bins and less) are fastest unrestricted.  SEEKR_COUNT_OCC overrides.
-    const int occ = ctx->knobs.count_occ > 0 ? ctx->knobs.count_occ : (WPS == 1 && k == 6 ? 16 : 0);
+    // Round 4: at k = 6 the LDS would let 19 one-wave workgroups share a CU; SEVENTEEN (enforced by asking for 9.25 KiB of
+    // LDS each) write the rows 7-8 % faster behind a contraction — 0.138-0.140 ms against 0.149-0.150 for 50 000 x 2 kb,
+    // 0.76 against 0.70 of 8 TB/s, two runs of tools/count_bench.py --pre gemm (profiles/r4_count_occupancy.log: 18 and 19
+    // per CU 0.150, 17 and 16 0.139, 15 and 14 0.146, 12 0.160, 8 0.187) — fewer row streams, no SIMD with a fifth wave
+    // for long.  Inside the bench step 17 measured 0.141-0.142 ms against 0.144-0.145 for 16 (two runs each), so 17 it is.
+    // Smaller k (2 KiB of bins and less) are fastest unrestricted.  SEEKR_COUNT_OCC overrides.
+    const int occ = ctx->knobs.count_occ > 0 ? ctx->knobs.count_occ : (WPS == 1 && k == 6 ? 17 : 0);
     if (!persistent && occ > 0) {
         lds_launch = std::max(lds, ((size_t)160 * 1024 / (size_t)occ) & ~(size_t)255);
         SKR_TRY(skr_kernel_lds(ctx, reinterpret_cast<const void*>(kern), lds_launch));

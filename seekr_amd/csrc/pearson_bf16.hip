@@ -216,12 +216,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
         a_voff[p] = (uint32_t)(ra * pitch * 2 + chunk * 16);
         b_voff[p] = (uint32_t)(rb * pitch * 2 + chunk * 16);
     }
-    auto stage = [&](int buf, int64_t tile) {
+    auto stage = [&](int buf, int64_t tile, bool half = false) {  // half: diagnostic only (a timing experiment, below)
         char* abase = smem + buf * kStageBytes;
         char* bbase = abase + TM * kRowBytes;
         const uint32_t toff = (uint32_t)tile * kRowBytes;  // folded into the 32-bit lane offset: saddr + voffset form
 #pragma unroll
         for (int p = 0; p < PP; p++) {
+            if (DIAG && half && p >= PP / 2) break;
             lds_dma16(a_tile + (a_voff[p] + toff), abase + (wave * PP + p) * 1024);
             lds_dma16(b_tile + (b_voff[p] + toff), bbase + (wave * PP + p) * 1024);
         }
@@ -305,9 +306,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
         typedef int i32x8v __attribute__((ext_vector_type(8)));
         typedef int i32x4v __attribute__((ext_vector_type(4)));
         constexpr int kScaleA = 0x82828282, kScaleB = 0x7f7f7f7f;  // E8M0 block scales 2^3 (= 128 / 16) and 2^0, the same in every lane
+        // DIAG flag 16 (libseekr_hip_diag.so, timing only): the X line staged HALF — what the loop would cost if that line
+        // carried lo8 alone (hi8 derived from the H line's fp16 values in registers): 192 instead of 256 bytes per 64 columns
+        const bool half_x = DIAG && (diag[1] & 16);
         for (int64_t t = 0; t < kt; t += 2) {
             {   // H stage
-                if (t + 1 < kt) stage(cur ^ 1, t + 1);
+                if (t + 1 < kt) stage(cur ^ 1, t + 1, half_x);
                 const char* base = smem + cur * kStageBytes;
                 vec8<T> a0[MT], a1[MT], b0[NT], b1[NT];
 #pragma unroll
@@ -680,7 +684,7 @@ int launch_chunk(skr_ctx* ctx, const T* Ac, const T* Bc, const SplitOut& o, int6
         // libseekr_hip_diag.so only (python -m seekr_amd.build --diag; tools/gemm_diag.py): the production library holds
         // neither the stamping instance nor the switches below, which make r meaningless.  Never with an edge sink
         // active: the stamps live in the ctx workspace, which is where the sink's list is.
-        if (std::is_same<T, _Float16>::value && NPROD == 3 && (MODE == PLAIN || MODE == SELF) && ctx->diag_mode && !es.count) {
+        if (std::is_same<T, _Float16>::value && (NPROD == 3 || NPROD == 2) && (MODE == PLAIN || MODE == SELF) && ctx->diag_mode && !es.count) {
             void* ws = nullptr;
             SKR_TRY(skr_ctx_workspace(ctx, (size_t)(8 + 8 * 65536) * 8, &ws));
             diag = (unsigned long long*)ws;
@@ -688,8 +692,9 @@ int launch_chunk(skr_ctx* ctx, const T* Ac, const T* Bc, const SplitOut& o, int6
             // experiments: 2 = k loop without staging, 3 = every stage re-loads k tile 0, 4 = self mode without the mirror
             // stores, 5 = two product-units per k (one int8 MFMA in place of the two cross products: timing ceiling)
             const int dmode = ctx->diag_mode;
-            if (dmode >= 2 && dmode <= 5)
-                SKR_HIP(hipMemsetAsync(diag + 1, dmode == 2 ? 1 : (dmode == 3 ? 2 : (dmode == 4 ? 4 : 8)), 1, ctx->stream));
+            // 6 (f16f8 operands only) = the X line staged half (timing ceiling of a layout without the hi8 copies)
+            if (dmode >= 2 && dmode <= 6)
+                SKR_HIP(hipMemsetAsync(diag + 1, dmode == 2 ? 1 : (dmode == 3 ? 2 : (dmode == 4 ? 4 : (dmode == 5 ? 8 : 16))), 1, ctx->stream));
             kern = pearson_gemm_split16_kernel<T, NPROD, (MODE == SELF ? SELF : PLAIN), true, true>;
         }
 #endif
@@ -824,9 +829,9 @@ extern "C" int skr_gemm_diag_read(skr_ctx* ctx, unsigned long long* out, int64_t
     return SKR_OK;
 }
 
-// 0 = production kernels; 1 = stamps only (r stays valid); 2-5 = timing experiments that make r meaningless (above)
+// 0 = production kernels; 1 = stamps only (r stays valid); 2-6 = timing experiments that make r meaningless (above)
 extern "C" int skr_gemm_diag_mode(skr_ctx* ctx, int mode) {
-    SKR_REQUIRE(ctx && mode >= 0 && mode <= 5, "mode 0..5");
+    SKR_REQUIRE(ctx && mode >= 0 && mode <= 6, "mode 0..6");
     ctx->diag_mode = mode;
     return SKR_OK;
 }

@@ -52,7 +52,7 @@ def bits(a):
 
 
 def dump_case(seed, n_cases, seqs, tag):
-    """Keep a failing case for replay (python tests/fuzz_differential.py --replay file)."""
+    """Keep a failing case for replay (python tools/replay_case.py file)."""
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(d, exist_ok=True)
     path = os.path.join(d, "fuzz_fail_%d_%d.npz" % (seed, n_cases))
@@ -91,7 +91,7 @@ def gen_case(r):
     return seqs, k, alphabet, log2, mean, std, tag
 
 
-def fuzz(seed, budget_s=60.0, max_cases=10 ** 9, replay=None):
+def fuzz(seed, budget_s=60.0, max_cases=10 ** 9):
   rng_ = np.random.default_rng(seed)
   t0, n_cases = time.time(), 0
   while time.time() - t0 < budget_s and n_cases < max_cases:
@@ -171,9 +171,5 @@ def fuzz(seed, budget_s=60.0, max_cases=10 ** 9, replay=None):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[1] == "--replay":
-        fuzz(0, replay=sys.argv[2])
-        print("replayed case passes")
-    else:
-        n = fuzz(int(sys.argv[1]) if len(sys.argv) > 1 else 0, float(sys.argv[2]) if len(sys.argv) > 2 else 60.0)
-        print("fuzz ok: %d cases" % n)
+    n = fuzz(int(sys.argv[1]) if len(sys.argv) > 1 else 0, float(sys.argv[2]) if len(sys.argv) > 2 else 60.0)
+    print("fuzz ok: %d cases" % n)

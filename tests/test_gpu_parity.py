@@ -1364,6 +1364,17 @@ def test_two_product_unit_precision_f16f8(K, rows, W, L, ctx):
     L.pearson_gemm_op(ctx, op, op.view(0, rows), r2, symmetric=False)
     g2 = r2.to_numpy().astype(np.float64)
     assert (np.abs(g2 - truth) / (2e-6 + 1e-5 * np.abs(truth))).max() <= 1.0
+    # the thresholding epilogue (EDGES mode, K = 16 384: through the scratch block of the earlier k chunks) keeps exactly
+    # the cells of this very r
+    from seekr_amd import consumers
+    cutoff = 0.03 if K == 4096 else 0.015
+    fe = consumers.FusedEdges(ctx)
+    ei, ej, ev = fe.block(op, op.view(0, rows), cutoff, upper_only=True)
+    want = np.triu(np.where(r2.to_numpy() < cutoff, np.float32(0), r2.to_numpy()), 1)
+    wi, wj = np.nonzero(want)
+    assert len(ei) > 50 and np.array_equal(ei, wi.astype(np.uint32)) and np.array_equal(ej, wj.astype(np.uint32))
+    assert np.array_equal(ev.view(np.uint32), want[wi, wj].view(np.uint32))
+    fe.free()
     # few-valued rows: degraded to the three-product split by the fill's own flag
     draw = ctx.from_numpy(raw)
     op_raw, _ = L.operand_fill(ctx, draw, precision=L.PREC_F16F8, row_standardize=True)

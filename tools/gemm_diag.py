@@ -28,19 +28,25 @@ ap.add_argument("--data", default="counts", choices=["counts", "zeros", "ones"],
 ap.add_argument("--no-dma", action="store_true", help="k loop without its LDS-DMA staging (timing experiment; r is garbage)")
 ap.add_argument("--same-tile", action="store_true", help="every stage re-loads k tile 0: the staging traffic stays, its source is the nearest cache (timing experiment; r is garbage)")
 ap.add_argument("--two-units", action="store_true", help="TIMING CEILING of a two-product-unit split (VERDICT r3 #5): one v_mfma_i32_16x16x64_i8 in place of the two cross products, same staging and LDS reads; r is garbage.  Printed next to a stamps-only launch of the same process")
+ap.add_argument("--half-x", action="store_true", help="f16f8 operands; TIMING CEILING of an H / X layout whose X line carries lo8 alone (staged half); r is garbage.  Printed next to a stamps-only launch of the f16f8 kernel")
 ap.add_argument("--no-mirror", action="store_true", help="self mode without the mirror stores (timing experiment; the lower triangle stays unwritten)")
 args = ap.parse_args()
 ctx = _lib.default_context()
 rng = np.random.default_rng(0)
-op = _lib.Operand(ctx, args.rows, args.cols, _lib.PREC_F16X3)
+PREC = _lib.PREC_F16F8 if args.half_x else _lib.PREC_F16X3
+op = _lib.Operand(ctx, args.rows, args.cols, PREC)
 for r0 in range(0, args.rows, 8192):
     nr = min(8192, args.rows - r0)
     x = np.log2(rng.binomial(1995, 1.0 / 4096, size=(nr, args.cols)).astype(np.float32) * np.float32(0.5) + 1.0)
+    if args.half_x:  # every cell a different value (column-standardised counts), or the fill routes the rows back to f16x3
+        c = rng.binomial(1995, 1.0 / 4096, size=(nr, args.cols)).astype(np.float32)
+        zc = (c - c.mean(0)) / np.maximum(c.std(0), 1e-6)
+        x = np.log2(zc + np.abs(zc.min()) + 1.0).astype(np.float32)
     if args.data == "zeros":
         x[:] = 0
     d = ctx.from_numpy(x.astype(np.float32))
     # zeros: rows used as they are (row standardisation of a constant row is 0/0)
-    _lib.operand_fill(ctx, d, op=op.view(r0, nr), precision=_lib.PREC_F16X3, row_standardize=args.data == "counts")
+    _lib.operand_fill(ctx, d, op=op.view(r0, nr), precision=PREC, row_standardize=args.data == "counts")
     d.free()
 b = op
 if args.mode == "plain":
@@ -74,7 +80,7 @@ def one_launch(mode, label):
         print("%-30s median %8.0f cycles = %6.1f us   (5-95 %%: %.0f - %.0f)"
               % (name, np.median(v), np.median(v) / np.median(clock) / 1e3, *np.percentile(v, [5, 95])))
     kt = (args.cols + 31) // 32
-    units = 64 if mode == 5 else 96
+    units = 64 if (mode == 5 or args.half_x) else 96
     mfma = kt * 2 * units * 16
     print("MFMA cycles per tile and SIMD (2 waves x %d MFMA x 16 cycles x %d k tiles): %d = %.3f of the k loop, %.3f of the tile"
           % (units, kt, mfma, mfma / np.median(k1 - k0), mfma / np.median(t1 - t0)))
@@ -83,7 +89,13 @@ def one_launch(mode, label):
 
 print("%d warm-up launches" % n)
 mode = 2 if args.no_dma else (3 if args.same_tile else (4 if args.no_mirror else (5 if args.two_units else 1)))
-if mode == 5:
+if args.half_x:
+    assert op.kind == 3, "the operand was routed back to f16x3 (kind %d)" % op.kind
+    for rep in range(3):
+        a_ms = one_launch(1, "f16f8 as shipped (stamps only)")
+        b_ms = one_launch(6, "f16f8 with the X line staged half (timing ceiling)")
+        print("==== launch %.3f -> %.3f ms: %+.1f %%" % (a_ms, b_ms, (b_ms / a_ms - 1) * 100))
+elif mode == 5:
     for rep in range(3):  # alternate in one process: stamps only / two product-units
         a_ms = one_launch(1, "three product-units (shipped arithmetic, stamps only)")
         b_ms = one_launch(5, "two product-units (timing ceiling)")
