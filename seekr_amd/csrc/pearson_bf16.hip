@@ -736,6 +736,9 @@ int launch16(skr_ctx* ctx, const T* A, const T* B, const SplitOut& o, int64_t M,
     // of adds and with the accumulator — 5e-6 relative on an r ~ 1 pair at K = 4 096, four times that at
     // 16 384 in one go.  Later chunks add their partial result to C in the epilogue (rounded float32 adds).
     const int64_t kChunkTiles = skr_gemm_chunk_tiles(ctx, coherent);
+    if (NPROD == 2 && ((kChunkTiles | kt) & 1))  // H and X lines come in pairs: a chunk must not end between them
+        return skr_set_error(SKR_ERR_INVALID, "f16f8 operands need an even number of lines per row and per k chunk (%lld, %lld)",
+                             (long long)kt, (long long)kChunkTiles);
     const EdgeSink es = sink ? *sink : EdgeSink{};
     SkrProfScope prof(ctx, name);
     for (int64_t t0 = 0; t0 < kt; t0 += kChunkTiles) {

@@ -111,6 +111,14 @@ class HipEngine:
         op = _lib.Operand(self.ctx, x.rows, x.cols, _lib.PREC_FP32) if op is None or op.kind != 0 else op
         return _lib.operand_fill(self.ctx, x, op=op, precision=_lib.PREC_FP32, row_standardize=True)[0]
 
+    def prepare_f16x3(self, x, op=None):
+        """The rows of `x` (already normalised) as a split-fp16 (three-product) operand in the storage of `op`: what every
+        rank switches to when any rank's opt-in f16f8 operand routed itself back."""
+        like = _lib.Operand(self.ctx, 1, x.cols, _lib.PREC_F16X3)
+        op = _lib.Operand(self.ctx, x.rows, x.cols, _lib.PREC_F16X3) if op is None else op.adopt_layout(like)
+        like.free()
+        return _lib.operand_fill(self.ctx, x, op=op, precision=_lib.PREC_F16X3, row_standardize=True)[0]
+
     def gemm(self, a, b, r, col0, symmetric=False):
         _lib.pearson_gemm_op(self.ctx, a, b, r, symmetric and self.use_symmetry, 0, col0)
 
@@ -350,23 +358,24 @@ def _any_rank(comm, flag):
     return bool(flag)
 
 
-def _verdicts(comm, fell_back, coherent, has_nan):
+def _verdicts(comm, fell_back, coherent, has_nan, routed_back=False):
     """The per-step verdicts of the normalisation as ONE host all-reduce (a stream drain and a round trip each, were they
     separate): did any rank's operand fall back to the float32 layout, is any rank's shard 'mostly one repeated value',
-    did any rank see a NaN — and did a link of the mailbox chain give up waiting on ANY rank (the sums behind
-    such a link are garbage on every later rank, in every log2 mode; all ranks raise together instead of one rank raising
-    and the others hanging in the next collective).  sharded_normalize and sharded_normalize_prepare both end with it, so
-    that ranks may mix the two entry points (tests/dist_worker.py does)."""
+    did any rank see a NaN, did any rank's opt-in f16f8 operand route itself back to the three-product split — and did a
+    link of the mailbox chain give up waiting on ANY rank (the sums behind such a link are garbage on every
+    later rank, in every log2 mode; all ranks raise together instead of one rank raising and the others hanging in the
+    next collective).  sharded_normalize and sharded_normalize_prepare both end with it, so that ranks may mix the two
+    entry points (tests/dist_worker.py does)."""
     if comm.size > 1:
         gave_up = bool(getattr(comm, "chain_gave_up", lambda: False)())
         out = comm.allreduce([1.0 if fell_back else 0.0, 1.0 if coherent else 0.0, 1.0 if has_nan else 0.0,
-                              1.0 if gave_up else 0.0], "max")
+                              1.0 if gave_up else 0.0, 1.0 if routed_back else 0.0], "max")
         if out[3] > 0:
             raise _lib.SeekrHipError("rank {}: a link of the column-sum chain gave up waiting for a peer's mailbox store "
                                      "({}): the column statistics of this step are invalid on every rank".format(
                                          comm.rank, "this rank" if gave_up else "another rank"))
-        return tuple(v > 0 for v in out[:3])
-    return bool(fell_back), bool(coherent), bool(has_nan)
+        return out[0] > 0, out[1] > 0, out[2] > 0, out[4] > 0
+    return bool(fell_back), bool(coherent), bool(has_nan), bool(routed_back)
 
 
 def sharded_normalize(engine, comm, x, n_total, log2="Log2.post", mean=True, std=True):
@@ -385,10 +394,6 @@ def sharded_normalize_prepare(engine, comm, x, n_total, log2="Log2.post", mean=T
     """sharded_normalize fused with the Pearson preparation: one pass writes the normalised
     counts (into `x`, when keep_counts) and the row-standardised operand.
     Returns (mean_vec, std_vec, has_nan, operand)."""
-    if comm.size > 1 and getattr(engine, "precision", None) == _lib.PREC_F16F8:
-        # a rank whose rows route back to the three-product split would have to make every other rank follow; the
-        # all-reduced layout flag exists for the float32 fallback only
-        raise NotImplementedError("SKR_PREC_F16F8 (opt-in) is implemented for one GPU; use f16x3 across ranks")
     center, scale, post, shift = sharded_stats(engine, comm, x, n_total, log2, mean, std)
     operand, has_nan = engine.prepare(x, center, scale, post, shift, keep_counts=keep_counts, op=op)
     # A rank whose rows need more dynamic range than the split contraction has (skr_operand_kind) comes
@@ -401,11 +406,20 @@ def sharded_normalize_prepare(engine, comm, x, n_total, log2="Log2.post", mean=T
     if comm.size > 1:
         fell_back = hasattr(engine, "layout") and engine.layout(operand) == 0 and engine.precision != _lib.PREC_FP32
         coherent = bool(getattr(operand, "coherent", False))
-        any_fell_back, any_coherent, any_nan = _verdicts(comm, fell_back, coherent, has_nan)
+        # the opt-in f16f8 layout (kind 3): a rank whose fill routed its rows back to the three-product split (kind 2:
+        # neighbouring cells repeat each other, or the shape has no H / X layout) makes every rank follow
+        x8 = getattr(engine, "precision", None) == _lib.PREC_F16F8 and hasattr(engine, "layout")
+        routed_back = x8 and engine.layout(operand) == 2
+        any_fell_back, any_coherent, any_nan, any_routed_back = _verdicts(comm, fell_back, coherent, has_nan, routed_back)
+        normalised_in_x = keep_counts or (center is None and scale is None and not post)  # x still holds what was prepared
         if any_fell_back and hasattr(engine, "layout") and engine.layout(operand) != 0:
-            if not keep_counts:
+            if not normalised_in_x:
                 raise NotImplementedError("a rank fell back to the float32 contraction; re-run with keep_counts=True")
             operand = engine.prepare_f32(x)
+        elif x8 and any_routed_back and engine.layout(operand) == 3:
+            if not normalised_in_x:
+                raise NotImplementedError("a rank routed its f16f8 operand back to f16x3; re-run with keep_counts=True")
+            operand = engine.prepare_f16x3(x, op=operand)
         if hasattr(operand, "coherent") and any_coherent != bool(operand.coherent) and not any_fell_back:
             operand.coherent = any_coherent
         has_nan = any_nan

@@ -26,6 +26,27 @@ def main():
         blob[:2 * length] = ord("A")
     packed = _lib.PackedSeqs.from_buffer(ctx, blob, offsets, "AGTC")
     x = _lib.count_per_kb(ctx, packed, k)
+    x8_mode = os.environ.get("MOCK_X8", "")
+    if x8_mode:
+        # the opt-in f16f8 precision across ranks: "keep" = every shard keeps the H / X layout (kind 3); "route" = rank 0's
+        # rows are few-valued, its fill routes them back to the three-product split, and every rank must follow
+        from x8_case import x8_matrix
+        full = x8_matrix(n_total, x.cols, x8_mode == "route", bounds[1])
+        x = ctx.from_numpy(full[lo:hi])
+        engine = HipEngine(ctx, _lib.PREC_F16F8)
+        _, _, has_nan, z = sharded_normalize_prepare(engine, comm, x, n_total, "Log2.none", False, False, keep_counts=False)
+        max_shard = max(bounds[g + 1] - bounds[g] for g in range(size))
+        recv = [engine.empty_operand(max_shard, x.cols) for _ in range(2)]
+        r = ctx.zeros(hi - lo, n_total)
+        sharded_pearson_rowblock(engine, comm, z, bounds, r, recv)
+        r_row, r_col = ctx.zeros(hi - lo, n_total), ctx.zeros(n_total, hi - lo)
+        blocks = sharded_pearson_symmetric(engine, comm, z, bounds, r_row, r_col, recv)
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), r=r.to_numpy(), kind=np.array(z.kind), lo=np.array(lo), hi=np.array(hi),
+                 r_row=r_row.to_numpy(), r_col=r_col.to_numpy(),
+                 blocks=np.array([(0 if b[0] == "row" else 1,) + tuple(b[1:]) for b in blocks], dtype=np.int64))
+        comm.barrier()
+        ctx.sync()
+        return
     engine = HipEngine(ctx)
     coherent_mode = os.environ.get("MOCK_COHERENT_LAST_RANK") == "1"
     if coherent_mode:

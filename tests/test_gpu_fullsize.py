@@ -40,3 +40,7 @@ def test_bench_line_carries_the_measurement_contract():
     assert cb["kind"] == "port" and "median of 3" in cb["sample"] and cb["value"] > 0 and cb["cores"] >= 1
     assert d["verified"] is True and d["verified_detail"]["worst_error_over_bar"] <= 1.0
     assert d["e2e"]["fasta_to_host_counts_mbases_per_s"] > 0 and d["e2e"]["host_to_host_pearson_mpairs_per_s"] > 0
+    # round 4: the opt-in two-product-unit contraction measured after the timed region, verified like the headline
+    arm = d["f16f8_arm"]
+    assert arm["operand_kind"] == 3 and arm["verified"] is True and arm["worst_error_over_bar"] <= 1.0 and arm["value"] > 0
+    assert "never part of `value`" in arm["note"] and d["config"]["precision"] == "f16x3"

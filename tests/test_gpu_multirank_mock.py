@@ -283,6 +283,39 @@ def test_every_rank_switches_when_one_needs_the_fp32_kernel(mock_lib, tmp_path):
     assert np.allclose(full, orc.pearson(x, x), rtol=1e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("mode,want_kind", [("keep", 3), ("route", 2)])
+def test_f16f8_across_ranks(mode, want_kind, mock_lib, tmp_path):
+    """The opt-in two-product-unit precision with three ranks: every shard keeps the H / X layout (kind 3), or — rank 0's
+    rows are few-valued, its fill routes them back to the three-product split — the all-reduced verdict makes EVERY rank
+    refill as f16x3 (kind 2), so that shards stay compatible; r (row blocks and the half ring) inside the bar of float64
+    either way."""
+    from x8_case import x8_matrix
+    from oracle import seekr_oracle as orc
+    size, n_total, cols = 3, 700, 4096
+    env = dict(os.environ, WORLD_SIZE=str(size), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), LOCAL_RANK="0",
+               SEEKR_TEST_HOOKS="1", SEEKR_RCCL_LIB=mock_lib, MOCK_RCCL_ASYNC="1", MOCK_X8=mode)
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "mock_rank_worker.py"), str(tmp_path), str(n_total), "600", "6"],
+                              env=dict(env, RANK=str(rank)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for rank in range(size)]
+    for rank, p in enumerate(procs):
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, "rank %d failed:\n%s" % (rank, out.decode()[-3000:])
+    parts = [np.load(str(tmp_path / ("rank%d.npz" % rank))) for rank in range(size)]
+    assert [int(p["kind"]) for p in parts] == [want_kind] * size
+    bounds = [int(parts[0]["lo"])] + [int(p["hi"]) for p in parts]
+    x = x8_matrix(n_total, cols, mode == "route", bounds[1])
+    truth = orc.pearson_f64_truth(x, x)
+    bar = 2e-6 + 1e-5 * np.abs(truth)
+    full = np.concatenate([p["r"] for p in parts], axis=0)
+    assert (np.abs(full - truth) <= bar).all(), float((np.abs(full - truth) / bar).max())
+    sym = np.zeros_like(full)
+    for p in parts:
+        for which, br, bc, nr, nc, gr, gc in p["blocks"]:
+            buf = p["r_row"] if which == 0 else p["r_col"]
+            sym[gr:gr + nr, gc:gc + nc] = buf[br:br + nr, bc:bc + nc]
+    assert (np.abs(sym - truth) <= bar).all(), float((np.abs(sym - truth) / bar).max())
+
+
 def test_coherent_flag_is_global(mock_lib, tmp_path):
     """only the last rank holds rows that are mostly one repeated value.  Its flag (skr_operand_coherent)
     is all-reduced, so every rank restarts the accumulators of every block every 1 024 columns; at K = 16 384 the
