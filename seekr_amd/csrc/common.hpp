@@ -25,7 +25,6 @@ struct SkrKnobs {
     int count_wps = 0;           // SEEKR_COUNT_WPS: waves per sequence (0 = by k)
     bool count_generic_global = false;  // SEEKR_COUNT_GENERIC_GLOBAL=1: any-alphabet counting on the round-1 path (histogram in HBM)
     bool count_k8_global = false;  // SEEKR_COUNT_K8_GLOBAL=1: k = 8 on the round-1 path (histogram in the output row, L2 atomics)
-    int count_flush = 0;         // SEEKR_COUNT_FLUSH: 0 interleaved lo/hi pieces, 1 row in ascending order, 2 = 1 with plain stores
     int count_occ = 0;           // SEEKR_COUNT_OCC: cap on one-wave workgroups per CU of the non-persistent launch (0 = what the LDS allows)
     bool chain_host_wait = false;  // SEEKR_CHAIN_HOST_WAIT=1 (only under SEEKR_TEST_HOOKS=1): the column-sum chain waits for its
                                    // mailbox on the HOST before it launches — several ranks sharing one GPU (tests) cannot wait

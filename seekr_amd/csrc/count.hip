@@ -237,11 +237,10 @@ __device__ __forceinline__ void lds_add_u32(uint32_t* lds_base, uint32_t byte_ad
                                  __HIP_MEMORY_SCOPE_WORKGROUP);  // result unused: ds_add_u32
 }
 
-// FLUSH (A/B, tools/count_bench.py): 0 = a lane step stores the lo piece (bins w4..w4+3) and the hi piece (the same words'
-// upper halves, 2 * 4^k bytes further on) back to back — two interleaved 1-KiB streams per row; 1 = the row strictly in
-// ascending address order: the hi pieces wait in registers (at most 8 steps x 4) until the lo half of the row is out;
-// 2 = as 1 with ordinary instead of nontemporal stores.
-template <int OUT, int WPS, bool TILES, int FLUSH = 0>
+// (Round 4 measured two other orders of the row flush — the row strictly in ascending address order, the hi pieces parked
+// in registers, with nontemporal or ordinary stores: 2 % at best at k = 6, 12-23 % slower at k = 7; DESIGN §4 — and
+// removed them again: a lane step stores its lo piece and its hi piece back to back.)
+template <int OUT, int WPS, bool TILES>
 __global__ __launch_bounds__(WPS * 64) void count_rows_kernel(const CountArgs a) {
     constexpr int T = WPS * 64;
     constexpr int P = WPS == 1 ? 2 : 1;  // sweeps of packed words prefetched one item ahead (2 048 / 4 096 bases)
@@ -393,36 +392,6 @@ __global__ __launch_bounds__(WPS * 64) void count_rows_kernel(const CountArgs a)
             const size_t row = (size_t)(TILES ? it : seq) * nbins;
             typedef float f4 __attribute__((ext_vector_type(4)));
             typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-            if (FLUSH != 0 && (OUT == OUT_F32 || OUT == OUT_F32_LOG2) && nwords >= 4 && nwords <= (uint32_t)T * 32) {
-                f4 parked[8];
-                float* rowp = reinterpret_cast<float*>(a.out) + row;
-#pragma unroll
-                for (int s8 = 0; s8 < 8; s8++) {
-                    const uint32_t w4 = (uint32_t)(s8 * T + tid) * 4;
-                    if (w4 < nwords) {
-                        const uint4 c = *reinterpret_cast<const uint4*>(&hist[w4]);
-                        *reinterpret_cast<uint4*>(&hist[w4]) = make_uint4(0, 0, 0, 0);
-                        f4 lo4;
-                        if (((c.x | c.y | c.z | c.w) & 0xFFF0FFF0u) == 0) {  // all eight counts below 16: table
-                            lo4 = f4{tab[c.x & 15u], tab[c.y & 15u], tab[c.z & 15u], tab[c.w & 15u]};
-                            parked[s8] = f4{tab[c.x >> 16], tab[c.y >> 16], tab[c.z >> 16], tab[c.w >> 16]};
-                        } else {
-                            lo4 = f4{value_of(c.x & 0xFFFFu), value_of(c.y & 0xFFFFu), value_of(c.z & 0xFFFFu), value_of(c.w & 0xFFFFu)};
-                            parked[s8] = f4{value_of(c.x >> 16), value_of(c.y >> 16), value_of(c.z >> 16), value_of(c.w >> 16)};
-                        }
-                        if (FLUSH == 2) *reinterpret_cast<f4*>(rowp + w4) = lo4;
-                        else __builtin_nontemporal_store(lo4, reinterpret_cast<f4*>(rowp + w4));
-                    }
-                }
-#pragma unroll
-                for (int s8 = 0; s8 < 8; s8++) {
-                    const uint32_t w4 = (uint32_t)(s8 * T + tid) * 4;
-                    if (w4 < nwords) {
-                        if (FLUSH == 2) *reinterpret_cast<f4*>(rowp + nwords + w4) = parked[s8];
-                        else __builtin_nontemporal_store(parked[s8], reinterpret_cast<f4*>(rowp + nwords + w4));
-                    }
-                }
-            } else
             for (uint32_t w4 = tid * 4; w4 < nwords; w4 += T * 4) {
                 const uint4 c = *reinterpret_cast<const uint4*>(&hist[w4]);
                 *reinterpret_cast<uint4*>(&hist[w4]) = make_uint4(0, 0, 0, 0);
@@ -540,11 +509,7 @@ int launch_rows(skr_ctx* ctx, const skr_seqs* s, int k, void* out) {
     };
     CountArgs a{s->d_packed, s->d_word_off, s->d_len, s->d_mask, s->d_mask_off, nullptr, nullptr, s->n, out, k};
     unsigned grid = 1;
-    void (*kern)(const CountArgs) = count_rows_kernel<OUT, WPS, false>;
-    if constexpr (OUT == OUT_F32 || OUT == OUT_F32_LOG2) {
-        if (ctx->knobs.count_flush == 1) kern = count_rows_kernel<OUT, WPS, false, 1>;  // A/B knob
-        if (ctx->knobs.count_flush == 2) kern = count_rows_kernel<OUT, WPS, false, 2>;
-    }
+    auto kern = count_rows_kernel<OUT, WPS, false>;
     SKR_TRY(grid_for_kernel(reinterpret_cast<const void*>(kern), WPS * 64, s->n, &grid));
     // One wave per sequence (k <= 6): NOT persistent — one workgroup per sequence, dispatched by the hardware in order, as
     // many resident as the LDS allows (19 per CU at k = 6).  The rows being written then form a compact front that
@@ -554,7 +519,9 @@ int launch_rows(skr_ctx* ctx, const skr_seqs* s, int k, void* out) {
     // k = 5: 0.100 vs 0.108.
     // k = 7 (four waves per sequence): one workgroup per sequence as well since round 4 — 0.323 against 0.340 ms for the
     // persistent grid (30 000 x 5 kb behind a contraction: 0.775 against 0.737 of 8 TB/s); SEEKR_COUNT_PERSIST=1 restores it
-    const bool persistent = ctx->knobs.count_persist == 1;  // A/B knob
+    // (k = 8: one 128-KiB workgroup per CU — the persistent grid stays: a fresh workgroup per sequence would zero its 128 KiB of
+    // bins every time, 0.63 against 0.70 of 8 TB/s for 20 000 x 2 kb)
+    const bool persistent = ctx->knobs.count_persist == 1 || (ctx->knobs.count_persist == 0 && k >= 8);  // A/B knob
     if (!persistent) grid = (unsigned)std::min<int64_t>(s->n, 0x7fffffff);
     size_t lds_launch = lds;
     // Round 4: at k = 6 the LDS would let 19 one-wave workgroups share a CU; SEVENTEEN (enforced by asking for 9.25 KiB of

@@ -1321,14 +1321,13 @@ def test_k8_counts_in_the_lds_like_the_round_1_path(L, ctx):
 
 @pytest.mark.parametrize("k,length", [(6, 2000), (5, 900), (7, 5000), (3, 300)])
 def test_counting_kernel_ab_knobs_give_the_same_bits(k, length, L, ctx):
-    """The A/B arms of the row flush (tools/count_bench.py: SEEKR_COUNT_FLUSH 1 = row in ascending address order, 2 = the
-    same with ordinary stores; SEEKR_COUNT_OCC = fewer one-wave workgroups per CU) only move stores around."""
+    """The A/B knobs of the counting launch (tools/count_bench.py: SEEKR_COUNT_OCC = fewer one-wave workgroups per CU,
+    SEEKR_COUNT_PERSIST = persistent grid or one workgroup per sequence) only move work around."""
     seqs = orc.codes_to_seqs(orc.synthetic_codes(k, 300, length)) + ["A" * (length + 7), "ACGTN" * 50, "AC" * 40]
     packed = ctx.pack(seqs)
     base = L.count_per_kb(ctx, packed, k).to_numpy()
     assert_bits(base, orc.raw_counts(seqs, k), "base")
-    for env in ({"SEEKR_COUNT_FLUSH": "1"}, {"SEEKR_COUNT_FLUSH": "2"}, {"SEEKR_COUNT_OCC": "10"},
-                {"SEEKR_COUNT_FLUSH": "1", "SEEKR_COUNT_OCC": "12"}):
+    for env in ({"SEEKR_COUNT_OCC": "10"}, {"SEEKR_COUNT_OCC": "19"}, {"SEEKR_COUNT_PERSIST": "1"}, {"SEEKR_COUNT_PERSIST": "2"}):
         got = _with_knobs(ctx, env, lambda: L.count_per_kb(ctx, packed, k).to_numpy())
         assert_bits(got, base, str(env))
         pre = _with_knobs(ctx, env, lambda: L.count_per_kb(ctx, packed, k, log2_pre=True).to_numpy())

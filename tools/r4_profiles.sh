@@ -1,0 +1,8 @@
+# Round-4 evidence with the final library (run from the repo root on the GPU box): rocprofv3 kernel stats + PMC passes
+#   gpurun -- 'bash tools/r4_profiles.sh'   then copy gpurun_out/prof_r4_*/r4_*_{kernel_stats.csv,pmc_summary.txt,bench_under_rocprof.json} to profiles/
+set -u
+bash tools/profile.sh r4_f16x3 f16x3 > gpurun_out/r4_profile_default.log 2>&1
+bash tools/profile.sh r4_f16x3_k7 f16x3 --k 7 --length 5000 > gpurun_out/r4_profile_k7.log 2>&1
+bash tools/profile.sh r4_f16f8 f16f8 > gpurun_out/r4_profile_f16f8.log 2>&1
+T_TRACE=500 T_PMC=400 bash tools/profile.sh r4_f16x3_200k f16x3 --rows 200000 > gpurun_out/r4_profile_200k.log 2>&1
+for t in r4_f16x3 r4_f16x3_k7 r4_f16f8 r4_f16x3_200k; do head -3 gpurun_out/prof_$t/${t}_kernel_stats.csv | cut -c1-160; done
