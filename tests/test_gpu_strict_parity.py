@@ -24,3 +24,22 @@ def test_strict_parity_grid(tmp_path):
         assert cell["f16x3"]["strict"] <= 1.0 and cell["fp32"]["strict"] <= 1.0, cell
         # the device is never further from float64 than the bar allows on its own, whatever the reference does
         assert cell["f16x3"]["vs_f64"] <= 1.0, cell
+
+
+def test_strict_parity_grid_with_the_two_product_unit_precision(tmp_path):
+    """The same grid under the opt-in SKR_PREC_F16F8 (round 4), routing included: the points whose operand keeps the H / X
+    layout (kind 3: Log2.post of binomial counts, gaussian raw and Log2.post at K = 4 096 and 16 384) stay within 0.6 of
+    the bar, every other point is served by the three-product split or the fp32 kernel and equals the default's value."""
+    out_json = str(tmp_path / "strict8.json")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "strict_parity.py"), "--rows", "768", "--f16f8", "--json", out_json],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "f16f8 (routing included)" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    grid = json.load(open(out_json))["grid"]
+    kept = [c for c in grid if c["f16f8"]["operand_kind"] == 3]
+    assert len(kept) >= 5 and all(c["K"] >= 4096 for c in kept)
+    for c in grid:
+        assert c["f16f8"]["strict"] <= 1.0 and c["f16f8"]["vs_f64"] <= 1.0, c
+        if c["f16f8"]["operand_kind"] == 3:
+            assert c["f16f8"]["strict"] <= 0.6, c
+        else:
+            assert c["f16f8"]["strict"] == c["f16x3"]["strict"] or c["f16f8"]["operand_kind"] == 0, c
