@@ -896,16 +896,21 @@ extern "C" int skr_operand_create(skr_ctx* ctx, int64_t rows, int64_t cols, int 
     // (|dr| <= 2e-6 + 1e-5 |r|); below that the exact-product fp32 MFMA is used.  fp16 halves keep 22 bits of z, so
     // the dropped lo*lo term is bounded by 2^-21 sum|z_i z_j| / K <= 5e-7 whatever K is: the split kernel is used
     // from 64 columns (k = 3) up, where it is faster than the fp32 one (k = 4, 50 000 rows: 6.9 -> 3.2 ms).
-    // Above 16 384 columns (k >= 8) one float32 accumulator per cell over the whole of K drifts
-    // past the bar (1e-5 at K = 65 536 measured), so those shapes also take the fp32 kernel, whose
-    // accumulation is blocked.
+    // One float32 accumulator per cell over the whole of K drifts past the bar at K = 65 536 (1e-5 measured in round 1):
+    // the split contraction restarts its accumulators every 4 096 columns (pearson_bf16.hip: launch16).
     // SKR_PREC_F16F8 (opt-in): the H / X line layout exists for the three register-resident widths; any other shape is
     // served by the split-fp16 operand it degrades to
     // (4 096 and 16 384 columns: the fp8 roundings average out like 1 / sqrt(K) — measured 0.5 and 0.25 of the bar; at 1 024
     // columns they would not fit it)
     if (precision == SKR_PREC_F16F8 && !(cols == 4096 || cols == 16384)) op->precision = precision = SKR_PREC_F16X3;
     const int64_t split_min = precision == SKR_PREC_F16X3 ? 64 : 1024;
-    if (precision == SKR_PREC_FP32 || cols < split_min || cols > 16384) op->kind = 0;
+    // Round 4: split-fp16 up to 65 536 columns (k = 8; SEEKR_SPLIT_MAX_COLS=16384 restores the fp32 kernel for the A/B) — the
+    // accumulators restart every 4 096 columns and the chunks' partial sums are added in float32, so the drift of ONE
+    // accumulator over the whole of K that sent these shapes to the fp32 kernel in round 1 no longer applies (20 000 x 65 536:
+    // the contraction 209 -> 61 ms, the step 231 -> 97 ms, worst cell 0.04 of the bar either way); bf16 halves and wider rows
+    // (k >= 9) keep the fp32 kernel.
+    const int64_t split_max = precision == SKR_PREC_F16X3 ? std::max<int64_t>(16384, ctx->knobs.split_max_cols) : 16384;
+    if (precision == SKR_PREC_FP32 || cols < split_min || cols > split_max) op->kind = 0;
     else op->kind = precision == SKR_PREC_F16F8 ? 3 : (precision == SKR_PREC_F16X3 ? 2 : 1);
     // fp16 halves: rows are stored times a power of two chosen so that sqrt(K) — the largest value a
     // row-standardised row can hold — lands just below 2^15.  The lo half of a small z then stays a

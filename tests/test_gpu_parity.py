@@ -1303,6 +1303,34 @@ def test_any_alphabet_rows_without_a_window_after_other_work(L, ctx):
     assert not L.count_generic(ctx, seqs, alphabet, k, np.uint32).to_numpy().any()
 
 
+def test_split_fp16_contraction_at_65536_columns(L, ctx):
+    """Round 4: k = 8 rows (65 536 columns) take the split-fp16 contraction in sixteen 4 096-column chunks instead of the
+    fp32 kernel (3.4 x faster); strict against the reference on normalised-count-like and gaussian rows, and within a
+    tenth of the bar of what the fp32 kernel gives."""
+    rng = np.random.default_rng(8)
+    K, rows = 65536, 192
+    for name, x in (("gaussian", rng.standard_normal((rows, K)).astype(np.float32)),
+                    ("Log2.post of binomial counts", None)):
+        if x is None:
+            raw = (rng.binomial(7993, 1.0 / K, size=(rows, K)) * (1000.0 / 7993)).astype(np.float32)
+            with np.errstate(all="ignore"):
+                x = np.ascontiguousarray(orc.normalize(raw, True, True, "Log2.post")[0], dtype=np.float32)
+            if not np.isfinite(x).all():
+                continue
+        with np.errstate(all="ignore"):
+            ref = orc.pearson(x, x).astype(np.float64)
+        dev = ctx.from_numpy(x)
+        op, _ = L.operand_fill(ctx, dev, precision=L.PREC_F16X3, row_standardize=True)
+        assert op.kind == 2, name
+        r = ctx.empty(rows, rows)
+        L.pearson_gemm_op(ctx, op, op, r, symmetric=True)
+        got = r.to_numpy().astype(np.float64)
+        got32 = L.pearson(ctx, dev, dev, True, L.PREC_FP32).to_numpy().astype(np.float64)
+        bar = 2e-6 + 1e-5 * np.abs(ref)
+        assert (np.abs(got - ref) / bar).max() <= 0.5, (name, float((np.abs(got - ref) / bar).max()))
+        assert (np.abs(got - got32) / bar).max() <= 0.2, name
+
+
 def test_k8_counts_in_the_lds_like_the_round_1_path(L, ctx):
     """Round 4: k = 8 on the tuned kernel (65 536 sixteen-bit bins = 128 KiB of LDS, one 4-wave workgroup per CU); the
     same bits as the histogram-in-HBM path it replaces, incl. N runs, a homopolymer and a sequence cut into 8 192-window
