@@ -388,7 +388,21 @@ __global__ __launch_bounds__(256) void operand_fill_block_kernel(FillArgs a) {
             if (IN_LDS) return rowbuf[c];
             return yr ? yr[c] : fill_tail(a, xr[c], c, scratch_nan);
         };
-        float s = 0.f;
+        // the 8 cells of group g as they were parked in pass 1 (LDS, or y), 16 bytes at a time where the width allows it —
+        // round 4: the later passes used to fetch them one float at a time (30 ms per 20 000 x 65 536, 0.5 TB/s); cells past
+        // the end of the row read as 0 and are never used
+        auto load8 = [&](int64_t g, float (&v)[8]) {
+            const int64_t c0 = g * 8;
+            if (vec && (IN_LDS || yr)) {
+                const float* src = IN_LDS ? rowbuf + c0 : yr + c0;
+                const float4 u = *reinterpret_cast<const float4*>(src), w = *reinterpret_cast<const float4*>(src + 4);
+                v[0] = u.x, v[1] = u.y, v[2] = u.z, v[3] = u.w, v[4] = w.x, v[5] = w.y, v[6] = w.z, v[7] = w.w;
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++) v[jj] = c0 + jj < K ? val(c0 + jj) : 0.f;
+            }
+        };
+        float s = 0.f, vmin = INFINITY, vmax = -INFINITY;
         for (int64_t g = tid; g < groups; g += 256) {
             const int64_t c0 = g * 8;
             if (vec) {
@@ -410,58 +424,89 @@ __global__ __launch_bounds__(256) void operand_fill_block_kernel(FillArgs a) {
                     *reinterpret_cast<float4*>(rowbuf + c0 + 4) = w;
                 }
                 s += ((u.x + u.y) + (u.z + u.w)) + ((w.x + w.y) + (w.z + w.w));
+                vmin = fminf(fminf(fminf(vmin, fminf(u.x, u.y)), fminf(u.z, u.w)), fminf(fminf(w.x, w.y), fminf(w.z, w.w)));
+                vmax = fmaxf(fmaxf(fmaxf(vmax, fmaxf(u.x, u.y)), fmaxf(u.z, u.w)), fmaxf(fmaxf(w.x, w.y), fmaxf(w.z, w.w)));
             } else {
                 for (int64_t c = c0; c < std::min<int64_t>(K, c0 + 8); c++) {
                     const float v = fill_tail(a, xr[c], c, any_nan);
                     if (yr) yr[c] = v;
                     if (IN_LDS) rowbuf[c] = v;
                     s += v;
+                    vmin = fminf(vmin, v);
+                    vmax = fmaxf(vmax, v);
                 }
             }
         }
         float mean = 0.f, sd = 1.f;
-        if (a.row_standardize) {
-            const float kf = (float)K;
-            mean = block_sum(s) / kf;
-            s = 0.f;
-            for (int64_t g = tid; g < groups; g += 256)
-                for (int64_t c = g * 8; c < std::min<int64_t>(K, g * 8 + 8); c++) s += val(c) - mean;
-            const float m2 = block_sum(s) / kf;
-            s = 0.f;
-            for (int64_t g = tid; g < groups; g += 256)
-                for (int64_t c = g * 8; c < std::min<int64_t>(K, g * 8 + 8); c++) {
-                    const float d = (val(c) - mean) - m2;
-                    s += d * d;
-                }
-            sd = sqrtf(block_sum(s) / kf);
-        }
-        float zmax2 = 0.f;
+        // pass 2 also counts how much of the row one value holds (its minimum, or — neighbouring cells equal — any value:
+        // operand_fill_kernel), which needs the row minimum of pass 1
         if (sizeof(T) != 4) {
-            for (int64_t g = tid; g < groups; g += 256)
-                for (int64_t c = g * 8; c < std::min<int64_t>(K, g * 8 + 8); c++) {
-                    const float zc = (val(c) - mean) / sd;
-                    zmax2 = fmaxf(zmax2, zc * zc);
-                }
-            zmax2 = wave_max(zmax2);
-            if (lane == 0) red[wave] = zmax2;
-            __syncthreads();
-            zmax2 = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-            __syncthreads();
-            // share of the row held by its minimum (see operand_fill_reg_kernel); equal raw values give equal z
-            float vmin = INFINITY;
-            for (int64_t g = tid; g < groups; g += 256)
-                for (int64_t c = g * 8; c < std::min<int64_t>(K, g * 8 + 8); c++) vmin = fminf(vmin, val(c));
             vmin = -wave_max(-vmin);
+            vmax = wave_max(vmax);
             if (lane == 0) red[wave] = vmin;
             __syncthreads();
             vmin = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
             __syncthreads();
-            float same = 0.f, adj = 0.f;  // ... or by any one value: see operand_fill_kernel
-            for (int64_t g = tid; g < groups; g += 256)
-                for (int64_t c = g * 8; c < std::min<int64_t>(K, g * 8 + 8); c++) {
-                    same += (float)(val(c) == vmin);
-                    if (c + 1 < K) adj += (float)(val(c) == val(c + 1));
+            if (lane == 0) red[wave] = vmax;
+            __syncthreads();
+            vmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            __syncthreads();
+        }
+        float same = 0.f, adj = 0.f;
+        auto count_repeats = [&](int64_t g, const float (&v)[8]) {
+            const int64_t c0 = g * 8;
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++)
+                if (c0 + jj < K) {
+                    same += (float)(v[jj] == vmin);
+                    if (jj < 7) {
+                        if (c0 + jj + 1 < K) adj += (float)(v[jj] == v[jj + 1]);
+                    } else if (c0 + 8 < K) {
+                        adj += (float)(v[7] == val(c0 + 8));
+                    }
                 }
+        };
+        if (a.row_standardize) {
+            const float kf = (float)K;
+            mean = block_sum(s) / kf;
+            s = 0.f;
+            for (int64_t g = tid; g < groups; g += 256) {
+                float v[8];
+                load8(g, v);
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++)
+                    if (g * 8 + jj < K) s += v[jj] - mean;
+                if (sizeof(T) != 4) count_repeats(g, v);
+            }
+            const float m2 = block_sum(s) / kf;
+            s = 0.f;
+            for (int64_t g = tid; g < groups; g += 256) {
+                float v[8];
+                load8(g, v);
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++)
+                    if (g * 8 + jj < K) {
+                        const float d = (v[jj] - mean) - m2;
+                        s += d * d;
+                    }
+            }
+            sd = sqrtf(block_sum(s) / kf);
+        } else if (sizeof(T) != 4) {
+            for (int64_t g = tid; g < groups; g += 256) {
+                float v[8];
+                load8(g, v);
+                count_repeats(g, v);
+            }
+        }
+        float zmax2 = 0.f;
+        if (sizeof(T) != 4) {
+            // the largest z^2 of the row sits at its largest or its smallest value: rounding is monotone, so these two
+            // evaluations are what the maximum over all cells was (NaN cells never counted; a row without a finite value: 0)
+            if (vmin <= vmax) {
+                const float z_lo = (vmin - mean) / sd, z_hi = (vmax - mean) / sd;
+                zmax2 = fmaxf(z_lo * z_lo, z_hi * z_hi);
+                if (!(zmax2 == zmax2)) zmax2 = 0.f;
+            }
             const float n_same = block_sum(same), n_adj = block_sum(adj);
             if (n_same >= 0.85f * (float)K || n_adj >= 0.70f * (float)(K - 1)) coherent = true;
         }
@@ -469,10 +514,11 @@ __global__ __launch_bounds__(256) void operand_fill_block_kernel(FillArgs a) {
         for (int64_t g = tid; g < groups; g += 256) {
             const int64_t tile = g >> 2, sub = g & 3, k0 = g * 8;
             float z[8];
+            load8(g, z);
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const int64_t k = k0 + j;
-                float v = k < K ? val(k) : 0.f;
+                float v = k < K ? z[j] : 0.f;
                 if (a.row_standardize && k < K) v = __fdiv_rn(__fsub_rn(v, mean), sd);
                 z[j] = v;
                 sq = __fmaf_rn(v, v, sq);

@@ -60,11 +60,31 @@ def gen_case(rng):
     return a, b, rs, tag
 
 
+def gen_case_wide(rng):
+    """k = 8 rows (65 536 columns: sixteen accumulator chunks of the split contraction since round 4), float32, row-standardised.
+    A generator of its own — gen_case's random stream is what tests/golden/refspread.json stores states of."""
+    K = 65536
+    M, N = int(rng.integers(1, 24)), int(rng.integers(1, 24))
+    same = bool(rng.integers(0, 2))
+    kind = int(rng.choice([0, 1, 5]))
+    def make(rows):
+        if kind == 0:
+            x = rng.standard_normal((rows, K)) * rng.uniform(0.1, 50)
+        elif kind == 1:
+            x = rng.binomial(20, 0.2, size=(rows, K)).astype(np.float64) * 1.5
+        else:
+            x = rng.standard_normal((1, K)) * 3 + rng.standard_normal((rows, K)) * rng.choice([1e-3, 1e-2, 0.3])
+        return x.astype(np.float32)
+    a = make(M)
+    b = a if same else make(N)
+    return a, b, True, dict(K=K, M=a.shape[0], N=b.shape[0], dt="f32", same=same, rs=True, kind=kind)
+
+
 def fuzz(seed, budget_s=60.0, max_cases=10 ** 9):
     rng = np.random.default_rng(seed)
     t0, n_cases = time.time(), 0
     while time.time() - t0 < budget_s and n_cases < max_cases:
-        a, b, rs, tag = gen_case(rng)
+        a, b, rs, tag = gen_case_wide(rng) if rng.integers(0, 200) == 0 else gen_case(rng)
         same = tag["same"]
         try:
             with np.errstate(all="ignore"):
