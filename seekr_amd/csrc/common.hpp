@@ -23,7 +23,7 @@ struct SkrKnobs {
     int count_persist = 0;       // SEEKR_COUNT_PERSIST=1: persistent grid at k <= 6; 2: one workgroup per sequence at k = 7 too
     bool count_legacy = false;   // SEEKR_COUNT_LEGACY=1: the round-1 counting kernel
     int count_wps = 0;           // SEEKR_COUNT_WPS: waves per sequence (0 = by k)
-    int64_t split_max_cols = 65536;     // SEEKR_SPLIT_MAX_COLS: widest row the split-fp16 contraction takes (16384 = rounds 1-3: k = 8 on the fp32 kernel)
+    int64_t split_max_cols = 262144;    // SEEKR_SPLIT_MAX_COLS: widest row the split-fp16 contraction takes (k = 9; 16384 = rounds 1-3: k >= 8 on the fp32 kernel)
     bool count_generic_global = false;  // SEEKR_COUNT_GENERIC_GLOBAL=1: any-alphabet counting on the round-1 path (histogram in HBM)
     bool count_k8_global = false;  // SEEKR_COUNT_K8_GLOBAL=1: k = 8 on the round-1 path (histogram in the output row, L2 atomics)
     int count_occ = 0;           // SEEKR_COUNT_OCC: cap on one-wave workgroups per CU of the non-persistent launch (0 = what the LDS allows)

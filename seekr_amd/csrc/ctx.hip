@@ -55,7 +55,7 @@ extern "C" int skr_ctx_reload_knobs(skr_ctx* c) {
     kn.count_persist = env_int("SEEKR_COUNT_PERSIST", 0);
     kn.count_legacy = env_int("SEEKR_COUNT_LEGACY", 0) != 0;
     kn.count_wps = env_int("SEEKR_COUNT_WPS", 0);
-    kn.split_max_cols = env_int("SEEKR_SPLIT_MAX_COLS", 65536);
+    kn.split_max_cols = env_int("SEEKR_SPLIT_MAX_COLS", 262144);
     kn.count_generic_global = env_int("SEEKR_COUNT_GENERIC_GLOBAL", 0) != 0;
     kn.count_k8_global = env_int("SEEKR_COUNT_K8_GLOBAL", 0) != 0;
     kn.count_occ = std::max(0, env_int("SEEKR_COUNT_OCC", 0));

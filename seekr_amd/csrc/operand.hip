@@ -950,11 +950,11 @@ extern "C" int skr_operand_create(skr_ctx* ctx, int64_t rows, int64_t cols, int 
     // columns they would not fit it)
     if (precision == SKR_PREC_F16F8 && !(cols == 4096 || cols == 16384)) op->precision = precision = SKR_PREC_F16X3;
     const int64_t split_min = precision == SKR_PREC_F16X3 ? 64 : 1024;
-    // Round 4: split-fp16 up to 65 536 columns (k = 8; SEEKR_SPLIT_MAX_COLS=16384 restores the fp32 kernel for the A/B) — the
-    // accumulators restart every 4 096 columns and the chunks' partial sums are added in float32, so the drift of ONE
-    // accumulator over the whole of K that sent these shapes to the fp32 kernel in round 1 no longer applies (20 000 x 65 536:
-    // the contraction 209 -> 61 ms, the step 231 -> 97 ms, worst cell 0.04 of the bar either way); bf16 halves and wider rows
-    // (k >= 9) keep the fp32 kernel.
+    // Round 4: split-fp16 up to 262 144 columns (k = 8 and 9; SEEKR_SPLIT_MAX_COLS=16384 restores the fp32 kernel for the
+    // A/B) — the accumulators restart every 4 096 columns and the chunks' partial sums are added in float32, so the drift of
+    // ONE accumulator over the whole of K that sent these shapes to the fp32 kernel in round 1 no longer applies (20 000 x
+    // 65 536: the contraction 209 -> 60 ms, worst cell 0.04 of the bar either way; K = 262 144: strict 0.11-0.26, the fp32
+    // kernel's own values); bf16 halves and wider rows (k >= 10) keep the fp32 kernel.
     const int64_t split_max = precision == SKR_PREC_F16X3 ? std::max<int64_t>(16384, ctx->knobs.split_max_cols) : 16384;
     if (precision == SKR_PREC_FP32 || cols < split_min || cols > split_max) op->kind = 0;
     else op->kind = precision == SKR_PREC_F16F8 ? 3 : (precision == SKR_PREC_F16X3 ? 2 : 1);
