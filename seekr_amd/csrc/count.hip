@@ -1,15 +1,15 @@
 // K2 + K3 — k-mer counting: sliding-window 4^k indexer, per-sequence LDS histogram, and the
 // per-kb scaling fused into the histogram flush (kmer_counts.py:140-151, 194-202).
 //
-// count_rows_kernel (k <= 7, the tuned path).  A work item is one sequence (or one 8 192-window tile
+// count_rows_kernel (k <= 8, the tuned path).  A work item is one sequence (or one 8 192-window tile
 // of a long sequence) and is owned by ONE WAVE at k <= 6 (64-thread workgroups: no barrier anywhere,
-// ~19 independent waves per CU) or by a 4-wave workgroup at k = 7.  Lane l of a sweep takes the 16
+// 17 independent waves per CU at k = 6) or by a 4-wave workgroup at k = 7 and 8.  Lane l of a sweep takes the 16
 // windows that start in packed word 64*sweep + l; it holds that word and the next (coalesced loads,
 // the first sweeps prefetched one item ahead).  The packer stores the first base in the top bits, so
 // window j of the pair is r_j = v_alignbit(hi, lo, 32 - 2j) and its column the top 2k bits of r_j:
 // no branch, five vector instructions per window.  Bins are 16-bit counters packed two to an LDS
 // word (bin b and bin b + 4^k/2 share word b mod 4^k/2: the top bit of the column picks the half):
-// 8 KiB per item at k = 6, 32 KiB at k = 7 — an item never has more than 8 192 windows, so a bin cannot
+// 8 KiB per item at k = 6, 32 KiB at k = 7, 128 KiB at k = 8 — an item never has more than 8 192 windows, so a bin cannot
 // overflow.  Counting is ds_add_u32 (no return).  When all 64 lanes of a sweep hold the same two
 // packed words (homopolymers and every repeat whose period divides 16 bases) the 64 x 16 atomics —
 // 64 lanes on one address each — are replaced by 16 adds of 64 from one lane (wave-level aggregation
@@ -28,7 +28,7 @@
 // sequence thus spreads over the whole chip instead of serialising on one CU.
 //
 // count_kmers_kernel (the round-1 kernel: one 256-thread workgroup per sequence, uint32 bins) is kept
-// for float64 output and, with GLOBAL = true, for k >= 8 (4^k bins no longer fit the LDS): it counts
+// for float64 output and, with GLOBAL = true, for k >= 9 (4^k sixteen-bit bins no longer fit the LDS): it counts
 // straight into the sequence's output row, used as a uint32 histogram in HBM (zeroed by a memset first,
 // L2 atomics), and converts the row in place.
 #include <algorithm>
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(kThreads) void count_kmers_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-// The tuned path (k <= 7): see the file header.
+// The tuned path (k <= 8): see the file header.
 // ---------------------------------------------------------------------------------------
 constexpr int kItemWindows = 8192;  // windows per work item: longer sequences are cut into tiles of this many; also keeps a 16-bit bin from overflowing
 
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void convert_long_kernel(const uint32_t* __res
     }
 }
 
-// k <= 7, float32 / uint32 output: count_rows_kernel over the sequences, then the tiles of the long ones.
+// k <= 8, float32 / uint32 output: count_rows_kernel over the sequences, then the tiles of the long ones.
 template <int OUT, int WPS>
 int launch_rows(skr_ctx* ctx, const skr_seqs* s, int k, void* out) {
     const uint32_t nbins = 1u << (2 * k);
