@@ -454,6 +454,23 @@ def run_rank(args):
     rank, size, _ = skr_launch.world()
     if size != args.gpus:
         raise SystemExit("--gpus {} but WORLD_SIZE={}".format(args.gpus, size))
+    stage = ["start"]
+    if size > 1:
+        # a rank that makes no progress (a collective one peer never enters) must not hold the whole job until the caller's
+        # own limit: after --launch-timeout seconds it says where it stood and leaves; torch.distributed.run (or this
+        # script's own launcher) then ends the other ranks
+        # (a timer THREAD, not SIGALRM: a Python signal handler only runs between bytecodes, and a stuck rank sits inside a
+        # ctypes call — which releases the GIL, so the thread does get to run)
+        import threading
+
+        def give_up():
+            print("bench.py rank {}: no progress after {:.0f} s, last stage: {}".format(rank, args.launch_timeout, stage[0]),
+                  file=sys.stderr, flush=True)
+            os._exit(3)
+        watchdog = threading.Timer(max(1.0, float(args.launch_timeout)), give_up)
+        watchdog.daemon = True
+        watchdog.start()
+    stage[0] = "RCCL initialisation"
     ctx, comm = skr_launch.init()
     k, length = args.k, args.length
     generic = not (len(args.alphabet) == 4 and len(set(args.alphabet)) == 4)
@@ -465,6 +482,7 @@ def run_rank(args):
     engine = HipEngine(ctx, _lib.PRECISIONS[args.precision], use_symmetry=not args.no_symmetry)
     symmetric_layout = args.layout == "symmetric" and args.precision != "fp32" and not args.no_symmetry
 
+    stage[0] = "half-ring self-test"
     if size > 1 and symmetric_layout and not args.no_selftest:
         why = symmetric_selftest(ctx, comm, engine, k, args.grouped_shifts)
         if why:
@@ -505,10 +523,12 @@ def run_rank(args):
         else:
             sharded_pearson_rowblock(engine, comm, zz, bounds, r, recv[:2])
 
+    stage[0] = "warm-up steps"
     for _ in range(args.warmup):
         step()
     ctx.sync()
     comm.barrier()
+    stage[0] = "timed steps"
     ctx.prof_reset()
     ctx.prof_enable(True)
     t0 = time.perf_counter()
@@ -519,6 +539,7 @@ def run_rank(args):
     elapsed = time.perf_counter() - t0
     ctx.prof_enable(False)
     elapsed = comm.allreduce([elapsed], "max")[0]
+    stage[0] = "after the timed region (per-rank statistics, verification, chain A/B)"
 
     # ---- per-kernel device times of the timed region (HIP events on the ctx stream; comm_* on the communication stream)
     kern = exclusive_kernel_times(ctx)
@@ -584,6 +605,8 @@ def run_rank(args):
     gemm = kern.get(gemm_name, {"ms_total": 0.0, "launches": 0})
     count = kern.get("count_generic" if generic else "count_kmers_f32", {"ms_total": 0.0, "launches": 0})
 
+    if size > 1:
+        watchdog.cancel()
     if rank != 0:
         return
     pairs_per_step = float(n_total) * n_total

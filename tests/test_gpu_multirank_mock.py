@@ -246,6 +246,21 @@ def test_eight_ranks_at_the_drivers_weak_scaling_size(layout, mock_lib):
     assert len(out["per_rank"]["gemm_ms"]) == 8 and min(out["per_rank"]["gemm_ms"]) > 0
 
 
+def test_bench_rank_gives_up_when_a_peer_never_arrives(mock_lib):
+    """bench.py as rank 0 of 2 (the shape torch.distributed.run gives it) while rank 1 never starts: the rank sits inside a
+    collective's C call for ever — a watchdog thread says where it stood after --launch-timeout seconds and leaves with
+    exit code 3, so that the launcher (or torchrun) ends the job instead of waiting for its own limit."""
+    import time
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+               SEEKR_TEST_HOOKS="1", SEEKR_RCCL_LIB=mock_lib, SEEKR_FORCE_DEVICE="0", MOCK_RCCL_ASYNC="1")
+    t0 = time.time()
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--rows", "4000",
+                          "--length", "400", "--launch-timeout", "6"], env=env, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 3, (res.returncode, res.stderr[-1500:])
+    assert "no progress after 6 s, last stage:" in res.stderr and time.time() - t0 < 60
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+
+
 def test_bench_falls_back_to_row_blocks_when_the_selftest_fails(mock_lib):
     """The half-ring self-test fails on rank 1 of 3 (test hook): every rank leaves with the self-test's exit code, and the
     launcher starts a NEW set of rank processes with --layout allgather; the line says so."""
