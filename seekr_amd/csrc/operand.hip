@@ -584,7 +584,7 @@ using vec4h = T __attribute__((ext_vector_type(4)));
 template <typename T, int VPL, int MODE, int RW, bool HASY, bool X8 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VPL == 16 ? 2 : 4))) void operand_fill_reg_kernel(FillArgs a) {
     static_assert(!X8 || std::is_same<T, _Float16>::value, "the fp8 cross layout pairs with fp16 hi halves");
-    __shared__ float red[8][4];
+    __shared__ float red[9][4];
     const int lane = threadIdx.x & 63;
     // the wave index through readfirstlane: the compiler then KNOWS the row index is wave-uniform and keeps every row
     // base in scalar registers (derived from threadIdx it is 'divergent', and all addresses become 64-bit VGPR pairs)
@@ -737,6 +737,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VPL == 16 ?
             eq = row_sum(eq, 7);
             if (eq >= 0.45f * (float)K) coherent = true;
             if (X8 && eq >= (float)K * (1.0f / 256.0f)) repeats = true;
+            if constexpr (X8) {
+                // ... and rows that repeat values WITHOUT neighbours being equal (a periodic row against a shifted copy
+                // of itself: the same pair of values meets in every period and the fp8 roundings of that pair add up).
+                // What the averaging needs is many DISTINCT pairs of values per pair of rows, and two rows meet in at
+                // least as many distinct pairs as either has distinct values; tools/f8_cross_study.py, rows of period D
+                // at 4 096 and 16 384 columns alike: D = 3 / 64 / 513 / 1 025 / 2 049 -> 2.4 / 1.1 / 0.8 / 0.6 / 0.4 bars
+                // (all distinct: 0.30 / 0.13).  The row's values are hashed into a bitmap of 2 K bits in the LDS; fewer
+                // than 2 048 occupied bits (about 2 100 - 2 350 distinct values) send the row back to the three-product split.
+                constexpr int LOGB = K == 1024 ? 11 : K == 4096 ? 13 : 15;
+                static_assert((int64_t)1 << LOGB == 2 * K, "the bitmap has two bits per column");
+                constexpr int WORDS = (int)(2 * K / 32), STEP = RW == 1 ? 64 : 256;
+                __shared__ uint32_t seen_bits[(RW == 1 ? 4 : 1) * WORDS];
+                uint32_t* bm = seen_bits + (RW == 1 ? wave * WORDS : 0);
+                const int first = RW == 1 ? lane : (int)threadIdx.x;
+                for (int w = first; w < WORDS; w += STEP) bm[w] = 0u;
+                if (RW == 1) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); else __syncthreads();
+#pragma unroll
+                for (int i = 0; i < VPL; i++) {
+                    const float z4[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t h = (__float_as_uint(z4[j]) * 0x9E3779B1u) >> (32 - LOGB);
+                        __hip_atomic_fetch_or(&bm[h >> 5], 1u << (h & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                if (RW == 1) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); else __syncthreads();
+                float occ = 0.f;
+                for (int w = first; w < WORDS; w += STEP) occ += (float)__popc(bm[w]);
+                if (row_sum(occ, 8) < 2048.f) repeats = true;
+            }
         }
 #pragma unroll
         for (int i = 0; i < VPL; i++) {

@@ -1415,6 +1415,41 @@ def test_two_product_unit_precision_f16f8(K, rows, W, L, ctx):
         m.free()
 
 
+@pytest.mark.parametrize("K,period", [(4096, 3), (4096, 64), (4096, 513), (4096, 1500), (16384, 64), (16384, 1025)])
+def test_f16f8_routes_rows_that_repeat_values_without_equal_neighbours(K, period, L, ctx):
+    """Rows of a short period, each a shifted copy of the same sequence of distinct values: no cell equals its neighbour
+    (the adjacent-pair flag sees nothing), but the same PAIR of values meets once per period, the fp8 roundings of the
+    cross terms add up instead of averaging out (tools/f8_cross_study.py: 2.4 / 1.1 / 0.8 bars at periods 3 / 64 / 513).
+    The fill counts the row's distinct values through a hashed bitmap in the LDS and sends such rows back to the
+    three-product split: the operand reports kind 2 and r has f16x3's bits."""
+    rng = np.random.default_rng(period)
+    vals = rng.standard_normal(period).astype(np.float32)
+    rows = 260
+    idx = (np.arange(K)[None, :] + rng.integers(0, period, (rows, 1))) % period
+    x = np.ascontiguousarray(vals[idx])
+    assert not (x[:, 1:] == x[:, :-1]).any()
+    dev = ctx.from_numpy(x)
+    op8, _ = L.operand_fill(ctx, dev, precision=L.PREC_F16F8, row_standardize=True)
+    op3, _ = L.operand_fill(ctx, dev, precision=L.PREC_F16X3, row_standardize=True)
+    assert op8.kind == 2 and op3.kind == 2
+    ra, rb = ctx.empty(rows, rows), ctx.empty(rows, rows)
+    L.pearson_gemm_op(ctx, op8, op8, ra, symmetric=True)
+    L.pearson_gemm_op(ctx, op3, op3, rb, symmetric=True)
+    got = ra.to_numpy()
+    assert np.array_equal(got.view(np.uint32), rb.to_numpy().view(np.uint32))
+    truth = orc.pearson_f64_truth(x, x)
+    assert (np.abs(got - truth) / (2e-6 + 1e-5 * np.abs(truth))).max() <= 1.0
+    # mixed: ONE such row among distinct-valued ones is enough (the flag is per operand)
+    y = rng.standard_normal((rows, K)).astype(np.float32)
+    opy, _ = L.operand_fill(ctx, ctx.from_numpy(y), precision=L.PREC_F16F8, row_standardize=True)
+    assert opy.kind == 3
+    y[17] = x[0]
+    opm, _ = L.operand_fill(ctx, ctx.from_numpy(y), precision=L.PREC_F16F8, row_standardize=True)
+    assert opm.kind == 2
+    for m in (dev, ra, rb, op8, op3, opy, opm):
+        m.free()
+
+
 def test_f16f8_degrades_on_other_widths_and_through_the_api(L, ctx, monkeypatch):
     rng = np.random.default_rng(3)
     for cols in (729, 1024):
