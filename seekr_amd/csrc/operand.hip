@@ -584,7 +584,7 @@ using vec4h = T __attribute__((ext_vector_type(4)));
 template <typename T, int VPL, int MODE, int RW, bool HASY, bool X8 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VPL == 16 ? 2 : 4))) void operand_fill_reg_kernel(FillArgs a) {
     static_assert(!X8 || std::is_same<T, _Float16>::value, "the fp8 cross layout pairs with fp16 hi halves");
-    __shared__ float red[9][4];
+    __shared__ float red[13][4];
     const int lane = threadIdx.x & 63;
     // the wave index through readfirstlane: the compiler then KNOWS the row index is wave-uniform and keeps every row
     // base in scalar registers (derived from threadIdx it is 'divergent', and all addresses become 64-bit VGPR pairs)
@@ -768,6 +768,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VPL == 16 ?
                 if (row_sum(occ, 8) < 2048.f) repeats = true;
             }
         }
+        // X8: sums over the row of what the fp8 copies hold and of what they lose (decoded back: 128 h8, hi - 128 h8,
+        // l8 / 16, lo - l8 / 16), for the routing rule on the MEANS below
+        float x8_h8 = 0.f, x8_dh = 0.f, x8_l8 = 0.f, x8_dl = 0.f;
 #pragma unroll
         for (int i = 0; i < VPL; i++) {
             const int64_t c = (i * RW + piece0) * 256 + lane * 4;
@@ -797,12 +800,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VPL == 16 ?
                     l8 = __builtin_amdgcn_cvt_pk_fp8_f32((float)lo[2] * 16.f, (float)lo[3] * 16.f, l8, true);
                     *reinterpret_cast<int*>(line + 128 + j) = h8;
                     *reinterpret_cast<int*>(line + 192 + j) = l8;
+                    const float fh[4] = {__builtin_amdgcn_cvt_f32_fp8(h8, 0), __builtin_amdgcn_cvt_f32_fp8(h8, 1),
+                                         __builtin_amdgcn_cvt_f32_fp8(h8, 2), __builtin_amdgcn_cvt_f32_fp8(h8, 3)};
+                    const float fl[4] = {__builtin_amdgcn_cvt_f32_fp8(l8, 0), __builtin_amdgcn_cvt_f32_fp8(l8, 1),
+                                         __builtin_amdgcn_cvt_f32_fp8(l8, 2), __builtin_amdgcn_cvt_f32_fp8(l8, 3)};
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        x8_h8 += fh[q] * 128.f;
+                        x8_dh += __fmaf_rn(fh[q], -128.f, (float)hi[q]);
+                        x8_l8 += fl[q] * 0.0625f;
+                        x8_dl += __fmaf_rn(fl[q], -0.0625f, (float)lo[q]);
+                    }
                 } else {
                     T* dst = reinterpret_cast<T*>(a.out) + ((size_t)r * a.kt + (c >> 5)) * 64 + (c & 31);
                     *reinterpret_cast<vec4h<T>*>(dst) = hi;
                     *reinterpret_cast<vec4h<T>*>(dst + 32) = lo;
                 }
                 if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if constexpr (X8) {
+            // Tightly clustered values (a few levels with a jitter below the fp16 spacing: every cell of a level gets the
+            // same hi, the same fp8 copy of it, and a lo that is the level's offset instead of a pseudo-random remainder):
+            // then neither hi - 128 h8 nor lo averages out over a row, and the cross term of two such rows is off by
+            // K x mean(hi - 128 h8) x mean(lo) (tools/f8_cross_study.py: 4 levels with a jitter of 1e-4: 3 bars, every value
+            // distinct).  The row means go into four maxima over the operand; skr_operand_fill turns their products into
+            // a bound on that error and routes the operand back above 0.6 of the bar.  NaN rows do not count.
+            const float inv = 1.0f / (float)K;
+            const float m[4] = {row_sum(x8_h8, 9) * inv, row_sum(x8_dh, 10) * inv, row_sum(x8_l8, 11) * inv, row_sum(x8_dl, 12) * inv};
+            if (lane == 0 && (RW == 1 || wave == 0)) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    // a load first: 4 atomics per row on four words of one cache line serialise the whole launch (2.3 instead
+                    // of 0.46 ms at 50 000 rows); a running maximum is raised O(log rows) times
+                    const uint32_t bits = __float_as_uint(fabsf(m[q]));
+                    if (m[q] == m[q] && bits > __hip_atomic_load(&a.flags[24 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                        atomicMax(&a.flags[24 + q], bits);
+                }
             }
         }
     }
@@ -1090,6 +1124,7 @@ extern "C" int skr_operand_fill(skr_ctx* ctx, const skr_mat* x, const skr_mat* c
     // accumulator per cell has, [5] a row is mostly one repeated value ([2] belongs to the counting kernel)
     SKR_HIP(hipMemsetAsync(ctx->d_flags + 1, 0, 4, ctx->stream));
     SKR_HIP(hipMemsetAsync(ctx->d_flags + 3, 0, 16, ctx->stream));  // [6]: neighbouring cells repeat each other (f16f8 only)
+    SKR_HIP(hipMemsetAsync(ctx->d_flags + 24, 0, 16, ctx->stream));  // [24..27]: f16f8's maxima of the row means (float bits)
     op->coherent = false;
     if (op->kind == 3) {
         // the H / X line layout is written by the register kernels alone: float32 vectors computed on the device (or none),
@@ -1107,10 +1142,22 @@ extern "C" int skr_operand_fill(skr_ctx* ctx, const skr_mat* x, const skr_mat* c
     const bool was_x8 = op->kind == 3;
     const bool split = op->kind != 0;
     if (has_nan || check_range || split) {
-        SKR_HIP(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        SKR_HIP(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 28 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         SKR_HIP(hipStreamSynchronize(ctx->stream));
         if (has_nan) *has_nan = ctx->h_flags[1] != 0;
         op->coherent = split && ctx->h_flags[5] != 0;
+        bool x8_means = false;
+        if (was_x8) {
+            // error of a cell of r from the row means alone (operand_fill_reg_kernel, X8): 2 (mean(hi - 128 h8) mean(l8 / 16) +
+            // mean(128 h8) mean(lo - l8 / 16)) / scale^2, the largest means of the operand standing in for every pair of rows
+            float mx[4];
+            for (int q = 0; q < 4; q++) {
+                const uint32_t bits = ctx->h_flags[24 + q];
+                mx[q] = *reinterpret_cast<const float*>(&bits);
+            }
+            const double bound = 2.0 * ((double)mx[1] * mx[2] + (double)mx[0] * mx[3]) / ((double)op->scale * op->scale);
+            x8_means = bound > 0.6 * 2e-6;
+        }
         if (split && ctx->h_flags[4] != 0) {
             // a row is dominated by so few columns that the split contraction would drop the others
             // (see row_needs_fp32): same storage, float32 layout, and the fp32 kernel from here on.  The
@@ -1129,8 +1176,9 @@ extern "C" int skr_operand_fill(skr_ctx* ctx, const skr_mat* x, const skr_mat* c
             SKR_TRY(launch_fill(ctx, op, b));
             return SKR_OK;
         }
-        if (was_x8 && (ctx->h_flags[5] != 0 || ctx->h_flags[6] != 0)) {
-            // rows that are mostly one repeated value, or whose neighbouring cells repeat each other (raw counts, 0/1 rows):
+        if (was_x8 && (ctx->h_flags[5] != 0 || ctx->h_flags[6] != 0 || x8_means)) {
+            // rows that are mostly one repeated value, whose neighbouring cells repeat each other (raw counts, 0/1 rows), that
+            // hold too few distinct values, or whose fp8 roundings do not average out over a row (tight clusters):
             // the fp8 copies of a repeated value carry the same rounding everywhere — the three-product split serves them
             if (!op->owner)
                 return skr_set_error(SKR_ERR_UNSUPPORTED, "these rows need the three-product split, and a VIEW cannot change the layout "

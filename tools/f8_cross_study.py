@@ -3,8 +3,9 @@
 hi = fp16(z s) rounded to nearest, lo = fp16(z s - hi), h8 = e4m3(hi / 128), l8 = e4m3(16 lo);
 r = (hi.hi + 8 (h8.l8 + l8.h8)) / (K s^2) — the sums in float64 here, so what is measured is the operands' own rounding
 (the lost lo.lo term and the fp8 roundings of the cross terms), not the accumulation order.  Rows with D distinct values
-placed at random: the fp8 rounding of a value is the same wherever it stands, so the error of a cell is a sum over
-value PAIRS, not over columns, and grows like sqrt(K / D) — the question the fill's routing flag has to answer.
+placed at random, rows of a short period, rows whose values sit on a few tightly jittered levels: the fp8 rounding of a value
+is the same wherever it stands, so the error of a cell is a sum over value PAIRS, not over columns — the cases the fill's
+three routing statistics (equal neighbours, distinct values, row means of the rounding residues) have to find.
 
     python tools/f8_cross_study.py [--cols 4096] [--rows 192]"""
 import argparse
@@ -23,7 +24,7 @@ def e4m3(x):
     return np.sign(x) * q
 
 
-def emulate(x, cols):
+def emulate(x, cols, want_means=False):
     x = np.asarray(x, np.float32)
     z = ((x.T - x.mean(1)).T)
     z = ((z.T / z.std(1)).T).astype(np.float32)
@@ -32,6 +33,11 @@ def emulate(x, cols):
     hi = zs.astype(np.float16).astype(np.float64)
     lo = (zs - hi).astype(np.float16).astype(np.float64)
     h8, l8 = e4m3(hi / 128.0), e4m3(lo * 16.0)
+    if want_means:
+        # the fill's third statistic: the largest row means of what the fp8 copies hold and lose -> a bound on the error
+        # of a cell from the means alone, in units of the bar at r = 0 (skr_operand_fill routes above 0.6)
+        m = [np.abs(v.mean(1)).max() for v in (128.0 * h8, hi - 128.0 * h8, l8 / 16.0, lo - l8 / 16.0)]
+        return 2.0 * (m[1] * m[2] + m[0] * m[3]) / (s * s) / 2e-6
     r8 = (hi @ hi.T + 8.0 * (h8 @ l8.T + l8 @ h8.T)) / (cols * s * s)
     r3 = (hi @ hi.T + hi @ lo.T + lo @ hi.T) / (cols * s * s)
     truth = (z.astype(np.float64) @ z.astype(np.float64).T) / cols
@@ -65,7 +71,7 @@ def main():
     K, n = args.cols, args.rows
     rng = np.random.default_rng(1)
     print("K = %d, %d rows; worst off-diagonal cell in bars vs float64: f16f8 | f16x3 operands; adjacent-equal share (max, min row); "
-          "occupied bits of the 2 K-bit value bitmap / K (worst row); routed by either rule (adjacent-equal >= K/256, fewer than 2 048 occupied bits)" % (K, n))
+          "occupied bits of the 2 K-bit value bitmap / K (worst row); the means bound in bars; routed by any rule (adjacent-equal >= K/256, fewer than 2 048 occupied bits, means bound > 0.6)" % (K, n))
     cases = []
     cases.append(("gaussian (all distinct)", rng.standard_normal((n, K)).astype(np.float32)))
     for D in (8192, 4096, 2048, 1024, 512, 256, 128, 64, 16, 3):
@@ -79,12 +85,18 @@ def main():
         vals = rng.standard_normal(P).astype(np.float32)
         idx = (np.arange(K)[None, :] + rng.integers(0, P, (n, 1))) % P
         cases.append(("period %d, no equal neighbours" % P, vals[idx]))
+    for nc in (2, 4, 16):
+        centres = (rng.standard_normal(nc) * 2).astype(np.float32)
+        for jit in (1e-2, 1e-3, 3e-4, 1e-4, 1e-5):
+            x = centres[rng.integers(0, nc, (n, K))] * (1.0 + jit * rng.standard_normal((n, K)))
+            cases.append(("%2d levels, jitter %.0e (all distinct)" % (nc, jit), x.astype(np.float32)))
     for name, x in cases:
         e8, e3 = emulate(x, K)
+        mb = emulate(x, K, want_means=True)
         amax, amin = adjacent_equal(x)
         occ = bitmap_share(x, K)
-        routed = amin >= 1.0 / 256.0 or occ * K < 2048
-        print("%-34s %7.3f | %6.3f   adj-eq %.4f / %.4f  bitmap %.3f  %s%s" % (name, e8, e3, amax, amin, occ, "routed" if routed else "KEPT",
+        routed = amin >= 1.0 / 256.0 or occ * K < 2048 or mb > 0.6
+        print("%-36s %7.3f | %6.3f   adj-eq %.4f / %.4f  bitmap %.3f  means %6.3f  %s%s" % (name, e8, e3, amax, amin, occ, mb, "routed" if routed else "KEPT",
                                                                    "  <-- over the bar, not routed" if (e8 > 1.0 and not routed) else ""))
 
 
