@@ -254,6 +254,17 @@ int skr_operand_adopt_layout(skr_operand* op, const skr_operand* like);
  * split contraction restart its accumulators every 1 024 columns; skr_operand_fill computes it from the rows
  * it sees, a multi-GPU caller all-reduces it so that every shard of a set carries the same value.            */
 int skr_operand_coherent(skr_operand* op, int set, int* value);
+
+/* SKR_PREC_F16F8 only.  The fill of an operand in the H / X layout keeps three numbers with it — the largest |row mean| of
+ * hi - 128 h8, of lo and of lo - l8 / 16 over its rows — because the cross term of two rows is off by the products of
+ * those means when the fp8 roundings do not average out over a row ("Two product-units").  Within one operand
+ * skr_operand_fill applies the rule itself and routes the rows back to SKR_PREC_F16X3; two operands that were filled
+ * separately are checked pairwise by skr_pearson_gemm_op / skr_pearson_gemm_edges (SKR_ERR_UNSUPPORTED when they do not go
+ * together; skr_pearson and skr_pearson_gemm refill both instead).  Shards of ONE matrix on several GPUs: all-reduce (max)
+ * the three values, apply the rule to the result, set it on every shard; receive buffers take it over in
+ * skr_operand_adopt_layout.  set = 0: read into v[3]; set = 1: store v[3].  Zeros for every other layout.
+ * (New in round 4; the reference has no counterpart — numpy's float32 inner product, seekr/pearson.py:41.) */
+int skr_operand_x8_stats(skr_operand* op, int set, float* v);
 /* r[row0 + i, col0 + j] = <a_i, b_j> / K on prepared operands (same meaning as skr_pearson_gemm) */
 int skr_pearson_gemm_op(skr_ctx* ctx, const skr_operand* a, const skr_operand* b, int symmetric, skr_mat* r,
                         int64_t row0, int64_t col0);

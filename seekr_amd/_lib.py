@@ -6,6 +6,7 @@ box so that the build step and the host-logic tests can run there.
 """
 import atexit
 import ctypes as C
+import math
 import os
 import threading
 
@@ -19,6 +20,7 @@ SKR_OK = 0
 F32, F64, U32 = 0, 1, 2
 LOG2_NONE, LOG2_PRE, LOG2_POST = 0, 1, 2
 PREC_FP32, PREC_BF16X3, PREC_F64, PREC_BF16X4, PREC_F16X3, PREC_F16F8 = 0, 1, 2, 3, 4, 5
+X8_MEANS_LIMIT = 0.6 * 2e-6  # kX8MeansLimit of the library: what the f16f8 rule on the row means allows (of r)
 LOG2_CODES = {"Log2.none": LOG2_NONE, "Log2.pre": LOG2_PRE, "Log2.post": LOG2_POST}
 PRECISIONS = {"fp32": PREC_FP32, "bf16x3": PREC_BF16X3, "bf16x4": PREC_BF16X4, "f16x3": PREC_F16X3, "f64": PREC_F64,
               "f16f8": PREC_F16F8}  # f16f8: opt-in, two product-units per k; degrades to f16x3 by itself
@@ -91,6 +93,7 @@ SIGNATURES = {
     "skr_operand_kind": (_int, [_p, C.POINTER(_int)]),
     "skr_operand_adopt_layout": (_int, [_p, _p]),
     "skr_operand_coherent": (_int, [_p, _int, C.POINTER(_int)]),
+    "skr_operand_x8_stats": (_int, [_p, _int, C.POINTER(C.c_float)]),
     "skr_pearson_gemm_op": (_int, [_p, _p, _p, _int, _p, _i64, _i64]),
     "skr_pearson_gemm_op_mirror": (_int, [_p, _p, _p, _p, _i64, _i64, _p, _i64, _i64]),
     "skr_threshold_zero_diag": (_int, [_p, _p, C.c_float, _i64]),
@@ -382,6 +385,26 @@ class Operand:
     def coherent(self, flag):
         v = _int(1 if flag else 0)
         check(lib().skr_operand_coherent(self._h, 1, C.byref(v)))
+
+    @property
+    def x8_stats(self):
+        """f16f8 layout only (zeros otherwise): the largest |row mean| of hi - 128 h8, of lo and of lo - l8 / 16 over the
+        rows of this operand (skr_operand_x8_stats) — what the routing rule on the row means is evaluated from."""
+        v = (C.c_float * 3)()
+        check(lib().skr_operand_x8_stats(self._h, 0, v))
+        return tuple(float(t) for t in v)
+
+    @x8_stats.setter
+    def x8_stats(self, values):
+        v = (C.c_float * 3)(*[float(t) for t in values])
+        check(lib().skr_operand_x8_stats(self._h, 1, v))
+
+    def x8_bound(self, stats=None):
+        """The bound on the error of a cell of r that follows from the row means alone (operand.hip, X8), for this operand
+        against itself with its own or with the given (e.g. all-reduced) maxima; X8_MEANS_LIMIT is what the fill allows."""
+        d, l, dl = self.x8_stats if stats is None else stats
+        s = 2.0 ** math.floor(math.log2(32768.0 / math.sqrt(self.cols)))
+        return 2.0 * (d * (l + dl) + (d + l) * dl) / (s * s)
 
     def adopt_layout(self, like):
         """Tag this buffer (a receive buffer) with the storage kind of `like`."""

@@ -196,8 +196,21 @@ struct skr_operand {
     bool diag_valid = false;  // false for buffers that only ever received rows from a peer
     bool coherent = false;    // rows are mostly one repeated value: the contraction restarts its accumulators twice as often
     bool owner = true;
+    // kind 3 (the opt-in SKR_PREC_F16F8 layout) only: the largest |row mean| of what the fp8 copies lose and of lo over the
+    // rows filled into this operand (dh = hi - 128 h8, lo, dl = lo - l8 / 16; operand.hip, X8), and the allocation the rows
+    // live in — two operands of different allocations are multiplied only if the products of their means bound the error
+    float x8_stat[3] = {0.f, 0.f, 0.f};
+    const void* x8_root = nullptr;
     size_t row_bytes() const { return (size_t)kt * 128; }
 };
+// error of a cell of r from the row means alone when rows of a meet rows of b in the f16f8 layout (see operand.hip)
+inline double skr_x8_pair_bound(const skr_operand* a, const skr_operand* b) {
+    const double Da = a->x8_stat[0], La = a->x8_stat[1], la = a->x8_stat[2];
+    const double Db = b->x8_stat[0], Lb = b->x8_stat[1], lb = b->x8_stat[2];
+    return (Da * (Lb + lb) + (Da + La) * lb + Db * (La + la) + (Db + Lb) * la) / ((double)a->scale * b->scale);
+}
+constexpr double kX8MeansLimit = 0.6 * 2e-6;  // of the bar at r = 0
+int skr_x8_pair_check(const skr_operand* a, const skr_operand* b);  // operand.hip
 int skr_activate(const skr_ctx* ctx);
 
 // float32 log2 rounded from a float64 evaluation: correctly rounded except for near-ties of the

@@ -234,6 +234,7 @@ extern "C" int skr_pearson_gemm_edges(skr_ctx* ctx, const skr_operand* a, const 
                 "handle belongs to a different ctx");
     SKR_REQUIRE(a->cols == b->cols && a->kind == b->kind && a->precision == b->precision,
                 "operands were prepared for different shapes or precisions");
+    SKR_TRY(skr_x8_pair_check(a, b));
     if (a->kind == 0)
         return skr_set_error(SKR_ERR_UNSUPPORTED, "float32-layout operands take the two-step path (skr_pearson_gemm_op + skr_edges)");
     SKR_REQUIRE(out_rows->dtype == SKR_U32 && out_cols->dtype == SKR_U32 && out_vals->dtype == SKR_F32, "outputs are U32, U32, F32");

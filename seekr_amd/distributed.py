@@ -358,7 +358,7 @@ def _any_rank(comm, flag):
     return bool(flag)
 
 
-def _verdicts(comm, fell_back, coherent, has_nan, routed_back=False):
+def _verdicts(comm, fell_back, coherent, has_nan, routed_back=False, x8_stats=None):
     """The per-step verdicts of the normalisation as ONE host all-reduce (a stream drain and a round trip each, were they
     separate): did any rank's operand fall back to the float32 layout, is any rank's shard 'mostly one repeated value',
     did any rank see a NaN, did any rank's opt-in f16f8 operand route itself back to the three-product split — and did a
@@ -369,7 +369,9 @@ def _verdicts(comm, fell_back, coherent, has_nan, routed_back=False):
     if comm.size > 1:
         gave_up = bool(getattr(comm, "chain_gave_up", lambda: False)())
         out = comm.allreduce([1.0 if fell_back else 0.0, 1.0 if coherent else 0.0, 1.0 if has_nan else 0.0,
-                              1.0 if gave_up else 0.0, 1.0 if routed_back else 0.0], "max")
+                              1.0 if gave_up else 0.0, 1.0 if routed_back else 0.0] + list(x8_stats or ()), "max")
+        if x8_stats is not None:  # the opt-in f16f8 layout: the three row-mean maxima of every shard, made global
+            x8_stats[:] = out[5:8]
         if out[3] > 0:
             raise _lib.SeekrHipError("rank {}: a link of the column-sum chain gave up waiting for a peer's mailbox store "
                                      "({}): the column statistics of this step are invalid on every rank".format(
@@ -410,7 +412,17 @@ def sharded_normalize_prepare(engine, comm, x, n_total, log2="Log2.post", mean=T
         # neighbouring cells repeat each other, or the shape has no H / X layout) makes every rank follow
         x8 = getattr(engine, "precision", None) == _lib.PREC_F16F8 and hasattr(engine, "layout")
         routed_back = x8 and engine.layout(operand) == 2
-        any_fell_back, any_coherent, any_nan, any_routed_back = _verdicts(comm, fell_back, coherent, has_nan, routed_back)
+        # ... and the rule on the row means of the rounding residues (skr_operand_x8_stats) has to hold between ANY two rows
+        # of the matrix, not just inside a shard: the three maxima ride on the same all-reduce, every rank applies the rule
+        # to the global values and routes back together
+        stats = list(operand.x8_stats) if x8 and hasattr(operand, "x8_stats") and engine.layout(operand) == 3 else [0.0, 0.0, 0.0]
+        any_fell_back, any_coherent, any_nan, any_routed_back = _verdicts(comm, fell_back, coherent, has_nan, routed_back,
+                                                                          stats if x8 else None)
+        if x8 and hasattr(operand, "x8_bound") and not any_routed_back and engine.layout(operand) == 3:
+            if operand.x8_bound(stats) > _lib.X8_MEANS_LIMIT:
+                any_routed_back = True
+            else:
+                operand.x8_stats = stats  # receive buffers take them over in adopt_layout
         normalised_in_x = keep_counts or (center is None and scale is None and not post)  # x still holds what was prepared
         if any_fell_back and hasattr(engine, "layout") and engine.layout(operand) != 0:
             if not normalised_in_x:

@@ -80,11 +80,60 @@ def gen_case_wide(rng):
     return a, b, True, dict(K=K, M=a.shape[0], N=b.shape[0], dt="f32", same=same, rs=True, kind=kind)
 
 
+def gen_case_layout(rng):
+    """Rows with STRUCTURE at the two widths that can take the opt-in f16f8 operand layout (4 096 / 16 384 columns, float32,
+    row-standardised): short periods, a few jittered levels, few distinct values, levels aligned between rows, quantised
+    values, and mixtures of those with plain gaussian rows — the inputs on which the fp8 roundings of that layout do not
+    average out and its fill has to route the operand back to the three-product split (tools/f8_cross_study.py).  Under
+    the default precision the same cases exercise the coherent-row flag and the accumulator chunks."""
+    K = int(rng.choice([4096, 4096, 16384]))
+    M, N = int(rng.integers(2, 48)), int(rng.integers(2, 48))
+    same = bool(rng.integers(0, 2))
+    kind = int(rng.integers(0, 7))
+    jit = float(10.0 ** rng.uniform(-6.5, -1.0))
+    def make(rows):
+        if kind == 0:    # periodic rows, shifted copies of one sequence
+            P = int(rng.integers(2, 6000))
+            vals = rng.standard_normal(P)
+            x = vals[(np.arange(K)[None, :] + rng.integers(0, P, (rows, 1))) % P] * (1.0 + jit * rng.standard_normal((rows, K)) * (rng.integers(0, 2)))
+        elif kind == 1:  # a few levels, jittered
+            L = int(rng.integers(2, 33))
+            x = (rng.standard_normal(L) * 2)[rng.integers(0, L, (rows, K))] * (1.0 + jit * rng.standard_normal((rows, K)))
+        elif kind == 2:  # D distinct values at random
+            D = int(2 ** rng.uniform(1, 13))
+            x = rng.standard_normal(D)[rng.integers(0, D, (rows, K))]
+        elif kind == 3:  # the SAME level in a column for every row, rows scaled and jittered
+            L = int(rng.integers(2, 17))
+            x = (rng.standard_normal(L) * 2)[rng.integers(0, L, (1, K))] * rng.uniform(0.5, 2.0, (rows, 1)) * (1.0 + jit * rng.standard_normal((rows, K)))
+        elif kind == 4:  # quantised gaussian
+            q = 2.0 ** int(rng.integers(-8, 3))
+            x = np.rint(rng.standard_normal((rows, K)) * 3 / q) * q
+        elif kind == 5:  # count levels jittered by column statistics (what the pipeline hands over), tighter than real
+            c = rng.binomial(int(rng.integers(200, 4000)), 1.0 / K * rng.uniform(0.5, 8), (rows, K)).astype(np.float64)
+            m = 0.3 * (1.0 + jit * rng.standard_normal((1, K)))
+            x = (np.log2(c + 1.0) - m) / (0.45 * (1.0 + jit * rng.standard_normal((1, K))))
+        else:            # a smooth ramp or wave plus noise
+            t = np.arange(K)[None, :] / K
+            x = np.sin(2 * np.pi * t * rng.uniform(0.5, 40, (rows, 1)) + rng.uniform(0, 6, (rows, 1))) + jit * rng.standard_normal((rows, K))
+        x = np.array(x, dtype=np.float64)
+        if rng.integers(0, 3) == 0:  # some rows plain gaussian: ONE structured row has to be enough
+            plain = rng.integers(0, 2, rows).astype(bool)
+            x[plain] = rng.standard_normal((int(plain.sum()), K))
+        return x.astype(np.float32)
+    a = make(M)
+    b = a if same else make(N)
+    return a, b, True, dict(K=K, M=a.shape[0], N=b.shape[0], dt="f32", same=same, rs=True, kind=100 + kind, jitter=jit)
+
+
+LAYOUT_EVERY = 3 if os.environ.get("SEEKR_PRECISION", "") == "f16f8" else 40
+
+
 def fuzz(seed, budget_s=60.0, max_cases=10 ** 9):
     rng = np.random.default_rng(seed)
     t0, n_cases = time.time(), 0
     while time.time() - t0 < budget_s and n_cases < max_cases:
-        a, b, rs, tag = gen_case_wide(rng) if rng.integers(0, 200) == 0 else gen_case(rng)
+        pick = int(rng.integers(0, 200 * LAYOUT_EVERY))
+        a, b, rs, tag = gen_case_wide(rng) if pick == 0 else gen_case_layout(rng) if pick % LAYOUT_EVERY == 1 else gen_case(rng)
         same = tag["same"]
         try:
             with np.errstate(all="ignore"):

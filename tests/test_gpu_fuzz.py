@@ -116,3 +116,42 @@ def test_regression_rows_that_repeat_a_value_other_than_their_minimum(golden_dir
     ok = np.isfinite(ref)
     assert (np.abs(got - ref)[ok] <= (2e-6 + 1e-5 * np.abs(ref))[ok]).all()
     assert (np.abs(got - truth)[ok] <= 0.5 * (2e-6 + 1e-5 * np.abs(truth))[ok]).all()
+
+
+def test_regression_near_copies_of_a_two_level_row(golden_dir):
+    """Found by the structured-row class of tests/fuzz_pearson.py (round 4): 45 rows that are scaled, 6e-6-jittered copies of
+    ONE pattern on two levels (2 062 columns at -0.993, 2 034 at +1.007 after standardisation).  Every product of two such
+    rows is nearly 1, the k-tile sums that reach the MFMA's truncating accumulate are as regular as a clock, the truncations
+    all go one way: r = 1.0000122, 1.01 bars from float64 (the reference: 0.04).  A standardised row on two levels meets
+    kurtosis = skewness^2 + 1; the fills flag it 'coherent' and the contraction restarts its accumulators every 32 k-tiles."""
+    import os
+    import numpy as np
+    from oracle import seekr_oracle as orc
+    from seekr_amd import _lib as L
+    from seekr_amd.pearson import pearson
+    x = np.ascontiguousarray(np.load(os.path.join(golden_dir, "regress_r4_two_level_rows.npz"))["a"])
+    assert x.shape == (16, 4096)
+    with np.errstate(all="ignore"):
+        ref, truth = orc.pearson(x, x).astype(np.float64), orc.pearson_f64_truth(x, x)
+    got = pearson(x, x).astype(np.float64)
+    assert (np.abs(got - ref) <= 2e-6 + 1e-5 * np.abs(ref)).all()
+    assert (np.abs(got - truth) <= 0.5 * (2e-6 + 1e-5 * np.abs(truth))).all()
+    ctx = L.default_context()
+    rng = np.random.default_rng(1)
+    for K in (729, 4096, 16384, 65536):            # the generic, both register-resident and the workgroup-per-row fill
+        for share in (0.5, 0.3):
+            base = np.where(rng.random((1, K)) < share, 2.5, -0.75)
+            y = np.ascontiguousarray((base * rng.uniform(0.5, 2.0, (24, 1)) * (1 + 1e-6 * rng.standard_normal((24, K)))).astype(np.float32))
+            op, _ = L.operand_fill(ctx, ctx.from_numpy(y), precision=L.PREC_F16X3, row_standardize=True)
+            assert op.kind == 2 and op.coherent, (K, share)
+            r = ctx.empty(24, 24)
+            L.pearson_gemm_op(ctx, op, op, r, symmetric=True)
+            t = orc.pearson_f64_truth(y, y)
+            assert (np.abs(r.to_numpy() - t) <= 0.5 * (2e-6 + 1e-5 * np.abs(t))).all(), (K, share)
+        z = rng.standard_normal((24, K)).astype(np.float32)   # three levels and continuous rows stay as they were
+        op, _ = L.operand_fill(ctx, ctx.from_numpy(z), precision=L.PREC_F16X3, row_standardize=True)
+        assert not op.coherent
+        z3 = np.array([-1.0, 0.25, 2.0], np.float32)[rng.integers(0, 3, (24, K))]
+        op, _ = L.operand_fill(ctx, ctx.from_numpy(z3), precision=L.PREC_F16X3, row_standardize=True)
+        assert not op.coherent
+

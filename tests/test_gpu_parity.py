@@ -1479,6 +1479,57 @@ def test_f16f8_routes_tightly_clustered_rows(K, levels, jitter, kept, L, ctx):
         m.free()
 
 
+def test_f16f8_routes_rows_whose_levels_are_aligned(L, ctx, golden_dir):
+    """Found by the structured-row class of tests/fuzz_pearson.py under SEEKR_PRECISION=f16f8 (soak, round 4): the same level
+    in a column for EVERY row (rows scaled and jittered by 3e-5) — near-copies of each other that meet in the same pairs of
+    values in every column: r = 1.0000176, 1.5 bars.  The row means of the residues cancel between the levels; what does not
+    is the row's own cross-term error, the fourth statistic of the fill.  12 of the 33 rows of the failing case."""
+    x = np.ascontiguousarray(np.load(os.path.join(golden_dir, "regress_r4_f16f8_aligned_levels.npz"))["a"])
+    rows = len(x)
+    dev = ctx.from_numpy(x)
+    op8, _ = L.operand_fill(ctx, dev, precision=L.PREC_F16F8, row_standardize=True)
+    assert op8.kind == 2
+    r = ctx.empty(rows, rows)
+    L.pearson_gemm_op(ctx, op8, op8, r, symmetric=True)
+    got = r.to_numpy().astype(np.float64)
+    truth = orc.pearson_f64_truth(x, x)
+    assert (np.abs(got - truth) / (2e-6 + 1e-5 * np.abs(truth))).max() <= 0.5
+    for m in (dev, r, op8):
+        m.free()
+
+
+def test_f16f8_operands_filled_separately_are_checked_as_a_pair(L, ctx, golden_dir, monkeypatch):
+    """Found by tests/fuzz_pearson.py under SEEKR_PRECISION=f16f8 (round 4): pearson(a, b) of two DIFFERENT matrices, each on a
+    few aligned levels.  Each passes the rule on the row means on its own (bound 0.29 of the bar: a loses little in the fp8
+    copy of hi but its lo does not average out, b the other way round); together mean(hi - 128 h8) of b meets mean(lo) of a:
+    r = 0.00342 came out 1.4 bars off.  The fill keeps the three maxima with the operand (skr_operand_x8_stats), the
+    contraction refuses the pair, and skr_pearson refills both as f16x3."""
+    d = np.load(os.path.join(golden_dir, "regress_r4_f16f8_two_operands.npz"))
+    a, b = np.ascontiguousarray(d["a"]), np.ascontiguousarray(d["b"])
+    oa, _ = L.operand_fill(ctx, ctx.from_numpy(a), precision=L.PREC_F16F8, row_standardize=True)
+    ob, _ = L.operand_fill(ctx, ctx.from_numpy(b), precision=L.PREC_F16F8, row_standardize=True)
+    assert oa.kind == 3 and ob.kind == 3
+    sa, sb = oa.x8_stats, ob.x8_stats
+    assert oa.x8_bound() <= L.X8_MEANS_LIMIT and ob.x8_bound() <= L.X8_MEANS_LIMIT
+    assert max(sa[0] * sb[1], sb[0] * sa[1]) / 256.0 ** 2 > L.X8_MEANS_LIMIT   # the cross product of their means is not
+    r = ctx.empty(len(a), len(b))
+    with pytest.raises(NotImplementedError, match="do not go together"):
+        L.pearson_gemm_op(ctx, oa, ob, r)
+    L.pearson_gemm_op(ctx, oa, oa.view(0, 3), ctx.empty(len(a), 3))   # views of one operand always go together
+    from seekr_amd.pearson import pearson
+    monkeypatch.setenv("SEEKR_PRECISION", "f16f8")
+    got = pearson(a, b).astype(np.float64)
+    with np.errstate(all="ignore"):
+        ref, truth = orc.pearson(a, b).astype(np.float64), orc.pearson_f64_truth(a, b)
+    assert (np.abs(got - ref) <= 2e-6 + 1e-5 * np.abs(ref)).all()
+    assert (np.abs(got - truth) <= 0.5 * (2e-6 + 1e-5 * np.abs(truth))).all()
+    # a receive buffer that adopted its shard's layout takes the shard's (all-reduced) maxima over
+    buf = L.Operand(ctx, len(a), a.shape[1], L.PREC_F16F8).adopt_layout(oa)
+    assert buf.x8_stats == sa
+    for m in (oa, ob, r, buf):
+        m.free()
+
+
 def test_f16f8_degrades_on_other_widths_and_through_the_api(L, ctx, monkeypatch):
     rng = np.random.default_rng(3)
     for cols in (729, 1024):

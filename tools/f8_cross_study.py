@@ -36,8 +36,13 @@ def emulate(x, cols, want_means=False):
     if want_means:
         # the fill's third statistic: the largest row means of what the fp8 copies hold and lose -> a bound on the error
         # of a cell from the means alone, in units of the bar at r = 0 (skr_operand_fill routes above 0.6)
-        m = [np.abs(v.mean(1)).max() for v in (128.0 * h8, hi - 128.0 * h8, l8 / 16.0, lo - l8 / 16.0)]
-        return 2.0 * (m[1] * m[2] + m[0] * m[3]) / (s * s) / 2e-6
+        dh, dl = hi - 128.0 * h8, lo - l8 / 16.0
+        m = [np.abs(v.mean(1)).max() for v in (dh, lo, dl)]
+        means = 2.0 * (m[0] * (m[1] + m[2]) + (m[0] + m[1]) * m[2]) / (s * s) / 2e-6
+        # the fourth: the error of a row's cross term WITH ITSELF (rows whose levels are aligned meet in the same pairs), as a
+        # multiple of its threshold 3e-6
+        own = 2.0 * np.abs((hi * lo - (hi - dh) * (lo - dl)).mean(1)).max() / (s * s) / 3e-6
+        return means, own
     r8 = (hi @ hi.T + 8.0 * (h8 @ l8.T + l8 @ h8.T)) / (cols * s * s)
     r3 = (hi @ hi.T + hi @ lo.T + lo @ hi.T) / (cols * s * s)
     truth = (z.astype(np.float64) @ z.astype(np.float64).T) / cols
@@ -71,7 +76,7 @@ def main():
     K, n = args.cols, args.rows
     rng = np.random.default_rng(1)
     print("K = %d, %d rows; worst off-diagonal cell in bars vs float64: f16f8 | f16x3 operands; adjacent-equal share (max, min row); "
-          "occupied bits of the 2 K-bit value bitmap / K (worst row); the means bound in bars; routed by any rule (adjacent-equal >= K/256, fewer than 2 048 occupied bits, means bound > 0.6)" % (K, n))
+          "occupied bits of the 2 K-bit value bitmap / K (worst row); the means bound in bars; the row's own cross-term error / 3e-6; routed by any rule (adjacent-equal >= K/256, fewer than 2 048 occupied bits, means bound > 0.6, own error > 1)" % (K, n))
     cases = []
     cases.append(("gaussian (all distinct)", rng.standard_normal((n, K)).astype(np.float32)))
     for D in (8192, 4096, 2048, 1024, 512, 256, 128, 64, 16, 3):
@@ -90,13 +95,18 @@ def main():
         for jit in (1e-2, 1e-3, 3e-4, 1e-4, 1e-5):
             x = centres[rng.integers(0, nc, (n, K))] * (1.0 + jit * rng.standard_normal((n, K)))
             cases.append(("%2d levels, jitter %.0e (all distinct)" % (nc, jit), x.astype(np.float32)))
+    for nc in (2, 4, 16):
+        centres = (rng.standard_normal(nc) * 2).astype(np.float32)
+        for jit in (1e-3, 3e-5):
+            x = centres[rng.integers(0, nc, (1, K))] * rng.uniform(0.5, 2.0, (n, 1)) * (1.0 + jit * rng.standard_normal((n, K)))
+            cases.append(("%2d ALIGNED levels, jitter %.0e" % (nc, jit), x.astype(np.float32)))
     for name, x in cases:
         e8, e3 = emulate(x, K)
-        mb = emulate(x, K, want_means=True)
+        mb, own = emulate(x, K, want_means=True)
         amax, amin = adjacent_equal(x)
         occ = bitmap_share(x, K)
-        routed = amin >= 1.0 / 256.0 or occ * K < 2048 or mb > 0.6
-        print("%-36s %7.3f | %6.3f   adj-eq %.4f / %.4f  bitmap %.3f  means %6.3f  %s%s" % (name, e8, e3, amax, amin, occ, mb, "routed" if routed else "KEPT",
+        routed = amin >= 1.0 / 256.0 or occ * K < 2048 or mb > 0.6 or own > 1.0
+        print("%-36s %7.3f | %6.3f   adj-eq %.4f / %.4f  bitmap %.3f  means %6.3f  own %5.2f  %s%s" % (name, e8, e3, amax, amin, occ, mb, own, "routed" if routed else "KEPT",
                                                                    "  <-- over the bar, not routed" if (e8 > 1.0 and not routed) else ""))
 
 
