@@ -369,7 +369,8 @@ def _verdicts(comm, fell_back, coherent, has_nan, routed_back=False, x8_stats=No
     if comm.size > 1:
         gave_up = bool(getattr(comm, "chain_gave_up", lambda: False)())
         out = comm.allreduce([1.0 if fell_back else 0.0, 1.0 if coherent else 0.0, 1.0 if has_nan else 0.0,
-                              1.0 if gave_up else 0.0, 1.0 if routed_back else 0.0] + list(x8_stats or ()), "max")
+                              1.0 if gave_up else 0.0, 1.0 if routed_back else 0.0] + list(x8_stats or (0.0, 0.0, 0.0)), "max")
+        # (always eight values: ranks may mix the two entry points, and an all-reduce of different lengths never returns)
         if x8_stats is not None:  # the opt-in f16f8 layout: the three row-mean maxima of every shard, made global
             x8_stats[:] = out[5:8]
         if out[3] > 0:
