@@ -250,9 +250,10 @@ int skr_operand_fill(skr_ctx* ctx, const skr_mat* x, const skr_mat* center, cons
  * width (a receive buffer) with the kind and scale of `like`.                                    */
 int skr_operand_kind(const skr_operand* op, int* kind);
 int skr_operand_adopt_layout(skr_operand* op, const skr_operand* like);
-/* get (set = 0) or set (set != 0, from *value) the "rows are mostly one repeated value" flag that makes the
- * split contraction restart its accumulators every 1 024 columns; skr_operand_fill computes it from the rows
- * it sees, a multi-GPU caller all-reduces it so that every shard of a set carries the same value.            */
+/* get (set = 0) or set (set != 0, from *value) the "rows are mostly one repeated value, or lie on two tight levels"
+ * flag that makes the split contraction restart its accumulators every 1 024 columns (near-copies of such rows feed
+ * the MFMA's truncating accumulate sums that are all cut the same way: DESIGN.md §2); skr_operand_fill computes it
+ * from the rows it sees, a multi-GPU caller all-reduces it so that every shard of a set carries the same value.   */
 int skr_operand_coherent(skr_operand* op, int set, int* value);
 
 /* SKR_PREC_F16F8 only.  The fill of an operand in the H / X layout keeps three numbers with it — the largest |row mean| of
