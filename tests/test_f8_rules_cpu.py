@@ -52,3 +52,27 @@ def test_every_emulated_hazard_is_routed_and_plain_rows_are_kept():
         if not routed(x, K):
             kept_errors.append((name, err8))
     assert ("gaussian" in [k for k, _ in kept_errors]) and max(e for _, e in kept_errors) <= 0.6, kept_errors
+
+
+def test_two_level_statistic_separates_two_point_rows():
+    """The flag the fill kernels raise for rows on two tight levels (operand.hip: row_on_two_levels): for a standardised
+    row, kurtosis - skewness^2 - 1 >= 0 with equality exactly for a two-point distribution.  The numpy mirror of the
+    device arithmetic (float32 z, sums of z^2, z^3, z^4) on the classes the GPU test uses: two levels at any share with a
+    jitter up to 1 % fall below the 5e-3 threshold, three or more levels and continuous rows stay far above it."""
+    rng = np.random.default_rng(4)
+
+    def stat(x):
+        x = np.asarray(x, np.float32)
+        z = ((x - x.mean()) / x.std()).astype(np.float32).astype(np.float64)
+        var = (z ** 2).mean()
+        return (z ** 4).mean() / var ** 2 - ((z ** 3).mean() / var ** 1.5) ** 2 - 1.0
+
+    for K in (729, 4096, 16384, 65536):
+        for share in (0.5, 0.3, 0.1):
+            for jitter in (0.0, 1e-6, 1e-3, 1e-2):
+                base = np.where(rng.random(K) < share, 2.5, -0.75) * (1 + jitter * rng.standard_normal(K))
+                assert stat(base) < 5e-3, (K, share, jitter, stat(base))
+        assert stat(np.array([-1.0, 0.25, 2.0])[rng.integers(0, 3, K)]) > 0.1
+        assert stat(rng.standard_normal(K)) > 1.0
+        assert stat(rng.poisson(0.5, K)) > 0.5
+        assert stat(np.where(rng.random(K) < 0.5, 1.0, -1.0) * (1 + 0.1 * rng.standard_normal(K))) > 5e-3
