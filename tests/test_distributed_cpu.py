@@ -10,6 +10,7 @@ import pytest
 
 from oracle import seekr_oracle as orc
 import dist_worker
+import dist_worker_x8
 
 
 def free_port():
@@ -150,3 +151,32 @@ def test_shard_bounds():
     assert shard_bounds(10, 3) == [0, 4, 7, 10]
     assert shard_bounds(8, 8) == list(range(9))
     assert shard_bounds(5, 8)[-1] == 5 and len(shard_bounds(5, 8)) == 9
+
+
+@pytest.mark.parametrize("scenario,size", [("keep", 2), ("pair", 2), ("local", 2), ("pair", 3)])
+def test_f16f8_routing_is_decided_on_global_maxima(scenario, size, tmp_path):
+    """The opt-in f16f8 layout across ranks (round 4): the three row-mean maxima of every shard ride on the verdict
+    all-reduce of the normalisation, the rule is applied to the GLOBAL values — two shards that pass it on their own may
+    fail it together (the two-operand case of tests/golden/regress_r4_f16f8_two_operands.npz, here as two shards) — and
+    all ranks keep the layout, with the global maxima set on every shard, or all route back."""
+    from seekr_amd import _lib
+    ctx = mp.get_context("spawn")
+    port = free_port()
+    procs = [ctx.Process(target=dist_worker_x8.run, args=(rank, size, port, str(tmp_path), scenario)) for rank in range(size)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0, "rank exited with {}".format(p.exitcode)
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(size)]
+    if scenario == "keep":
+        assert all(int(p["kind"]) == 3 and not bool(p["refilled"]) for p in parts)
+        want = (1.0, 0.006, 0.0002)   # the element-wise maxima over the shards
+        assert all(np.allclose(p["stats"], want) for p in parts)
+    elif scenario == "pair":
+        assert all(float(p["own_bound"]) <= _lib.X8_MEANS_LIMIT for p in parts)     # every shard passes on its own
+        assert all(int(p["kind"]) == 2 and bool(p["refilled"]) for p in parts)     # ... and none keeps the layout
+    else:
+        assert [int(p["kind"]) for p in parts] == [2, 2]
+        assert [bool(p["refilled"]) for p in parts] == [False, True]               # rank 0's fill had routed it already
+
