@@ -126,6 +126,8 @@ def gen_case_layout(rng):
 
 
 LAYOUT_EVERY = 3 if os.environ.get("SEEKR_PRECISION", "") == "f16f8" else 40
+if os.environ.get("SEEKR_FUZZ_LAYOUT_EVERY"):  # a soak of the structured class alone: SEEKR_FUZZ_LAYOUT_EVERY=2
+    LAYOUT_EVERY = max(2, int(os.environ["SEEKR_FUZZ_LAYOUT_EVERY"]))
 
 
 def fuzz(seed, budget_s=60.0, max_cases=10 ** 9):
