@@ -266,9 +266,27 @@ int skr_operand_coherent(skr_operand* op, int set, int* value);
  * skr_operand_adopt_layout.  set = 0: read into v[3]; set = 1: store v[3].  Zeros for every other layout.
  * (New in round 4; the reference has no counterpart — numpy's float32 inner product, seekr/pearson.py:41.) */
 int skr_operand_x8_stats(skr_operand* op, int set, float* v);
-/* r[row0 + i, col0 + j] = <a_i, b_j> / K on prepared operands (same meaning as skr_pearson_gemm) */
+/* r[row0 + i, col0 + j] = <a_i, b_j> / K on prepared operands (same meaning as skr_pearson_gemm).
+ * symmetric = 2: a plain block whose cells carry the bits of the MIRROR of the swapped call — r[i, j] = what
+ * skr_pearson_gemm_op(b, a) leaves at [j, i].  The split contractions add a cell's three products in an order that
+ * names A's halves first, so a_i . b_j and b_j . a_i differ in the last bits; a self-comparison keeps, for both cells of
+ * a pair, the value computed with the row of the smaller index as A.  Whoever computes a block BELOW the diagonal of a
+ * self-comparison from its own rows (a row stripe, a GPU's row block) asks for it with 2 and gets those bits.       */
 int skr_pearson_gemm_op(skr_ctx* ctx, const skr_operand* a, const skr_operand* b, int symmetric, skr_mat* r,
                         int64_t row0, int64_t col0);
+/* A row stripe of a self-comparison (np.inner(z, z) / K of pearson.py:41 when r is produced stripe by stripe — larger
+ * than the HBM — or row block by row block on several GPUs): r[row0 + i, j] for the rows i of `a` and all rows j of
+ * `full`, bit for bit the rows a_row0 .. a_row0 + a.rows of skr_pearson_gemm_op(full, full, 1, ...).  `a` holds those
+ * rows: a view of `full`, or the rank's own shard, of which `full` holds the all-gathered copy.  r: float32, at least
+ * [row0 + a.rows, full.rows].                                                                                       */
+int skr_pearson_gemm_op_rows(skr_ctx* ctx, const skr_operand* a, const skr_operand* full, int64_t a_row0, skr_mat* r,
+                             int64_t row0);
+/* The float64 contraction of skr_pearson as a step of its own: r[row0 + i, col0 + j] = <a_i, b_j> / K for float64 rows
+ * that are standardised already (skr_row_standardize) and may be zero-padded to a->cols >= K columns.  symmetric != 0:
+ * a and b are the same rows (one triangle computed and mirrored).  Float64 products round once, so stripes of a
+ * self-comparison need no swapped form: any tiling gives the same bits.                                             */
+int skr_pearson_gemm_f64(skr_ctx* ctx, const skr_mat* a, const skr_mat* b, int64_t K, int symmetric, skr_mat* r,
+                         int64_t row0, int64_t col0);
 /* As skr_pearson_gemm_op without the symmetric shortcut, and additionally the transposed block
  * rt[trow0 + j, tcol0 + i] = r[row0 + i, col0 + j].  r(b, a) = r(a, b)^T (np.inner is
  * symmetric in its arguments, pearson.py:41), so a rank that multiplied shard a by shard b

@@ -95,6 +95,8 @@ SIGNATURES = {
     "skr_operand_coherent": (_int, [_p, _int, C.POINTER(_int)]),
     "skr_operand_x8_stats": (_int, [_p, _int, C.POINTER(C.c_float)]),
     "skr_pearson_gemm_op": (_int, [_p, _p, _p, _int, _p, _i64, _i64]),
+    "skr_pearson_gemm_op_rows": (_int, [_p, _p, _p, _i64, _p, _i64]),
+    "skr_pearson_gemm_f64": (_int, [_p, _p, _p, _i64, _int, _p, _i64, _i64]),
     "skr_pearson_gemm_op_mirror": (_int, [_p, _p, _p, _p, _i64, _i64, _p, _i64, _i64]),
     "skr_threshold_zero_diag": (_int, [_p, _p, C.c_float, _i64]),
     "skr_triu_flatten": (_int, [_p, _p, _i64, _p]),
@@ -683,8 +685,22 @@ def operand_fill(ctx, x, op=None, precision=PREC_F16X3, center=None, scale=None,
     return op, bool(nan.value)
 
 
-def pearson_gemm_op(ctx, a, b, r, symmetric=False, row0=0, col0=0):
-    check(lib().skr_pearson_gemm_op(ctx._h, a._h, b._h, 1 if symmetric else 0, r._h, int(row0), int(col0)))
+def pearson_gemm_op(ctx, a, b, r, symmetric=False, row0=0, col0=0, lower=False):
+    """lower: a plain block with the bits of the mirror of (b, a) — a block below the diagonal of a self-comparison
+    computed from its own rows (skr_pearson_gemm_op, symmetric = 2)."""
+    check(lib().skr_pearson_gemm_op(ctx._h, a._h, b._h, 2 if lower else (1 if symmetric else 0), r._h, int(row0), int(col0)))
+    return r
+
+
+def pearson_gemm_op_rows(ctx, a, full, a_row0, r, row0=0):
+    """r[row0 + i, :] = rows a_row0 + i of the self-comparison of `full`, bit for bit (skr_pearson_gemm_op_rows)."""
+    check(lib().skr_pearson_gemm_op_rows(ctx._h, a._h, full._h, int(a_row0), r._h, int(row0)))
+    return r
+
+
+def pearson_gemm_f64(ctx, a, b, r, K, symmetric=False, row0=0, col0=0):
+    """float64 standardised (possibly zero-padded) rows: r[row0 + i, col0 + j] = <a_i, b_j> / K (skr_pearson_gemm_f64)."""
+    check(lib().skr_pearson_gemm_f64(ctx._h, a._h, b._h, int(K), 1 if symmetric else 0, r._h, int(row0), int(col0)))
     return r
 
 

@@ -1341,19 +1341,60 @@ extern "C" int skr_pearson_gemm_op(skr_ctx* ctx, const skr_operand* a, const skr
     if (M == 0 || N == 0) return SKR_OK;
     float* C = (float*)r->data + (size_t)row0 * r->cols + col0;
     const bool self = a->data == b->data && M == N;
+    const bool lower = symmetric == 2;  // a plain block that carries the bits of the mirror of (b, a): pearson_bf16.hip, LOWER
     if (a->kind == 0) {
+        // float32 operands: a_i . b_j and b_j . a_i are the same products in the same k order — nothing to swap
         const int64_t Kp = a->kt * 32;
         SKR_TRY(skr_launch_gemm_f32(ctx, (const float*)a->data, (const float*)b->data, C, M, N, Kp, Kp, Kp, r->cols, K,
-                                    symmetric && self && row0 == col0));
+                                    symmetric == 1 && self && row0 == col0));
     } else {
         SKR_TRY(skr_launch_gemm_split(ctx, a->precision, a->data, b->data, C, M, N, a->kt, r->cols,
-                                      (float)K * a->scale * b->scale, symmetric && self ? 1 : 0, nullptr, 0,
+                                      (float)K * a->scale * b->scale, lower ? 4 : (symmetric && self ? 1 : 0), nullptr, 0,
                                       a->coherent || b->coherent));
     }
-    if (self && a->diag_valid && a->diag) {
+    if (self && !lower && a->diag_valid && a->diag) {
         hipLaunchKernelGGL(patch_diag_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream, C, r->cols,
                            a->diag, M);
         SKR_HIP(hipGetLastError());
+    }
+    return SKR_OK;
+}
+
+/* Rows of a self-comparison, one stripe at a time (a result larger than the HBM; the rows of one GPU of several):
+ * r[row0 + i, j] for the rows i of `a` and ALL rows j of `full`, bit for bit what skr_pearson_gemm_op(full, full, 1, ...)
+ * writes into rows a_row0 .. a_row0 + a->rows: the block left of the stripe's diagonal block with the products in the
+ * mirror's order (symmetric = 2), the diagonal block as a self-comparison of `a` (its diagonal patched from a's own
+ * fill), the block right of it plain.  `a`: a view of those rows of `full`, or — several GPUs — the rank's own shard,
+ * of which `full` holds the all-gathered copy. */
+extern "C" int skr_pearson_gemm_op_rows(skr_ctx* ctx, const skr_operand* a, const skr_operand* full, int64_t a_row0,
+                                        skr_mat* r, int64_t row0) {
+    SKR_REQUIRE(ctx && a && full && r, "NULL argument");
+    SKR_REQUIRE(a_row0 >= 0 && a_row0 + a->rows <= full->rows, "rows [%lld, %lld) outside the %lld rows of the full operand",
+                (long long)a_row0, (long long)(a_row0 + a->rows), (long long)full->rows);
+    const int64_t M = a->rows, N = full->rows;
+    if (a_row0 > 0) {
+        skr_operand left = *full;
+        left.rows = a_row0;
+        left.owner = false;
+        SKR_TRY(skr_pearson_gemm_op(ctx, a, &left, 2, r, row0, 0));
+    }
+    if (M > 0) {
+        // the diagonal block is mirrored inside r: SELF needs its square at the same offset in rows and columns of C
+        skr_mat sq = *r;
+        sq.owner = false;
+        SKR_REQUIRE(row0 >= 0 && row0 + M <= r->rows && a_row0 + M <= r->cols, "stripe [%lld+%lld] outside the result",
+                    (long long)row0, (long long)M);
+        sq.data = (char*)r->data + ((size_t)row0 * r->cols + (size_t)a_row0) * sizeof(float);
+        sq.rows = M;  // [M, ld = r->cols]: the block starts at its own (0, 0)
+        SKR_TRY(skr_pearson_gemm_op(ctx, a, a, 1, &sq, 0, 0));
+    }
+    if (a_row0 + M < N) {
+        skr_operand right = *full;
+        right.rows = N - a_row0 - M;
+        right.owner = false;
+        right.data = (char*)full->data + (size_t)(a_row0 + M) * full->row_bytes();
+        right.diag = nullptr;
+        SKR_TRY(skr_pearson_gemm_op(ctx, a, &right, 0, r, row0, a_row0 + M));
     }
     return SKR_OK;
 }
@@ -1453,6 +1494,26 @@ extern "C" int skr_pearson_gemm(skr_ctx* ctx, const skr_mat* a, const skr_mat* b
     skr_operand_free(oa);
     skr_operand_free(ob);
     return rc;
+}
+
+/* r[row0 + i, col0 + j] = <a_i, b_j> / K for float64 rows that are standardised already and may be zero-padded (the
+ * stored width a->cols >= K; skr_pearson pads to whole 16-column stages): the contraction of skr_pearson's float64 path
+ * as a step of its own, for callers that produce r one row stripe at a time or hold the rows of b on several GPUs.
+ * A product of two doubles has one rounding, so a_i . b_j and b_j . a_i are the same bits: stripes need no swapped form. */
+extern "C" int skr_pearson_gemm_f64(skr_ctx* ctx, const skr_mat* a, const skr_mat* b, int64_t K, int symmetric, skr_mat* r,
+                                    int64_t row0, int64_t col0) {
+    SKR_TRY(check_pair(ctx, a, b));
+    SKR_REQUIRE(a->dtype == SKR_F64, "float64 rows only");
+    SKR_REQUIRE(r && r->ctx == ctx && r->dtype == SKR_F64, "result matrix missing or not float64");
+    SKR_REQUIRE(K > 0 && K <= a->cols, "K = %lld outside 1..%lld (the stored width)", (long long)K, (long long)a->cols);
+    SKR_REQUIRE(row0 >= 0 && col0 >= 0 && row0 + a->rows <= r->rows && col0 + b->rows <= r->cols,
+                "result block [%lld+%lld, %lld+%lld] outside [%lld, %lld]", (long long)row0, (long long)a->rows,
+                (long long)col0, (long long)b->rows, (long long)r->rows, (long long)r->cols);
+    SKR_TRY(skr_activate(ctx));
+    if (a->rows == 0 || b->rows == 0) return SKR_OK;
+    return skr_launch_gemm_f64(ctx, (const double*)a->data, (const double*)b->data,
+                               (double*)r->data + (size_t)row0 * r->cols + col0, a->rows, b->rows, a->cols, a->cols, b->cols,
+                               r->cols, (double)K, symmetric && a->data == b->data && a->rows == b->rows);
 }
 
 extern "C" int skr_pearson(skr_ctx* ctx, const skr_mat* counts1, const skr_mat* counts2, int row_standardize,

@@ -41,7 +41,13 @@ namespace {
 constexpr int TM = 256, TN = 256;
 constexpr int kRowBytes = 128;                       // one k tile of one row: 32 hi + 32 lo bf16
 constexpr int kStageBytes = (TM + TN) * kRowBytes;   // 64 KiB
-enum { PLAIN = 0, SELF = 1, CROSS = 2, EDGES = 3 };
+enum { PLAIN = 0, SELF = 1, CROSS = 2, EDGES = 3, LOWER = 4 };
+// LOWER: a PLAIN block whose cells carry the bits the MIRROR of the swapped product would: C[i, j] = what PLAIN(b, a) puts
+// at [j, i].  Per accumulator the products enter in the order lo x hi, hi x lo, hi x hi (A's half named first), so a_i . b_j
+// and b_j . a_i differ in their last bits; SELF keeps the value computed with the row of the SMALLER index as A for both
+// cells of a pair.  A row stripe of a self-comparison (r larger than the HBM, or the rows of one GPU of several:
+// skr_pearson_gemm_op_rows) reproduces those bits with LOWER left of its diagonal block — the two cross products swap
+// places, nothing else changes — SELF on it and PLAIN right of it.
 
 // EDGES mode: the epilogue does not store the tile; cells that kmer_leiden.py:94-96 would leave non-zero
 // (`ld_sim[ld_sim < cutoff] = 0; np.fill_diagonal(ld_sim, 0)`: kept iff !(v < cutoff), v != 0, off the diagonal; with
@@ -157,6 +163,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
     constexpr int WN = WAVES == 8 ? 4 : 2, MT = 8, NT = WAVES == 8 ? 4 : 8, PP = 32 / WAVES;  // waves as 2 x WN, wave tile 128 x 16 NT
     constexpr int WTN = NT * 16;                                                                // wave tile width
     constexpr bool SYM = MODE == SELF;
+    constexpr bool SWAPPED = MODE == LOWER;  // the roles of A and B in the order of the products (comment at the enum)
+    static_assert(!SWAPPED || WAVES == 8, "LOWER exists for the 8-wave geometry");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int64_t s_bid;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -338,7 +346,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
                 if (t + 2 < kt) stage(cur ^ 1, t + 2);
                 const char* base = smem + cur * kStageBytes;
                 i32x8v a8[MT], b8[NT];
-                const int qa = 2 * q, qb = 2 * (q ^ 2);  // A lane group q reads bytes 32q.., B the other half of the line
+                // A lane group q reads bytes 32q.., B the other half of the line; LOWER: the other way round, so that k position
+                // for k position the products are those of the swapped call (the block scales are powers of two: exact)
+                const int qa = SWAPPED ? 2 * (q ^ 2) : 2 * q, qb = SWAPPED ? 2 * q : 2 * (q ^ 2);
 #pragma unroll
                 for (int i = 0; i < NT; i++) {
                     const i32x4v lo4 = *reinterpret_cast<const i32x4v*>(base + b_off[i] + ((qb ^ b_swz[i]) << 4));
@@ -381,8 +391,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
     #pragma unroll
                 for (int nt = 0; nt < NT; nt++) {
                     if (NPROD >= 4) acc[mt][nt] = mfma16x16(alo[mt], blo[nt], acc[mt][nt]);
-                    acc[mt][nt] = mfma16x16(alo[mt], bhi[nt], acc[mt][nt]);
-                    acc[mt][nt] = mfma16x16(ahi[mt], blo[nt], acc[mt][nt]);
+                    if (SWAPPED) {
+                        acc[mt][nt] = mfma16x16(ahi[mt], blo[nt], acc[mt][nt]);
+                        acc[mt][nt] = mfma16x16(alo[mt], bhi[nt], acc[mt][nt]);
+                    } else {
+                        acc[mt][nt] = mfma16x16(alo[mt], bhi[nt], acc[mt][nt]);
+                        acc[mt][nt] = mfma16x16(ahi[mt], blo[nt], acc[mt][nt]);
+                    }
                     acc[mt][nt] = mfma16x16(ahi[mt], bhi[nt], acc[mt][nt]);
                 }
             __syncthreads();
@@ -700,7 +715,7 @@ int launch_chunk(skr_ctx* ctx, const T* Ac, const T* Bc, const SplitOut& o, int6
 #endif
         unsigned threads = 512;
 #ifdef SEEKR_DIAG
-        if constexpr (NPROD == 3) {
+        if constexpr (NPROD == 3 && MODE != LOWER) {
             // A/B arm (libseekr_hip_diag.so only; measured 13 % slower): 4 waves x 128 x 128 (kernel comment)
             if (ctx->knobs.gemm_wave_tile == 1 && !diag) {
                 kern = pearson_gemm_split16_kernel<T, NPROD, MODE, true, false, 4>;
@@ -764,6 +779,7 @@ int gemm_split(skr_ctx* ctx, const T* As, const T* Bs, const SplitOut& o, int64_
         case EDGES: return launch16<T, NPROD, EDGES>(ctx, As, Bs, o, M, N, kt, K, name, coherent, sink);
         case SELF: return launch16<T, NPROD, SELF>(ctx, As, Bs, o, M, N, kt, K, name, coherent);
         case CROSS: return launch16<T, NPROD, CROSS>(ctx, As, Bs, o, M, N, kt, K, name, coherent);
+        case LOWER: return launch16<T, NPROD, LOWER>(ctx, As, Bs, o, M, N, kt, K, name, coherent);
         default: return launch16<T, NPROD, PLAIN>(ctx, As, Bs, o, M, N, kt, K, name, coherent);
     }
 }
@@ -772,7 +788,7 @@ int gemm_split(skr_ctx* ctx, const T* As, const T* Bs, const SplitOut& o, int64_
 
 // A, B: split-interleaved operands ([rows, kt, {hi,lo}, 32] 16-bit halves) produced by operand.hip.
 // K: the divisor (columns x the operands' storage scales).  mode 0: C = A B^T / K; 1: A == B, one triangle computed and mirrored inside C; 2: C as mode 0 and
-// Ct[j * ldct + i] = C[i * ldc + j] as well.
+// Ct[j * ldct + i] = C[i * ldc + j] as well; 4: C as mode 0 with the bits of the swapped call's mirror (LOWER, above).
 int skr_launch_gemm_split(skr_ctx* ctx, int precision, const void* As, const void* Bs, float* C, int64_t M, int64_t N,
                           int64_t kt, int64_t ldc, float K, int mode, float* Ct, int64_t ldct, bool coherent) {
     SplitOut o{C, ldc, mode == SELF ? C : Ct, mode == SELF ? ldc : ldct};
