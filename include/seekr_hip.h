@@ -97,6 +97,13 @@ int skr_mat_shape(const skr_mat* m, int64_t* rows, int64_t* cols, int* dtype);
 /* copy `nrows` rows starting at `row0` between a dense host buffer and the matrix */
 int skr_mat_upload(skr_mat* m, const void* host, int64_t row0, int64_t nrows);
 int skr_mat_download(const skr_mat* m, void* host, int64_t row0, int64_t nrows);
+/* A download that runs BESIDE the compute stream.  skr_ctx_mark notes the point the compute stream has reached (the work
+ * enqueued so far); skr_mat_download_at copies rows to the host on the ctx's copy stream as soon as that point is passed —
+ * not waiting for work enqueued after the mark — and returns when the rows are in `host`.  A caller that produces r one
+ * row stripe at a time enqueues the contraction of stripe s + 1, then downloads stripe s: the two overlap.  A mark is
+ * used once; mark < 0 = "everything enqueued so far".                                                                */
+int skr_ctx_mark(skr_ctx* ctx, int64_t* mark);
+int skr_mat_download_at(const skr_mat* m, void* host, int64_t row0, int64_t nrows, int64_t mark);
 int skr_mat_fill_zero(skr_mat* m);
 /* non-owning view of rows [row0, row0+nrows) of `parent`; free it with skr_mat_free before the parent */
 int skr_mat_view(const skr_mat* parent, int64_t row0, int64_t nrows, skr_mat** out);
@@ -111,6 +118,18 @@ int skr_mat_device_ptr(const skr_mat* m, void** ptr);
  * fasta_reader.py:55,62; a caller assigning `seqs` directly gets lower case skipped).      */
 int skr_seqs_pack(skr_ctx* ctx, const char* bases, const int64_t* offsets, int64_t n,
                   const char alphabet[4], skr_seqs** out);
+/* The reader's half of skr_seqs_from_fasta as a step of its own: the file parsed into host memory once (same semantics,
+ * same errors), then packed onto one GPU or, range by range, onto several — each GPU packs and uploads the sequences it
+ * will count (skr_fasta_pack only reads the parsed file: the ranges may be packed from several host threads at once).
+ * lengths: int64 [n]; headers as skr_seqs_headers.                                                                   */
+typedef struct skr_fasta skr_fasta;
+int skr_fasta_open(const char* path, skr_fasta** out);
+int skr_fasta_free(skr_fasta* fa);
+int skr_fasta_info(const skr_fasta* fa, int64_t* n, int64_t* total_bases);
+int skr_fasta_lengths(const skr_fasta* fa, int64_t* lengths);
+int skr_fasta_headers(const skr_fasta* fa, char* buf, int64_t cap, int64_t* needed);
+int skr_fasta_pack(skr_ctx* ctx, const skr_fasta* fa, int64_t first, int64_t count, const char alphabet[4],
+                   skr_seqs** out);
 /* Read + pack a FASTA file with the reference reader's semantics (fasta_reader.py:41-63):
  * lines stripped, '>' first char == header, other lines concatenated and upper-cased.
  * Headers are returned through skr_seqs_headers.                                            */
@@ -266,6 +285,10 @@ int skr_operand_coherent(skr_operand* op, int set, int* value);
  * skr_operand_adopt_layout.  set = 0: read into v[3]; set = 1: store v[3].  Zeros for every other layout.
  * (New in round 4; the reference has no counterpart — numpy's float32 inner product, seekr/pearson.py:41.) */
 int skr_operand_x8_stats(skr_operand* op, int set, float* v);
+/* The rule on those maxima as the library applies it: *bound = the error of a cell of r that the row means of a's and b's
+ * rounding residues allow (b == a: the rows of one matrix against each other), *ok = whether skr_operand_fill's limit
+ * admits it.  0 / ok for operands in any other layout.  A multi-GPU caller sets the all-reduced maxima and asks here. */
+int skr_operand_x8_pair_bound(const skr_operand* a, const skr_operand* b, double* bound, int* ok);
 /* r[row0 + i, col0 + j] = <a_i, b_j> / K on prepared operands (same meaning as skr_pearson_gemm).
  * symmetric = 2: a plain block whose cells carry the bits of the MIRROR of the swapped call — r[i, j] = what
  * skr_pearson_gemm_op(b, a) leaves at [j, i].  The split contractions add a cell's three products in an order that
@@ -389,6 +412,14 @@ int skr_host_pearson(skr_ctx* ctx, const void* a, int64_t m, const void* b, int6
  * through pinned buffers; text is formatted by `threads` host threads (0 = pick).  The host
  * variants take a C-contiguous array in host memory and need no device.                      */
 int skr_mat_save_npy(skr_ctx* ctx, const skr_mat* m, int one_dim, const char* path);
+/* np.save of a matrix that comes into being one row stripe at a time, on one GPU or on several at once (pearson.py:43
+ * when r is larger than the HBM, or each GPU holds a row block): skr_npy_create writes numpy's header for [rows, cols]
+ * and gives the file its final size (*data_offset = where row 0 starts); skr_mat_write_rows_at then streams rows of a
+ * device matrix to byte offset file_offset (pwrite; through pinned buffers on the copy stream, behind `mark` as
+ * skr_mat_download_at) — stripes in any order, from any number of threads.                                           */
+int skr_npy_create(const char* path, int dtype, int64_t rows, int64_t cols, int64_t* data_offset);
+int skr_mat_write_rows_at(const skr_mat* m, int64_t row0, int64_t nrows, const char* path, int64_t file_offset,
+                          int64_t mark);
 int skr_mat_save_csv(skr_ctx* ctx, const skr_mat* m, int fmt_mode, int threads, const char* path);
 int skr_host_save_npy(const void* data, int dtype, int64_t rows, int64_t cols, int one_dim, const char* path);
 int skr_host_save_csv(const void* data, int dtype, int64_t rows, int64_t cols, int fmt_mode, int threads,

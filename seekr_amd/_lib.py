@@ -6,7 +6,6 @@ box so that the build step and the host-logic tests can run there.
 """
 import atexit
 import ctypes as C
-import math
 import os
 import threading
 
@@ -20,7 +19,6 @@ SKR_OK = 0
 F32, F64, U32 = 0, 1, 2
 LOG2_NONE, LOG2_PRE, LOG2_POST = 0, 1, 2
 PREC_FP32, PREC_BF16X3, PREC_F64, PREC_BF16X4, PREC_F16X3, PREC_F16F8 = 0, 1, 2, 3, 4, 5
-X8_MEANS_LIMIT = 0.6 * 2e-6  # kX8MeansLimit of the library: what the f16f8 rule on the row means allows (of r)
 LOG2_CODES = {"Log2.none": LOG2_NONE, "Log2.pre": LOG2_PRE, "Log2.post": LOG2_POST}
 PRECISIONS = {"fp32": PREC_FP32, "bf16x3": PREC_BF16X3, "bf16x4": PREC_BF16X4, "f16x3": PREC_F16X3, "f64": PREC_F64,
               "f16f8": PREC_F16F8}  # f16f8: opt-in, two product-units per k; degrades to f16x3 by itself
@@ -52,6 +50,17 @@ SIGNATURES = {
     "skr_mat_upload": (_int, [_p, _p, _i64, _i64]),
     "skr_mat_download": (_int, [_p, _p, _i64, _i64]),
     "skr_mat_fill_zero": (_int, [_p]),
+    "skr_ctx_mark": (_int, [_p, C.POINTER(_i64)]),
+    "skr_mat_download_at": (_int, [_p, _p, _i64, _i64, _i64]),
+    "skr_npy_create": (_int, [C.c_char_p, _int, _i64, _i64, C.POINTER(_i64)]),
+    "skr_mat_write_rows_at": (_int, [_p, _i64, _i64, C.c_char_p, _i64, _i64]),
+    "skr_fasta_open": (_int, [C.c_char_p, C.POINTER(_p)]),
+    "skr_fasta_free": (_int, [_p]),
+    "skr_fasta_info": (_int, [_p, C.POINTER(_i64), C.POINTER(_i64)]),
+    "skr_fasta_lengths": (_int, [_p, _p]),
+    "skr_fasta_headers": (_int, [_p, C.c_char_p, _i64, C.POINTER(_i64)]),
+    "skr_fasta_pack": (_int, [_p, _p, _i64, _i64, C.c_char_p, C.POINTER(_p)]),
+    "skr_operand_x8_pair_bound": (_int, [_p, _p, C.POINTER(C.c_double), C.POINTER(_int)]),
     "skr_mat_view": (_int, [_p, _i64, _i64, C.POINTER(_p)]),
     "skr_mat_device_ptr": (_int, [_p, C.POINTER(_p)]),
     "skr_seqs_pack": (_int, [_p, _p, _p, _i64, C.c_char_p, C.POINTER(_p)]),
@@ -225,6 +234,12 @@ class Context:
     def sync(self):
         check(lib().skr_ctx_sync(self._h))
 
+    def mark(self):
+        """The point the compute stream has reached (skr_ctx_mark): Matrix.to_numpy_at / write_rows_at wait for it only."""
+        m = _i64(-1)
+        check(lib().skr_ctx_mark(self._h, C.byref(m)))
+        return m.value
+
     def mem_info(self):
         """(free, total) bytes of device memory."""
         f, t = C.c_uint64(0), C.c_uint64(0)
@@ -283,8 +298,12 @@ _default_ctx = {}
 
 
 def default_context():
-    """Process-wide context on device $SEEKR_DEVICE (default 0)."""
-    dev = int(os.environ.get("SEEKR_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    """Process-wide context on device $SEEKR_DEVICE (default: the one device SEEKR_DEVICES names, else LOCAL_RANK, else 0)."""
+    dev = os.environ.get("SEEKR_DEVICE")
+    if dev is None:
+        listed = [t for t in os.environ.get("SEEKR_DEVICES", "").split(",") if t.strip()]
+        dev = listed[0] if len(listed) == 1 and listed[0].strip().isdigit() else os.environ.get("LOCAL_RANK", "0")
+    dev = int(dev)
     ctx = _default_ctx.get(dev)
     if ctx is None:
         ctx = _default_ctx[dev] = Context(dev)
@@ -334,6 +353,17 @@ class Matrix:
         if a.shape[1] != self.cols:
             raise ValueError("column count mismatch")
         check(lib().skr_mat_upload(self._h, a.ctypes.data_as(_p), int(row0), a.shape[0]))
+
+    def to_numpy_at(self, mark, out, row0=0):
+        """Rows [row0, row0 + len(out)) into `out` on the copy stream, as soon as the compute stream has passed `mark`
+        (Context.mark(); work enqueued after the mark is not waited for): skr_mat_download_at."""
+        assert out.flags.c_contiguous and out.dtype == self.dtype and out.ndim == 2 and out.shape[1] == self.cols
+        check(lib().skr_mat_download_at(self._h, out.ctypes.data_as(_p), int(row0), int(out.shape[0]), int(mark)))
+        return out
+
+    def write_rows_at(self, mark, path, file_offset, row0, nrows):
+        """Rows [row0, row0 + nrows) to byte `file_offset` of the file (skr_mat_write_rows_at), behind `mark`."""
+        check(lib().skr_mat_write_rows_at(self._h, int(row0), int(nrows), os.fsencode(path), int(file_offset), int(mark)))
 
     def to_numpy(self, row0=0, nrows=None, out=None):
         nrows = self.rows - row0 if nrows is None else nrows
@@ -401,12 +431,14 @@ class Operand:
         v = (C.c_float * 3)(*[float(t) for t in values])
         check(lib().skr_operand_x8_stats(self._h, 1, v))
 
-    def x8_bound(self, stats=None):
-        """The bound on the error of a cell of r that follows from the row means alone (operand.hip, X8), for this operand
-        against itself with its own or with the given (e.g. all-reduced) maxima; X8_MEANS_LIMIT is what the fill allows."""
-        d, l, dl = self.x8_stats if stats is None else stats
-        s = 2.0 ** math.floor(math.log2(32768.0 / math.sqrt(self.cols)))
-        return 2.0 * (d * (l + dl) + (d + l) * dl) / (s * s)
+    def x8_pair_bound(self, other=None):
+        """(bound, ok): the error of a cell of r that the row means of the rounding residues allow when rows of this
+        operand meet rows of `other` (None: its own rows) in the f16f8 layout, from the maxima the operands carry NOW
+        (x8_stats; a multi-GPU caller sets the all-reduced ones first), and whether the fill's limit admits it — the
+        library's own rule (skr_operand_x8_pair_bound), never re-derived here.  (0, True) for any other layout."""
+        bound, ok = C.c_double(0), _int(1)
+        check(lib().skr_operand_x8_pair_bound(self._h, (other or self)._h, C.byref(bound), C.byref(ok)))
+        return bound.value, bool(ok.value)
 
     def adopt_layout(self, like):
         """Tag this buffer (a receive buffer) with the storage kind of `like`."""
@@ -440,6 +472,48 @@ class Operand:
 
 def _h(m):
     return m._h if m is not None else None
+
+
+class FastaFile:
+    """A FASTA file parsed into host memory with the reference reader's semantics (skr_fasta): read once, then packed
+    onto one GPU or range by range onto several (pack() only reads: the GPUs of a node pack their ranges at once)."""
+
+    def __init__(self, path):
+        self._h = _p()
+        check(lib().skr_fasta_open(os.fsencode(path), C.byref(self._h)))
+        n, tot = _i64(0), _i64(0)
+        check(lib().skr_fasta_info(self._h, C.byref(n), C.byref(tot)))
+        self.n, self.total_bases = n.value, tot.value
+
+    def lengths(self):
+        out = np.empty(self.n, dtype=np.int64)
+        check(lib().skr_fasta_lengths(self._h, out.ctypes.data_as(_p)))
+        return out
+
+    def headers(self):
+        need = _i64(0)
+        check(lib().skr_fasta_headers(self._h, None, 0, C.byref(need)))
+        buf = C.create_string_buffer(max(need.value, 1))
+        check(lib().skr_fasta_headers(self._h, buf, need.value, None))
+        text = buf.value.decode("utf-8", "replace")
+        return text.split("\n") if text else []
+
+    def pack(self, ctx, first=0, count=None, alphabet="AGTC"):
+        count = self.n - first if count is None else count
+        h = _p()
+        check(lib().skr_fasta_pack(ctx._h, self._h, int(first), int(count), PackedSeqs._alpha(alphabet), C.byref(h)))
+        return PackedSeqs(ctx, h)
+
+    def free(self):
+        if getattr(self, "_h", None) and not _shutdown:
+            lib().skr_fasta_free(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 class PackedSeqs:
@@ -725,6 +799,14 @@ def npy_path(path):
     """np.save appends '.npy' unless the name already ends with it (kmer_counts.py:234 relies on it)."""
     path = os.fspath(path)
     return path if path.endswith(".npy") else path + ".npy"
+
+
+def npy_create(path, dtype, rows, cols):
+    """Create `path` (as given: no '.npy' is appended here) with numpy's header for a [rows, cols] array and its final
+    size; returns the byte offset of row 0 (skr_npy_create).  Stripes are then written with Matrix.write_rows_at."""
+    off = _i64(0)
+    check(lib().skr_npy_create(os.fsencode(path), _NP_DTYPES[np.dtype(dtype)], int(rows), int(cols), C.byref(off)))
+    return off.value
 
 
 def save_npy(path, a):

@@ -100,15 +100,16 @@ def _read_labelled_csv(path):
 
 def _run_pearson(counts1, counts2, outfile, binary_input, binary_output):
     names1 = names2 = None
+    same_file = counts1 == counts2  # one file twice: read once, and the contraction computes one triangle
     if binary_input:
         counts1 = np.load(counts1)
-        counts2 = np.load(counts2)
+        counts2 = counts1 if same_file else np.load(counts2)
     else:  # labelled CSVs; float64 path (console_scripts.py:628-631)
-        same_file = counts1 == counts2
         counts1, names1 = _read_labelled_csv(counts1)
         counts2, names2 = (counts1, names1) if same_file else _read_labelled_csv(counts2)
     if binary_output:
-        pearson_mod.pearson(counts1, counts2, outfile=outfile)
+        # np.save(outfile, dist) without dist ever standing in host memory: stripes of r go from the GPU(s) to the file
+        pearson_mod.pearson_to_file(counts1, counts2, outfile)
     else:
         dist = pearson_mod.pearson(counts1, counts2)
         # pd.DataFrame(dist, names1, names2).to_csv(outfile); names None -> RangeIndex labels 0..n-1

@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <rccl/rccl.h>
 
 #include "common.hpp"
@@ -26,7 +27,10 @@ struct RcclApi {
 
 RcclApi g_api;
 
+std::mutex g_api_lock;  // several host threads, one per GPU, may come here at once (seekr_amd/multi.py)
+
 int load_rccl() {
+    std::lock_guard<std::mutex> guard(g_api_lock);
     if (g_api.handle) return SKR_OK;
     // SEEKR_RCCL_LIB: test hook, honoured only under SEEKR_TEST_HOOKS=1 — tests/mock_rccl stands in for RCCL so that
     // several ranks can share the one GPU of a test box (RCCL refuses that); never set in production

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -41,6 +42,15 @@ struct skr_ctx {
     std::map<std::pair<const void*, size_t>, int> occupancy;  // hipOccupancyMaxActiveBlocksPerMultiprocessor results
     hipStream_t stream = nullptr;       // compute stream
     hipStream_t comm_stream = nullptr;  // RCCL traffic, overlapped with compute
+    // downloads that run beside the compute stream (skr_mat_download_at / skr_mat_write_rows_at: stripe s of r goes to
+    // the host while stripe s + 1 is contracted); created on first use.  A "mark" is an event recorded on the compute
+    // stream (skr_ctx_mark): the copy waits for that point only, not for what was enqueued after it.
+    hipStream_t copy_stream = nullptr;
+    std::vector<hipEvent_t> marks;   // slot -> event (created once, recycled)
+    std::vector<int> free_marks;
+    std::vector<uint8_t> mark_live;
+    void* h_copy[2] = {nullptr, nullptr};  // pinned staging of skr_mat_write_rows_at
+    size_t h_copy_bytes = 0;
     int num_cu = 256;
     // small device scratch: [0] encoded min, [1] nan flag, [2] error flag, ...
     uint32_t* d_flags = nullptr;
@@ -87,6 +97,9 @@ struct skr_ctx {
         hipEvent_t comm_done = nullptr;
     };
     std::vector<SmallBlock> small_blocks;
+    // a matrix may be freed by another host thread than the one driving this ctx (Python's collector runs where it
+    // likes; seekr_amd/multi.py has one thread per GPU): the list above is the only ctx state a free touches
+    std::mutex small_lock;
 };
 
 struct skr_mat {
@@ -212,6 +225,9 @@ inline double skr_x8_pair_bound(const skr_operand* a, const skr_operand* b) {
 constexpr double kX8MeansLimit = 0.6 * 2e-6;  // of the bar at r = 0
 int skr_x8_pair_check(const skr_operand* a, const skr_operand* b);  // operand.hip
 int skr_activate(const skr_ctx* ctx);
+// the copy stream, made to wait for `mark` (skr_ctx_mark; consumed here) or, mark < 0, for everything enqueued on the
+// compute stream so far
+int skr_copy_stream_after(skr_ctx* ctx, int64_t mark, hipStream_t* out);
 
 // float32 log2 rounded from a float64 evaluation: correctly rounded except for near-ties of the
 // f64 result, which is the closest a device can get to numpy's log2 (SVML / libm are correctly

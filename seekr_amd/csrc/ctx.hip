@@ -117,8 +117,13 @@ extern "C" int skr_ctx_destroy(skr_ctx* ctx) {
     if (ctx->d_recip) (void)hipFree(ctx->d_recip);
     if (ctx->d_np_plan) (void)hipFree(ctx->d_np_plan);
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
+    for (hipEvent_t ev : ctx->marks)
+        if (ev) (void)hipEventDestroy(ev);
+    for (void* hp : ctx->h_copy)
+        if (hp) (void)hipHostFree(hp);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     delete ctx;
     return SKR_OK;
 }
@@ -137,6 +142,54 @@ extern "C" int skr_ctx_sync(skr_ctx* ctx) {
     SKR_TRY(skr_activate(ctx));
     SKR_HIP(hipStreamSynchronize(ctx->stream));
     SKR_HIP(hipStreamSynchronize(ctx->comm_stream));
+    if (ctx->copy_stream) SKR_HIP(hipStreamSynchronize(ctx->copy_stream));
+    return SKR_OK;
+}
+
+// ---------------------------------------------------------------- marks + the copy stream
+extern "C" int skr_ctx_mark(skr_ctx* ctx, int64_t* mark) {
+    SKR_REQUIRE(ctx && mark, "NULL argument");
+    SKR_TRY(skr_activate(ctx));
+    int slot;
+    if (!ctx->free_marks.empty()) {
+        slot = ctx->free_marks.back();
+        ctx->free_marks.pop_back();
+    } else {
+        SKR_REQUIRE(ctx->marks.size() < 4096, "more than 4 096 marks are waiting to be used");
+        hipEvent_t ev = nullptr;
+        SKR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        ctx->marks.push_back(ev);
+        ctx->mark_live.push_back(0);
+        slot = (int)ctx->marks.size() - 1;
+    }
+    hipError_t e = hipEventRecord(ctx->marks[slot], ctx->stream);
+    if (e != hipSuccess) {
+        ctx->free_marks.push_back(slot);
+        return skr_set_error(SKR_ERR_HIP, "hipEventRecord failed: %s", hipGetErrorString(e));
+    }
+    ctx->mark_live[slot] = 1;
+    *mark = slot;
+    return SKR_OK;
+}
+
+int skr_copy_stream_after(skr_ctx* ctx, int64_t mark, hipStream_t* out) {
+    SKR_TRY(skr_activate(ctx));
+    if (!ctx->copy_stream) SKR_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (mark >= 0) {
+        SKR_REQUIRE(mark < (int64_t)ctx->marks.size() && ctx->mark_live[mark], "unknown mark (each mark is used once)");
+        hipError_t e = hipStreamWaitEvent(ctx->copy_stream, ctx->marks[mark], 0);
+        ctx->mark_live[mark] = 0;
+        ctx->free_marks.push_back((int)mark);
+        if (e != hipSuccess) return skr_set_error(SKR_ERR_HIP, "hipStreamWaitEvent failed: %s", hipGetErrorString(e));
+    } else {
+        hipEvent_t now;
+        SKR_HIP(hipEventCreateWithFlags(&now, hipEventDisableTiming));
+        hipError_t e = hipEventRecord(now, ctx->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, now, 0);
+        (void)hipEventDestroy(now);
+        if (e != hipSuccess) return skr_set_error(SKR_ERR_HIP, "ordering the copy stream failed: %s", hipGetErrorString(e));
+    }
+    *out = ctx->copy_stream;
     return SKR_OK;
 }
 
@@ -278,6 +331,7 @@ extern "C" int skr_mat_create(skr_ctx* ctx, int64_t rows, int64_t cols, int dtyp
     size_t bytes = m->bytes();
     if (bytes == 0) bytes = 16;
     if (bytes <= kSmallBlockBytes) {  // a recycled block of exactly this size (see skr_mat_free)
+        std::lock_guard<std::mutex> guard(ctx->small_lock);
         for (size_t i = 0; i < ctx->small_blocks.size(); i++) {
             if (ctx->small_blocks[i].bytes != bytes) continue;
             skr_ctx::SmallBlock b = ctx->small_blocks[i];
@@ -309,6 +363,7 @@ extern "C" int skr_mat_free(skr_mat* m) {
     if (m->owner) {  // views own nothing: no synchronisation needed to drop them
         (void)hipSetDevice(m->ctx->device);
         const size_t bytes = m->bytes() ? m->bytes() : 16;
+        std::unique_lock<std::mutex> guard(m->ctx->small_lock);
         if (m->data && bytes <= kSmallBlockBytes && m->ctx->small_blocks.size() < kSmallBlockCap) {
             // keep the block for the next matrix of this size: no hipFree, hence no host synchronisation
             skr_ctx::SmallBlock b;
@@ -322,6 +377,7 @@ extern "C" int skr_mat_free(skr_mat* m) {
             }
             if (b.comm_done) (void)hipEventDestroy(b.comm_done);
         }
+        guard.unlock();
         (void)hipStreamSynchronize(m->ctx->stream);
         (void)hipStreamSynchronize(m->ctx->comm_stream);
         if (m->data) (void)hipFree(m->data);
@@ -387,6 +443,19 @@ extern "C" int skr_mat_download(const skr_mat* m, void* host, int64_t row0, int6
     SKR_HIP(hipMemcpyAsync(host, (const char*)m->data + (size_t)row0 * rb, (size_t)nrows * rb,
                            hipMemcpyDeviceToHost, m->ctx->stream));
     SKR_HIP(hipStreamSynchronize(m->ctx->stream));
+    return SKR_OK;
+}
+
+// skr_mat_download beside the compute stream: the copy waits for `mark` (or, mark < 0, for what is enqueued now), the
+// compute stream does not wait for the copy — the caller enqueued the next stripe's contraction before it came here.
+extern "C" int skr_mat_download_at(const skr_mat* m, void* host, int64_t row0, int64_t nrows, int64_t mark) {
+    SKR_TRY(check_rows(m, host, row0, nrows));
+    hipStream_t cs = nullptr;
+    SKR_TRY(skr_copy_stream_after(m->ctx, mark, &cs));
+    size_t rb = (size_t)m->cols * m->elem();
+    if (nrows * rb == 0) return SKR_OK;
+    SKR_HIP(hipMemcpyAsync(host, (const char*)m->data + (size_t)row0 * rb, (size_t)nrows * rb, hipMemcpyDeviceToHost, cs));
+    SKR_HIP(hipStreamSynchronize(cs));
     return SKR_OK;
 }
 

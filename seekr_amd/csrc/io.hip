@@ -5,6 +5,9 @@
 // byte-identical to numpy's output.  Device matrices are streamed through two pinned buffers
 // (the D2H copy of chunk i+1 overlaps formatting / writing chunk i); text is formatted by a pool
 // of host threads, each on its own row range, and written in order.  Host code only — no kernel.
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cerrno>
 #include <cmath>
@@ -586,6 +589,93 @@ extern "C" int skr_mat_save_npy(skr_ctx* ctx, const skr_mat* m, int one_dim, con
     return stream_rows(ctx, m, (int64_t)((64u << 20) / rb) + 1, [&](const void* host, int64_t, int64_t n) {
         return write_all(f.fh, host, (size_t)n * m->cols * m->elem(), path);
     });
+}
+
+// ---- np.save of a matrix that comes into being one row stripe at a time, possibly on several GPUs at once (pearson.py:43
+// for a result larger than the HBM, or than one GPU's share): the file is created with numpy's header and its final size,
+// every stripe is then written at its own offset, in any order, by whoever produced it.
+extern "C" int skr_npy_create(const char* path, int dtype, int64_t rows, int64_t cols, int64_t* data_offset) {
+    SKR_REQUIRE(path && data_offset, "NULL argument");
+    SKR_REQUIRE(dtype == SKR_F32 || dtype == SKR_F64 || dtype == SKR_U32, "unknown dtype %d", dtype);
+    SKR_REQUIRE(rows >= 0 && cols >= 0, "negative shape");
+    const std::string h = npy_header(dtype, rows, cols, false);
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0) return skr_set_error(SKR_ERR_IO, "cannot open %s for writing: %s", path, strerror(errno));
+    const size_t total = h.size() + (size_t)rows * (size_t)cols * (dtype == SKR_F64 ? 8 : 4);
+    bool ok = pwrite(fd, h.data(), h.size(), 0) == (ssize_t)h.size() && ftruncate(fd, (off_t)total) == 0;
+    const int err = errno;
+    ok = close(fd) == 0 && ok;
+    if (!ok) return skr_set_error(SKR_ERR_IO, "cannot lay out %s (%zu bytes): %s", path, total, strerror(err));
+    *data_offset = (int64_t)h.size();
+    return SKR_OK;
+}
+
+// Rows [row0, row0 + nrows) of a device matrix -> the file at byte offset file_offset.  Runs on the ctx's copy stream
+// behind `mark` (skr_ctx_mark; < 0: behind everything enqueued so far): two pinned buffers, the pwrite of one chunk under
+// the copy of the next; the compute stream is not held up.
+extern "C" int skr_mat_write_rows_at(const skr_mat* m, int64_t row0, int64_t nrows, const char* path, int64_t file_offset,
+                                     int64_t mark) {
+    SKR_REQUIRE(m && path, "NULL argument");
+    SKR_REQUIRE(row0 >= 0 && nrows >= 0 && row0 + nrows <= m->rows, "row range [%lld, %lld) outside 0..%lld", (long long)row0,
+                (long long)(row0 + nrows), (long long)m->rows);
+    SKR_REQUIRE(file_offset >= 0, "negative file offset");
+    skr_ctx* ctx = m->ctx;
+    hipStream_t cs = nullptr;
+    SKR_TRY(skr_copy_stream_after(ctx, mark, &cs));
+    const size_t rb = (size_t)m->cols * m->elem();
+    if (nrows == 0 || rb == 0) return SKR_OK;
+    const size_t chunk_bytes = std::max<size_t>(rb, std::min<size_t>((size_t)nrows * rb, (size_t)32 << 20));
+    const int64_t chunk_rows = (int64_t)(chunk_bytes / rb);
+    if (ctx->h_copy_bytes < (size_t)chunk_rows * rb) {
+        for (void*& hp : ctx->h_copy) {
+            if (hp) (void)hipHostFree(hp);
+            hp = nullptr;
+        }
+        ctx->h_copy_bytes = 0;
+        for (void*& hp : ctx->h_copy) SKR_HIP(hipHostMalloc(&hp, (size_t)chunk_rows * rb, hipHostMallocDefault));
+        ctx->h_copy_bytes = (size_t)chunk_rows * rb;
+    }
+    const int fd = open(path, O_WRONLY);
+    if (fd < 0) return skr_set_error(SKR_ERR_IO, "cannot open %s for writing: %s", path, strerror(errno));
+    hipEvent_t done[2] = {nullptr, nullptr};
+    hipError_t e = hipEventCreateWithFlags(&done[0], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&done[1], hipEventDisableTiming);
+    auto issue = [&](int64_t r, int slot) -> hipError_t {
+        const int64_t n = std::min(chunk_rows, nrows - r);
+        hipError_t ee = hipMemcpyAsync(ctx->h_copy[slot], (const char*)m->data + (size_t)(row0 + r) * rb, (size_t)n * rb,
+                                       hipMemcpyDeviceToHost, cs);
+        if (ee == hipSuccess) ee = hipEventRecord(done[slot], cs);
+        return ee;
+    };
+    int rc = SKR_OK;
+    if (e == hipSuccess) e = issue(0, 0);
+    int slot = 0;
+    for (int64_t r = 0; r < nrows && e == hipSuccess && rc == SKR_OK; r += chunk_rows, slot ^= 1) {
+        const int64_t n = std::min(chunk_rows, nrows - r);
+        if (r + chunk_rows < nrows) e = issue(r + chunk_rows, slot ^ 1);
+        if (e == hipSuccess) e = hipEventSynchronize(done[slot]);
+        if (e != hipSuccess) break;
+        const char* src = (const char*)ctx->h_copy[slot];
+        size_t left = (size_t)n * rb;
+        off_t at = (off_t)file_offset + (off_t)((size_t)r * rb);
+        while (left) {
+            const ssize_t w = pwrite(fd, src, left, at);
+            if (w < 0 && errno == EINTR) continue;
+            if (w <= 0) {
+                rc = skr_set_error(SKR_ERR_IO, "short write to %s: %s", path, strerror(errno));
+                break;
+            }
+            src += w;
+            at += w;
+            left -= (size_t)w;
+        }
+    }
+    (void)hipStreamSynchronize(cs);
+    for (hipEvent_t ev : done)
+        if (ev) (void)hipEventDestroy(ev);
+    if (close(fd) != 0 && rc == SKR_OK && e == hipSuccess) rc = skr_set_error(SKR_ERR_IO, "closing %s failed: %s", path, strerror(errno));
+    if (e != hipSuccess) return skr_set_error(SKR_ERR_HIP, "device-to-file streaming failed: %s", hipGetErrorString(e));
+    return rc;
 }
 
 extern "C" int skr_mat_save_csv(skr_ctx* ctx, const skr_mat* m, int fmt_mode, int threads, const char* path) {

@@ -1290,6 +1290,18 @@ int skr_x8_pair_check(const skr_operand* a, const skr_operand* b) {
                          skr_x8_pair_bound(a, b));
 }
 
+/* The library's own verdict on two f16f8 operands whose three row-mean maxima are set (skr_operand_x8_stats): the bound
+ * on a cell of r that follows from the means alone, and whether skr_operand_fill's rule allows it — so that a multi-GPU
+ * caller who made the maxima global never re-derives the formula.  b == a: the rows of one matrix against each other.
+ * Operands in any other layout: bound 0, ok. */
+extern "C" int skr_operand_x8_pair_bound(const skr_operand* a, const skr_operand* b, double* bound, int* ok) {
+    SKR_REQUIRE(a && b, "NULL argument");
+    const double v = a->kind == 3 && b->kind == 3 ? skr_x8_pair_bound(a, b) : 0.0;
+    if (bound) *bound = v;
+    if (ok) *ok = v <= kX8MeansLimit ? 1 : 0;
+    return SKR_OK;
+}
+
 extern "C" int skr_operand_adopt_layout(skr_operand* op, const skr_operand* like) {
     SKR_REQUIRE(op && like && op->cols == like->cols, "operands of different widths");
     op->kind = like->kind;
@@ -1439,7 +1451,9 @@ extern "C" int skr_pearson_gemm_op_mirror(skr_ctx* ctx, const skr_operand* a, co
 // the blocked fp32 accumulation): refill the other one the same way so that one kernel serves both.
 static int match_layouts(skr_ctx* ctx, const skr_mat* xa, skr_operand* oa, const skr_mat* xb, skr_operand* ob,
                          int row_standardize) {
-    if (oa->kind == 3 && ob->kind == 3 && skr_x8_pair_check(oa, ob) != SKR_OK) {
+    // (the bound itself, not skr_x8_pair_check: that one leaves its refusal in the thread's error string, and this
+    // function goes on to succeed)
+    if (oa->kind == 3 && ob->kind == 3 && oa->x8_root != ob->x8_root && skr_x8_pair_bound(oa, ob) > kX8MeansLimit) {
         for (int q = 0; q < 2; q++) {  // both back to the three-product split
             skr_operand* o = q == 0 ? oa : ob;
             o->kind = 2;

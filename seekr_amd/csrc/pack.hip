@@ -19,6 +19,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <thread>
 
 #include "common.hpp"
@@ -51,7 +52,7 @@ struct SeqView {
 };
 
 // pack sequences [first, last) into the host staging arrays
-void pack_range(const std::vector<SeqView>& seqs, int64_t first, int64_t last, const Lut& lut,
+void pack_range(const SeqView* seqs, int64_t first, int64_t last, const Lut& lut,
                 const std::vector<int64_t>& word_off, const std::vector<int64_t>& mask_off, uint32_t* packed,
                 uint32_t* mask) {
     for (int64_t s = first; s < last; s++) {
@@ -84,9 +85,11 @@ void pack_range(const std::vector<SeqView>& seqs, int64_t first, int64_t last, c
     }
 }
 
-int upload_seqs(skr_ctx* ctx, const std::vector<SeqView>& seqs, const Lut& lut, std::string&& headers,
-                skr_seqs** out) {
-    const int64_t n = (int64_t)seqs.size();
+int upload_seqs(skr_ctx* ctx, const std::vector<SeqView>& all_seqs, const Lut& lut, std::string&& headers,
+                skr_seqs** out, int64_t first = 0, int64_t count = -1) {
+    // sequences [first, first + count) of `all_seqs` (count < 0: all of them)
+    const SeqView* seqs = all_seqs.data() + first;
+    const int64_t n = count < 0 ? (int64_t)all_seqs.size() - first : count;
     std::vector<int64_t> word_off(n + 1, 0), mask_off(n, -1), len(n, 0);
     int64_t total = 0, max_len = 0, mask_words = 0;
     const int nthreads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
@@ -120,7 +123,7 @@ int upload_seqs(skr_ctx* ctx, const std::vector<SeqView>& seqs, const Lut& lut, 
     {
         std::vector<std::thread> th;
         for (int t = 0; t < nthreads; t++)
-            th.emplace_back(pack_range, std::cref(seqs), n * t / nthreads, n * (t + 1) / nthreads, std::cref(lut),
+            th.emplace_back(pack_range, seqs, n * t / nthreads, n * (t + 1) / nthreads, std::cref(lut),
                             std::cref(word_off), std::cref(mask_off), packed.data(), mask.data());
         for (auto& t : th) t.join();
     }
@@ -206,6 +209,17 @@ void parse_piece(const char* data, size_t begin, size_t end, FastaPiece* out) {
 
 }  // namespace
 
+// A FASTA file parsed into host memory (skr_fasta_open): the reader's work done once, the sequences then packed and
+// uploaded whole (skr_seqs_from_fasta) or range by range, each range by the GPU that counts it (skr_fasta_pack).
+struct skr_fasta {
+    std::vector<FastaPiece> pieces;     // own the sequence bytes
+    std::vector<std::string> bridges;   // sequences that ran over a piece boundary, copied together
+    std::vector<SeqView> seqs;          // views into the two above
+    std::vector<size_t> header_at;      // per sequence: where its header starts in `headers`; one more = the end + 1
+    std::string headers;                // '\n'-joined
+    int64_t total_bases = 0;
+};
+
 extern "C" int skr_seqs_pack(skr_ctx* ctx, const char* bases, const int64_t* offsets, int64_t n,
                              const char alphabet[4], skr_seqs** out) {
     SKR_REQUIRE(ctx && out && alphabet, "NULL argument");
@@ -222,11 +236,9 @@ extern "C" int skr_seqs_pack(skr_ctx* ctx, const char* bases, const int64_t* off
     return upload_seqs(ctx, seqs, lut, std::string(), out);
 }
 
-extern "C" int skr_seqs_from_fasta(skr_ctx* ctx, const char* path, const char alphabet[4], skr_seqs** out) {
-    SKR_REQUIRE(ctx && out && alphabet && path, "NULL argument");
+extern "C" int skr_fasta_open(const char* path, skr_fasta** out) {
+    SKR_REQUIRE(out && path, "NULL argument");
     *out = nullptr;
-    Lut lut;
-    SKR_TRY(make_lut(alphabet, /*fold_upper=*/true, &lut));
     int fd = open(path, O_RDONLY);
     if (fd < 0) return skr_set_error(SKR_ERR_IO, "cannot open '%s': %s", path, strerror(errno));
     struct stat st;
@@ -264,7 +276,9 @@ extern "C" int skr_seqs_from_fasta(skr_ctx* ctx, const char* path, const char al
         while (p < fsize && !line_start(p)) p++;
         cut[i] = p;
     }
-    std::vector<FastaPiece> pieces((size_t)n_pieces);
+    std::unique_ptr<skr_fasta> fa(new skr_fasta());
+    fa->pieces.resize((size_t)n_pieces);
+    std::vector<FastaPiece>& pieces = fa->pieces;
     {
         std::vector<std::thread> th;
         for (int i = 1; i < n_pieces; i++) th.emplace_back(parse_piece, data, cut[i], cut[i + 1], &pieces[i]);
@@ -325,9 +339,10 @@ extern "C" int skr_seqs_from_fasta(skr_ctx* ctx, const char* path, const char al
     if (data) munmap((void*)data, fsize);
     // Sequences stay where the pieces put them; only one that runs over a piece boundary (at most one
     // per boundary) is copied together.
-    std::vector<SeqView> seqs(hdr_lines.size());
-    std::vector<std::string> bridges;
-    bridges.reserve((size_t)n_pieces);
+    std::vector<SeqView>& seqs = fa->seqs;
+    seqs.resize(hdr_lines.size());
+    std::vector<std::string>& bridges = fa->bridges;
+    bridges.reserve((size_t)n_pieces);  // never reallocated: the views point into its strings
     int pc = 0;
     for (size_t j = 0; j < seqs.size(); j++) {
         const int64_t lo = starts[j], hi = starts[j + 1];
@@ -345,7 +360,74 @@ extern "C" int skr_seqs_from_fasta(skr_ctx* ctx, const char* path, const char al
             seqs[j] = {bridges.back().data(), hi - lo};
         }
     }
-    return upload_seqs(ctx, seqs, lut, std::move(headers), out);
+    fa->total_bases = total_joined;
+    fa->header_at.reserve(seqs.size() + 1);
+    fa->header_at.push_back(0);
+    for (size_t i = 0; i < headers.size(); i++)
+        if (headers[i] == '\n') fa->header_at.push_back(i + 1);
+    fa->header_at.push_back(headers.size() + 1);
+    fa->headers = std::move(headers);
+    *out = fa.release();
+    return SKR_OK;
+}
+
+extern "C" int skr_fasta_free(skr_fasta* fa) {
+    delete fa;
+    return SKR_OK;
+}
+
+extern "C" int skr_fasta_info(const skr_fasta* fa, int64_t* n, int64_t* total_bases) {
+    SKR_REQUIRE(fa, "fasta is NULL");
+    if (n) *n = (int64_t)fa->seqs.size();
+    if (total_bases) *total_bases = fa->total_bases;
+    return SKR_OK;
+}
+
+extern "C" int skr_fasta_lengths(const skr_fasta* fa, int64_t* lengths) {
+    SKR_REQUIRE(fa && (lengths || fa->seqs.empty()), "NULL argument");
+    for (size_t i = 0; i < fa->seqs.size(); i++) lengths[i] = fa->seqs[i].len;
+    return SKR_OK;
+}
+
+extern "C" int skr_fasta_headers(const skr_fasta* fa, char* buf, int64_t cap, int64_t* needed) {
+    SKR_REQUIRE(fa, "fasta is NULL");
+    if (needed) *needed = (int64_t)fa->headers.size() + 1;
+    if (buf && cap > 0) {
+        size_t ncopy = std::min<size_t>((size_t)cap - 1, fa->headers.size());
+        memcpy(buf, fa->headers.data(), ncopy);
+        buf[ncopy] = 0;
+    }
+    return SKR_OK;
+}
+
+// Sequences [first, first + count) packed onto ctx's GPU.  Only reads `fa`: the GPUs of a node pack their ranges at once.
+extern "C" int skr_fasta_pack(skr_ctx* ctx, const skr_fasta* fa, int64_t first, int64_t count, const char alphabet[4],
+                              skr_seqs** out) {
+    SKR_REQUIRE(ctx && fa && out && alphabet, "NULL argument");
+    *out = nullptr;
+    const int64_t n = (int64_t)fa->seqs.size();
+    SKR_REQUIRE(first >= 0 && count >= 0 && first + count <= n, "sequences [%lld, %lld) outside 0..%lld", (long long)first,
+                (long long)(first + count), (long long)n);
+    Lut lut;
+    SKR_TRY(make_lut(alphabet, /*fold_upper=*/true, &lut));
+    std::string headers;
+    if (count > 0 && fa->header_at.size() == (size_t)n + 1) {
+        const size_t h0 = fa->header_at[(size_t)first], h1 = fa->header_at[(size_t)(first + count)] - 1;
+        headers.assign(fa->headers, h0, h1 - h0);
+    }
+    return upload_seqs(ctx, fa->seqs, lut, std::move(headers), out, first, count);
+}
+
+extern "C" int skr_seqs_from_fasta(skr_ctx* ctx, const char* path, const char alphabet[4], skr_seqs** out) {
+    SKR_REQUIRE(ctx && out && alphabet && path, "NULL argument");
+    *out = nullptr;
+    Lut lut;
+    SKR_TRY(make_lut(alphabet, /*fold_upper=*/true, &lut));  // a bad alphabet is reported before the file is read
+    skr_fasta* fa = nullptr;
+    SKR_TRY(skr_fasta_open(path, &fa));
+    const int rc = skr_fasta_pack(ctx, fa, 0, (int64_t)fa->seqs.size(), alphabet, out);
+    skr_fasta_free(fa);
+    return rc;
 }
 
 extern "C" int skr_seqs_free(skr_seqs* s) {

@@ -45,10 +45,11 @@ def shard_bounds(n_rows, size):
 class HipEngine:
     """The production engine: every op is a kernel launch through libseekr_hip."""
 
-    def __init__(self, ctx, precision=_lib.PREC_F16X3, use_symmetry=True):
+    def __init__(self, ctx, precision=_lib.PREC_F16X3, use_symmetry=True, row_standardize=True):
         self.ctx = ctx
         self.precision = precision
         self.use_symmetry = use_symmetry  # self-blocks compute one triangle and mirror it
+        self.row_standardize = row_standardize  # pearson(..., row_standardize=False): the operands hold the rows as they are
 
     def zeros_vec(self, n):
         return self.ctx.zeros(1, n)
@@ -94,7 +95,7 @@ class HipEngine:
         """Normalisation tail + row standardisation + operand layout in one pass over `x`;
         the normalised counts overwrite `x` when keep_counts.  Returns (operand, has_nan)."""
         return _lib.operand_fill(self.ctx, x, op=op, precision=self.precision, center=center, scale=scale, post=post,
-                                 shift=shift, y=x if keep_counts else None, row_standardize=True,
+                                 shift=shift, y=x if keep_counts else None, row_standardize=self.row_standardize,
                                  want_nan=scale is not None)
 
     def layout(self, op):
@@ -109,7 +110,7 @@ class HipEngine:
         """The rows of `x` (already normalised) as a float32-layout operand: what every rank switches
         to when any rank's rows need the fp32 kernel's dynamic range."""
         op = _lib.Operand(self.ctx, x.rows, x.cols, _lib.PREC_FP32) if op is None or op.kind != 0 else op
-        return _lib.operand_fill(self.ctx, x, op=op, precision=_lib.PREC_FP32, row_standardize=True)[0]
+        return _lib.operand_fill(self.ctx, x, op=op, precision=_lib.PREC_FP32, row_standardize=self.row_standardize)[0]
 
     def prepare_f16x3(self, x, op=None):
         """The rows of `x` (already normalised) as a split-fp16 (three-product) operand in the storage of `op`: what every
@@ -117,10 +118,16 @@ class HipEngine:
         like = _lib.Operand(self.ctx, 1, x.cols, _lib.PREC_F16X3)
         op = _lib.Operand(self.ctx, x.rows, x.cols, _lib.PREC_F16X3) if op is None else op.adopt_layout(like)
         like.free()
-        return _lib.operand_fill(self.ctx, x, op=op, precision=_lib.PREC_F16X3, row_standardize=True)[0]
+        return _lib.operand_fill(self.ctx, x, op=op, precision=_lib.PREC_F16X3, row_standardize=self.row_standardize)[0]
 
-    def gemm(self, a, b, r, col0, symmetric=False):
-        _lib.pearson_gemm_op(self.ctx, a, b, r, symmetric and self.use_symmetry, 0, col0)
+    def gemm(self, a, b, r, col0, symmetric=False, lower=False):
+        """lower: `b` holds rows that come BEFORE a's in the matrix both belong to — the block below the diagonal of a
+        self-comparison, asked for with the bits its mirror would have (skr_pearson_gemm_op, symmetric = 2)."""
+        _lib.pearson_gemm_op(self.ctx, a, b, r, symmetric and self.use_symmetry, 0, col0, lower=lower)
+
+    def gemm_rows(self, a, full, a_row0, r):
+        """r[i, :] = rows a_row0 + i of the self-comparison of `full`, with the one-block call's bits (skr_pearson_gemm_op_rows)."""
+        _lib.pearson_gemm_op_rows(self.ctx, a, full, a_row0, r)
 
     def gemm_mirror(self, a, b, r, row0, col0, rt, trow0, tcol0):
         """r[row0+i, col0+j] = <a_i, b_j>/K and rt[trow0+j, tcol0+i] = the same value."""
@@ -419,11 +426,10 @@ def sharded_normalize_prepare(engine, comm, x, n_total, log2="Log2.post", mean=T
         stats = list(operand.x8_stats) if x8 and hasattr(operand, "x8_stats") and engine.layout(operand) == 3 else [0.0, 0.0, 0.0]
         any_fell_back, any_coherent, any_nan, any_routed_back = _verdicts(comm, fell_back, coherent, has_nan, routed_back,
                                                                           stats if x8 else None)
-        if x8 and hasattr(operand, "x8_bound") and not any_routed_back and engine.layout(operand) == 3:
-            if operand.x8_bound(stats) > _lib.X8_MEANS_LIMIT:
+        if x8 and hasattr(operand, "x8_pair_bound") and not any_routed_back and engine.layout(operand) == 3:
+            operand.x8_stats = stats  # the global maxima; receive buffers take them over in adopt_layout
+            if not operand.x8_pair_bound()[1]:  # the library's own rule on them (skr_operand_x8_pair_bound)
                 any_routed_back = True
-            else:
-                operand.x8_stats = stats  # receive buffers take them over in adopt_layout
         normalised_in_x = keep_counts or (center is None and scale is None and not post)  # x still holds what was prepared
         if any_fell_back and hasattr(engine, "layout") and engine.layout(operand) != 0:
             if not normalised_in_x:
@@ -461,7 +467,9 @@ def sharded_pearson_rowblock(engine, comm, z, bounds, r, recv_bufs):
             nsrc = (rank - s - 1) % size
             tickets[s + 1] = comm.shift(z, (rank + s + 1) % size, recv_bufs[(s + 1) % 2],
                                         bounds[nsrc + 1] - bounds[nsrc], nsrc)
-        engine.gemm(z, engine.view(recv_bufs[s % 2], 0, bounds[src + 1] - bounds[src]), r, bounds[src])
+        # shards that come before ours lie below the diagonal: asked for with their mirror's bits, so that the row block
+        # is, bit for bit, rows bounds[rank]:bounds[rank+1] of the one-GPU self-comparison
+        engine.gemm(z, engine.view(recv_bufs[s % 2], 0, bounds[src + 1] - bounds[src]), r, bounds[src], lower=src < rank)
     return r
 
 
@@ -596,8 +604,8 @@ def allgather_operand(engine, comm, z, bounds, full=None):
 def sharded_pearson_allgather(engine, comm, z, bounds, r, full=None):
     """Row block r[n_g, N] = z_g . Z^T / K the way the north_star names it: ONE all-gather of the prepared operands
     (every rank's shard to every rank, all xGMI links at once: skr_comm_allgather_rows), then this rank's rows against
-    the gathered matrix — the own block as a symmetric product, the columns left and right of it as plain ones, so the
-    result is the row-block layout's bit for bit (same kernel, same operands).  No transfer overlaps a contraction here:
+    the gathered matrix — the own block as a symmetric product, the columns right of it as plain ones, those left of it with
+    their mirror's bits — so the result is the row-block layout's, and the one-GPU self-comparison's, bit for bit.  No transfer overlaps a contraction here:
     the schedule trades the half ring's overlap and its halved work for a single collective, which is what makes it the
     most robust of the three (bench.py --layout allgather).  `full`: an operand of bounds[-1] rows to gather into (kept
     between steps by the caller).  Returns r."""
@@ -607,7 +615,7 @@ def sharded_pearson_allgather(engine, comm, z, bounds, r, full=None):
     n_total = bounds[-1]
     engine.gemm(z, z, r, lo, symmetric=True)
     if lo > 0:
-        engine.gemm(z, engine.view(full, 0, lo), r, 0)
+        engine.gemm(z, engine.view(full, 0, lo), r, 0, lower=True)  # below the diagonal: the mirror's bits (skr_pearson_gemm_op)
     if hi < n_total:
         engine.gemm(z, engine.view(full, hi, n_total - hi), r, hi)
     return r

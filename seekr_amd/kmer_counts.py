@@ -13,7 +13,7 @@ from itertools import product
 
 import numpy as np
 
-from seekr_amd import _lib
+from seekr_amd import _lib, multi
 from seekr_amd.fasta_reader import Reader
 from seekr_amd.my_tqdm import my_tqdm
 
@@ -65,6 +65,7 @@ class BasicCounter:
         self.infasta = infasta
         self._seqs = None
         self._packed = None  # PackedSeqs resident in HBM (native FASTA path)
+        self._fasta = None   # SEEKR_DEVICES names several GPUs: the file parsed into host memory, packed range by range later
         self.alphabet = alphabet
         # 4 distinct letters: 2 bits per base and the tuned kernels; any other alphabet string the
         # reference accepts (kmer_counts.py:120-122) goes through the general counting kernel
@@ -73,7 +74,10 @@ class BasicCounter:
             # kmer_counts.py:103-105 reads the file here; errors of the reader surface here too
             if self._two_bit:
                 try:
-                    self._packed = _lib.default_context().pack_fasta(infasta, alphabet)
+                    if multi.requested_devices():
+                        self._fasta = _lib.FastaFile(infasta)  # the reader's errors surface here, as in the reference
+                    else:
+                        self._packed = _lib.default_context().pack_fasta(infasta, alphabet)
                 except ValueError as e:
                     # a file whose first line is not a header: the native reader refuses it, the reference slices its
                     # entry list anyway (Reader.get_seqs then returns what stands at the odd positions).  Same result
@@ -97,7 +101,7 @@ class BasicCounter:
         self.kmers = ["".join(t) for t in product(alphabet, repeat=k)]
         self.map = {kmer: col for col, kmer in enumerate(self.kmers)}
 
-        n_seqs = self._packed.n if self._packed is not None else (len(self._seqs) if self._seqs is not None else None)
+        n_seqs = self._n_seqs()
         if n_seqs == 1 and self.std is True:
             raise ValueError(
                 "You cannot standardize a single sequence. "
@@ -118,13 +122,22 @@ class BasicCounter:
     def seqs(self, value):
         self._seqs = value
         self._packed = None  # caller-assigned sequences win over the packed file
+        self._fasta = None
 
     def _ctx(self):
         return _lib.default_context()
 
+    def _n_seqs(self):
+        for held in (self._packed, self._fasta):
+            if held is not None:
+                return held.n
+        return len(self._seqs) if self._seqs is not None else None
+
     def _packed_seqs(self):
         if self._packed is not None:
             return self._packed
+        if self._fasta is not None:  # read under SEEKR_DEVICES, counted on one GPU after all
+            return self._fasta.pack(self._ctx(), alphabet=self.alphabet)
         if self._seqs is None:
             raise TypeError("BasicCounter has no sequences: pass infasta or assign `seqs`")
         return self._ctx().pack(self._seqs, self.alphabet)
@@ -174,7 +187,7 @@ class BasicCounter:
         launch, so the bar is advanced once by the number of sequences."""
         if self.silent:
             return None
-        total = self._packed.n if self._packed is not None else len(self._seqs)
+        total = self._n_seqs()
         if not self.leave:
             return my_tqdm()(total=total, desc="Kmers", leave=False)
         return my_tqdm()(total=total)
@@ -242,6 +255,21 @@ class BasicCounter:
         """Generates k-mer counts for the sequences: count -> Log2.pre -> centre ->
         standardise -> Log2.post, all on the GPU; `self.counts` receives the float32 result."""
         self._check_k()
+        devices = multi.requested_devices()
+        if devices:
+            # SEEKR_DEVICES: the rows in contiguous ranges, one per GPU; statistics, counts and warning as on one GPU
+            if self._fasta is None and self._seqs is None and self._packed is not None and self.infasta is not None:
+                self._fasta = _lib.FastaFile(self.infasta)  # read before SEEKR_DEVICES was set: onto the host again
+            if self._n_seqs() is None:
+                raise TypeError("BasicCounter has no sequences: pass infasta or assign `seqs`")
+            bar = self._progress()
+            has_nan = multi.counter_get_counts(self, devices)
+            if bar is not None:
+                bar.update(len(self.counts))
+                bar.close()
+            if has_nan:
+                print(NAN_WARNING)
+            return
         ctx = self._ctx()
         bar = self._progress()
         if self._two_bit:
@@ -293,7 +321,8 @@ class BasicCounter:
             _lib.save_npy(self.outfile, self.counts)  # np.save, streamed natively
         elif self.label:
             if names is None:
-                names = self._packed.headers() if self._packed is not None else Reader(self.infasta).get_headers()
+                held = self._packed if self._packed is not None else self._fasta
+                names = held.headers() if held is not None else Reader(self.infasta).get_headers()
             # DataFrame(data=self.counts, index=names, columns=self.kmers).to_csv(self.outfile), natively
             _lib.save_csv_labelled(self.outfile, self.counts, names, self.kmers)
         else:

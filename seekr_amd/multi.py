@@ -1,0 +1,558 @@
+"""SEEKR_DEVICES — the GPUs of one node behind the reference's own API.
+
+    SEEKR_DEVICES=all  (or 0,1,2,3)   seekr_kmer_counts transcripts.fa -o counts.npy -b -rl
+                                      seekr_pearson counts.npy counts.npy -o r.npy -bi -bo
+    >>> os.environ["SEEKR_DEVICES"] = "all"; BasicCounter("transcripts.fa").get_counts(); pearson(c, c)
+
+Unset (or naming one device) everything runs as before on one GPU.  With several devices ONE host process drives them
+all, one Python thread per GPU (every call into libseekr_hip releases the interpreter lock): the rows — transcripts — are
+cut into contiguous ranges, one per GPU, in input order (balanced by bases for FASTA input), every GPU uploads, counts and
+downloads its own range over its own PCIe link, and the three steps that need all rows are the ones of
+seekr_amd.distributed: the float32 column sums travel from GPU to GPU in row order (mean and std come out bit-identical to
+one GPU's, kmer_counts.py:168,174), the Log2.post minimum is a NaN-propagating all-reduce (:208), and for Pearson the
+prepared operands are all-gathered over RCCL / xGMI (pearson.py:41) — each GPU then produces its row block of r in row
+stripes, stripe s going to the host (or to its place in the .npy file) while stripe s + 1 is contracted.  Blocks below
+the diagonal of a self-comparison are asked for with their mirror's bits (skr_pearson_gemm_op_rows), so r does not depend
+on the number of GPUs: it is the one-GPU result bit for bit, as the counts and the statistics are.
+
+The same stripe loop serves ONE GPU when r would not fit its memory (pearson.py:41 is limited by host RAM only) or goes
+straight to a file: `pearson()` picks it by itself, SEEKR_PEARSON_STRIPE_ROWS forces a stripe height (tests).
+
+Errors keep the reference's types: what one GPU's range raises (a sequence of length k - 1: ZeroDivisionError,
+kmer_counts.py:144) is agreed on by all GPU threads before any of them enters a collective, every thread leaves the job,
+and the caller sees that one exception, once.
+"""
+import os
+import queue
+import threading
+
+import numpy as np
+
+from seekr_amd import _lib
+from seekr_amd.distributed import (HipEngine, RcclComm, SingleComm, allgather_operand, shard_bounds, sharded_normalize,
+                                   sharded_normalize_prepare)
+
+
+# ------------------------------------------------------------------------------ which devices --
+def _test_hooks():
+    return os.environ.get("SEEKR_TEST_HOOKS") == "1"
+
+
+def requested_devices():
+    """The device list SEEKR_DEVICES asks for when it names MORE than one GPU, else None (the one-GPU path: unset, empty,
+    or a single device — which _lib.default_context() then uses)."""
+    spec = os.environ.get("SEEKR_DEVICES", "").strip()
+    if not spec:
+        return None
+    n = _lib.device_count()
+    if spec.lower() == "all":
+        devices = list(range(n))
+    else:
+        try:
+            devices = [int(t) for t in spec.split(",") if t.strip()]
+        except ValueError:
+            raise ValueError("SEEKR_DEVICES must be 'all' or a comma-separated list of device numbers, got {!r}".format(spec))
+    bad = [d for d in devices if d < 0 or d >= n]
+    if bad:
+        raise ValueError("SEEKR_DEVICES={!r} names device {} but {} device(s) are visible".format(spec, bad[0], n))
+    if len(set(devices)) != len(devices) and not _test_hooks():
+        # (tests put several ranks on the one GPU of a test box, over tests/mock_rccl: RCCL itself refuses that)
+        raise ValueError("SEEKR_DEVICES={!r} names a device twice".format(spec))
+    return devices if len(devices) > 1 else None
+
+
+def bounds_by_bases(lengths, size):
+    """Contiguous row ranges with near-equal numbers of BASES (counting time follows the bases, not the sequences; real
+    transcript sets are length-skewed): bounds[g] = the first sequence whose start lies at or after g / size of the total."""
+    lengths = np.asarray(lengths, dtype=np.int64)
+    n = len(lengths)
+    if n == 0:
+        return [0] * (size + 1)
+    starts = np.concatenate(([0], np.cumsum(lengths)[:-1]))
+    total = int(lengths.sum())
+    if total == 0:
+        return shard_bounds(n, size)
+    cuts = [int(np.searchsorted(starts, (total * g + size - 1) // size, side="left")) for g in range(size)] + [n]
+    for g in range(1, size + 1):
+        cuts[g] = max(cuts[g], cuts[g - 1])
+    cuts[0] = 0
+    return cuts
+
+
+# ------------------------------------------------------------------------------ the group ------
+class GroupBroken(RuntimeError):
+    """A GPU thread left a job without the others' agreement (an error inside a collective phase): the group is discarded."""
+
+
+class _PeerFailed(Exception):
+    """Raised in the threads whose own phase succeeded when another thread's did not: they leave the job with it."""
+
+
+class HostCollectives:
+    """all-reduce / barrier of a few host numbers between the threads of a DeviceGroup: shared slots and a
+    threading.Barrier — no device round trip (the RCCL form costs a stream drain and a kernel per call)."""
+
+    def allreduce(self, values, op):
+        rows = self.group.gather(self.rank, [float(v) for v in values])
+        fn = {"sum": sum, "max": max, "min": min}[op]
+        return [fn(r[i] for r in rows) for i in range(len(rows[0]))]
+
+    def barrier(self):
+        self.group.gather(self.rank, None)
+
+
+class GroupRcclComm(HostCollectives, RcclComm):
+    """RcclComm for the threads of one process: device data (statistic vectors, operand shards) moves over RCCL exactly
+    as between processes; the handful of host scalars is exchanged in memory."""
+
+    def __init__(self, group, ctx, rank, size):
+        RcclComm.__init__(self, ctx, rank, size)
+        self.group = group
+
+    def chain_for(self, engine, n_cols):
+        # the peer-mailbox chain exchanges HIP IPC handles, which a process cannot open on itself: send/recv here
+        self._chain, self._chain_note = False, "one process drives all GPUs: send/recv chain"
+        return None
+
+    def barrier(self):
+        self.ctx.sync()
+        HostCollectives.barrier(self)
+
+
+class Rank:
+    """What a job sees of its GPU: ctx, comm, and the agreement primitive."""
+
+    def __init__(self, group, rank, ctx, comm):
+        self.group, self.rank, self.size, self.ctx, self.comm = group, rank, group.size, ctx, comm
+        self.agreed_error = None
+
+    def engine(self, precision=_lib.PREC_F16X3, row_standardize=True):
+        return ApiHipEngine(self.ctx, precision, row_standardize=row_standardize)
+
+    def phase(self, fn):
+        """Run fn() — local work that may raise the reference's exceptions — then agree with every other GPU thread: if
+        any raised, ALL leave the job here, before the next collective (the failing ones with their own exception)."""
+        err, out = None, None
+        try:
+            out = fn()
+        except BaseException as e:  # noqa: BLE001 - re-raised below, after the agreement
+            err = e
+        errors = self.group.gather(self.rank, err)
+        first = next((e for e in errors if e is not None), None)
+        if first is not None:
+            self.agreed_error = err if err is not None else _PeerFailed(first)
+            raise self.agreed_error
+        return out
+
+
+def _hip_backend(group, rank):
+    ctx = _lib.Context(group.devices[rank])
+    _lib.comm_init(ctx, group.size, rank, group.uid)
+    comm = GroupRcclComm(group, ctx, rank, group.size)
+    st = Rank(group, rank, ctx, comm)
+
+    def ring():  # one send/recv round the ring, checked: the first multi-GPU call diagnoses itself instead of hanging later
+        send = ctx.from_numpy(np.full((1, 256), float(rank + 1), np.float32))
+        recv = ctx.zeros(1, 256)
+        t = _lib.comm_sendrecv(ctx, send, 0, 1, (rank + 1) % group.size, recv, 0, 1, (rank - 1) % group.size)
+        _lib.comm_wait(ctx, t)
+        got, want = recv.to_numpy(), float((rank - 1) % group.size + 1)
+        if not (got == want).all():
+            raise _lib.SeekrHipError("GPU {} (rank {} of {}): the RCCL ring self-test delivered {} instead of {}".format(
+                group.devices[rank], rank, group.size, got[0, 0], want))
+    st.phase(ring)
+    return st
+
+
+class DeviceGroup:
+    """One thread per GPU, alive for the life of the process (RCCL's set-up costs seconds: it is paid once).  run(fn, spec)
+    executes fn(rank_state, spec) on every thread and returns the results in rank order; the lowest rank's exception, if
+    any, is re-raised in the caller."""
+
+    def __init__(self, devices, backend=None, uid=None):
+        self.devices, self.size = list(devices), len(devices)
+        self.uid = uid
+        self.broken = False
+        self._backend = backend or _hip_backend
+        self._barrier = threading.Barrier(self.size)
+        self._slots = [None] * self.size
+        self._inbox = [queue.Queue() for _ in range(self.size)]
+        self._outbox = queue.Queue()
+        self._lock = threading.Lock()
+        self._threads = [threading.Thread(target=self._worker, args=(rank,), daemon=True, name="seekr-gpu%d" % d)
+                         for rank, d in enumerate(self.devices)]
+        for t in self._threads:
+            t.start()
+        self._collect("set-up")
+
+    # -- host-side exchange between the threads: everyone deposits, everyone reads
+    def gather(self, rank, value):
+        try:
+            self._slots[rank] = value
+            self._barrier.wait()
+            out = list(self._slots)
+            self._barrier.wait()  # nobody overwrites a slot before everybody has read
+            return out
+        except threading.BrokenBarrierError:
+            raise GroupBroken("another GPU thread failed inside a collective phase") from None
+
+    def _worker(self, rank):
+        state = None
+        try:
+            state = self._backend(self, rank)
+            self._outbox.put((rank, True, None))
+        except BaseException as e:  # noqa: BLE001
+            agreed = state is not None and state.agreed_error is e
+            self._fail(rank, e, agreed or isinstance(e, _PeerFailed))
+            return
+        while True:
+            job = self._inbox[rank].get()
+            if job is None:
+                return
+            fn, spec = job
+            state.agreed_error = None
+            try:
+                self._outbox.put((rank, True, fn(state, spec)))
+            except BaseException as e:  # noqa: BLE001
+                if not self._fail(rank, e, state.agreed_error is e):
+                    return
+
+    def _fail(self, rank, error, agreed):
+        """Report; an error nobody agreed on may have left the others in a host barrier: break it, the group is done."""
+        if not agreed and not isinstance(error, GroupBroken):
+            self.broken = True
+            self._barrier.abort()
+        if isinstance(error, GroupBroken):
+            self.broken = True
+        self._outbox.put((rank, False, error))
+        return not self.broken
+
+    def _collect(self, what):
+        results, errors = [None] * self.size, {}
+        for _ in range(self.size):
+            rank, ok, value = self._outbox.get()
+            if ok:
+                results[rank] = value
+            else:
+                errors[rank] = value
+        real = {r: e for r, e in errors.items() if not isinstance(e, (_PeerFailed, GroupBroken))}
+        if real:
+            raise real[min(real)]
+        if errors:
+            raise GroupBroken("the multi-GPU {} failed: {}".format(what, errors[min(errors)]))
+        return results
+
+    def run(self, fn, spec):
+        with self._lock:
+            if self.broken:
+                raise GroupBroken("this device group is no longer usable")
+            for q in self._inbox:
+                q.put((fn, spec))
+            return self._collect("job")
+
+    def close(self):
+        for q in self._inbox:
+            q.put(None)
+
+
+_group = None
+_group_lock = threading.Lock()
+
+
+def group_for(devices):
+    """The process-wide DeviceGroup for this device list (created on first use, replaced when the list changes or the
+    group broke)."""
+    global _group
+    with _group_lock:
+        if _group is not None and (_group.broken or _group.devices != list(devices)):
+            _group.close()
+            _group = None
+        if _group is None:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's peer-to-peer set-up needs it here
+            _group = DeviceGroup(devices, uid=_lib.comm_unique_id())
+        return _group
+
+
+# ------------------------------------------------------------------------------ the engine -----
+class ApiHipEngine(HipEngine):
+    """HipEngine plus what the API-level jobs need around the kernels: host <-> device rows, counting from the caller's
+    sequences, stripe buffers and the two sinks of r."""
+
+    def count(self, source, lo, hi, k, log2_pre, alphabet, two_bit):
+        kind, payload = source
+        if kind == "fasta":
+            packed = payload.pack(self.ctx, lo, hi - lo, alphabet)
+        elif two_bit:
+            packed = self.ctx.pack(payload[lo:hi], alphabet)
+        else:
+            return _lib.count_generic(self.ctx, payload[lo:hi], alphabet, k, np.float32, log2_pre=log2_pre)
+        x = _lib.count_per_kb(self.ctx, packed, k, log2_pre=log2_pre)
+        packed.free()
+        return x
+
+    def user_vector(self, vec, n_cols):
+        from seekr_amd.kmer_counts import _as_device_vector
+        return _as_device_vector(self.ctx, vec, n_cols)
+
+    def vec_to_host(self, v):
+        return v.vector()
+
+    def upload(self, rows):
+        return self.ctx.from_numpy(rows) if len(rows) else self.ctx.empty(0, rows.shape[1], rows.dtype)
+
+    def download(self, x, out):
+        if x.rows:
+            x.to_numpy(out=out)
+
+    # -- float64 rows (CSV / integer inputs, pearson.py:35-41 in float64)
+    def rows_f64(self, rows, row_standardize, pad):
+        """Device rows ready for skr_pearson_gemm_f64: standardised in the rows' OWN dtype (float32 stays float32 until
+        the product promotes it, as numpy does), float64 afterwards, zero-padded to whole 16-column stages when `pad`."""
+        x = self.upload(rows)
+        cols = rows.shape[1]
+        if rows.dtype == np.float32:
+            if row_standardize and x.rows:
+                x = _lib.row_standardize(self.ctx, x)
+            return self.upload(x.to_numpy().astype(np.float64) if x.rows else np.empty((0, cols), np.float64))
+        if not row_standardize:
+            return x
+        z = self.ctx.zeros(x.rows, (cols + 15) // 16 * 16 if pad else cols, np.float64)
+        if x.rows:
+            _lib.row_standardize(self.ctx, x, z)
+        return z
+
+    def allgather_matrix(self, comm, z, bounds):
+        if comm.size == 1:
+            return z
+        full = self.ctx.empty(bounds[-1], z.cols, z.dtype)
+        comm.wait(_lib.comm_allgather_rows(self.ctx, z, full, bounds))
+        return full
+
+    def gemm_f64(self, a, b, r, K, col0=0, symmetric=False):
+        _lib.pearson_gemm_f64(self.ctx, a, b, r, K, symmetric=symmetric, col0=col0)
+
+    def view_matrix(self, x, row0, nrows):
+        return x.view(row0, nrows)
+
+    def block(self, rows, cols, dtype):
+        return self.ctx.empty(rows, cols, dtype)
+
+    def free_bytes(self):
+        return self.ctx.mem_info()[0]
+
+    def mark(self):
+        return self.ctx.mark()
+
+
+class HostSink:
+    """r lands in the caller's array: every GPU copies its stripes straight into its rows, over its own PCIe link."""
+
+    def __init__(self, out):
+        self.out = out
+
+    def put(self, buf, nrows, row0, mark):
+        buf.to_numpy_at(mark, self.out[row0:row0 + nrows])
+
+
+class NpySink:
+    """r lands in a .npy file, stripe by stripe, never whole in host memory (np.save(outfile, dist), pearson.py:43)."""
+
+    def __init__(self, path, dtype, rows, cols):
+        self.path = _lib.npy_path(path)
+        self.row_bytes = int(cols) * np.dtype(dtype).itemsize
+        self.offset = _lib.npy_create(self.path, dtype, rows, cols)
+
+    def put(self, buf, nrows, row0, mark):
+        buf.write_rows_at(mark, self.path, self.offset + row0 * self.row_bytes, 0, nrows)
+
+
+# ------------------------------------------------------------------------------ get_counts -----
+class CountSpec:
+    def __init__(self, source, bounds, k, log2, mean, std, alphabet, two_bit, out):
+        self.source, self.bounds, self.k, self.log2, self.mean, self.std = source, bounds, k, log2, mean, std
+        self.alphabet, self.two_bit, self.out = alphabet, two_bit, out
+
+
+def counts_job(st, spec):
+    """BasicCounter.get_counts (kmer_counts.py:194-209) on this GPU's row range: count (+ Log2.pre), the column statistics
+    over ALL ranges (rank-chained float32 sums), centre / standardise / Log2.post, rows to the caller's matrix."""
+    eng = st.engine()
+    lo, hi = spec.bounds[st.rank], spec.bounds[st.rank + 1]
+    n_total = spec.bounds[-1]
+    x = st.phase(lambda: eng.count(spec.source, lo, hi, spec.k, spec.log2 == "Log2.pre", spec.alphabet, spec.two_bit))
+    n_cols = eng.cols(x)
+    mean = spec.mean if isinstance(spec.mean, bool) else eng.user_vector(spec.mean, n_cols)
+    std = spec.std if isinstance(spec.std, bool) else eng.user_vector(spec.std, n_cols)
+    # Log2.pre went into the counting flush: the normaliser only has the post step left to do
+    log2 = "Log2.post" if spec.log2 == "Log2.post" else "Log2.none"
+    center, scale, has_nan = sharded_normalize(eng, st.comm, x, n_total, log2, mean, std)
+    eng.download(x, spec.out[lo:hi])
+    first = st.rank == 0
+    return (eng.vec_to_host(center) if first and spec.mean is True else None,
+            eng.vec_to_host(scale) if first and spec.std is True else None, bool(has_nan))
+
+
+def run_counts(run, size, source, lengths, k, log2, mean, std, alphabet, two_bit, n_cols):
+    """Cut the sequences into `size` ranges, run counts_job on every GPU thread (`run` = DeviceGroup.run), return
+    (counts, mean, std, has_nan) — mean / std None where they were not computed."""
+    bounds = bounds_by_bases(lengths, size)
+    out = np.empty((len(lengths), n_cols), dtype=np.float32)
+    parts = run(counts_job, CountSpec(source, bounds, k, log2, mean, std, alphabet, two_bit, out))
+    return out, parts[0][0], parts[0][1], any(p[2] for p in parts)
+
+
+def counter_get_counts(counter, devices):
+    """BasicCounter.get_counts() over several GPUs: fills counter.counts / .mean / .std; returns has_nan."""
+    if counter._fasta is not None:
+        source, lengths = ("fasta", counter._fasta), counter._fasta.lengths()
+    else:
+        if counter._seqs is None:
+            raise TypeError("BasicCounter has no sequences: pass infasta or assign `seqs`")
+        seqs = list(counter._seqs)
+        source, lengths = ("strings", seqs), np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
+    # True = compute, False = skip, anything else = the caller's vector (kmer_counts.py:104-117); `is`-tests as the reference's
+    mean = True if counter.mean is True else (False if counter.mean is False else counter.mean)
+    std = True if counter.std is True else (False if counter.std is False else counter.std)
+    counts, mean_out, std_out, has_nan = run_counts(group_for(devices).run, len(devices), source, lengths, counter.k,
+                                                    counter.log2, mean, std, counter.alphabet, counter._two_bit,
+                                                    len(counter.alphabet) ** counter.k)
+    counter.counts = counts
+    if mean_out is not None:
+        counter.mean = mean_out
+    if std_out is not None:
+        counter.std = std_out
+    return has_nan
+
+
+# ------------------------------------------------------------------------------ pearson --------
+class PearsonSpec:
+    def __init__(self, c1, c2, bounds1, bounds2, f64, pad, precision, row_standardize, sink, stripe_rows, out_dtype):
+        self.c1, self.c2, self.bounds1, self.bounds2, self.f64, self.pad = c1, c2, bounds1, bounds2, f64, pad
+        self.precision, self.row_standardize, self.sink, self.stripe_rows = precision, row_standardize, sink, stripe_rows
+        self.out_dtype = np.dtype(out_dtype)
+
+
+STRIPE_TARGET_BYTES = 2 << 30  # per stripe buffer (two of them): large enough to fill the chip, small beside 288 GB
+
+
+def stripe_height(rows, n_out, itemsize, free_bytes, forced=None):
+    """Rows per stripe of r: the forced height (SEEKR_PEARSON_STRIPE_ROWS / tests), else what two stripe buffers of
+    ~2 GiB — or 40 % of the free device memory, if that is less — hold, in multiples of the contraction's 256-row tile."""
+    if rows <= 0:
+        return 1
+    if forced:
+        return max(1, min(int(forced), rows))
+    row_bytes = max(1, n_out * itemsize)
+    budget = min(STRIPE_TARGET_BYTES, int(free_bytes * 0.4))
+    h = max(256, budget // row_bytes // 256 * 256)
+    return rows if h >= rows else h
+
+
+def _match_pair(eng, x1, z1, x2, z2):
+    """Two operands filled separately must share a storage kind (operand.hip: match_layouts; every rank holds the same
+    global flags by now, so every rank decides alike): one in the float32 layout -> so is the other; two f16f8 ones whose
+    row means do not go together, or an f16f8 one beside a three-product one -> both three-product."""
+    k1, k2 = eng.layout(z1), eng.layout(z2)
+    if k1 == 3 and k2 == 3 and not z1.x8_pair_bound(z2)[1]:
+        return eng.prepare_f16x3(x1, op=z1), eng.prepare_f16x3(x2, op=z2)
+    if k1 == k2:
+        return z1, z2
+    if k1 != 0 and k2 != 0:
+        return (eng.prepare_f16x3(x1, op=z1), z2) if k1 == 3 else (z1, eng.prepare_f16x3(x2, op=z2))
+    return (z1, eng.prepare_f32(x2)) if k1 == 0 else (eng.prepare_f32(x1), z2)
+
+
+def pearson_job(st, spec):
+    """This GPU's row block of pearson(c1, c2) (pearson.py:35-41): its rows of c1 against ALL rows of c2, the latter
+    prepared range by range on the GPUs and all-gathered; r leaves in row stripes through spec.sink."""
+    eng = st.engine(spec.precision, spec.row_standardize)
+    comm, g = st.comm, st.rank
+    b1, b2 = spec.bounds1, spec.bounds2
+    lo, hi = b1[g], b1[g + 1]
+    same = spec.c2 is None
+    n_out, K = b2[-1], spec.c1.shape[1]
+    if spec.f64:
+        z1 = eng.rows_f64(spec.c1[lo:hi], spec.row_standardize, spec.pad)
+        full = eng.allgather_matrix(comm, z1 if same else eng.rows_f64(spec.c2[b2[g]:b2[g + 1]], spec.row_standardize, spec.pad), b2)
+    else:
+        x1 = eng.upload(spec.c1[lo:hi])
+        z1 = sharded_normalize_prepare(eng, comm, x1, b1[-1], "Log2.none", False, False, keep_counts=False)[3]
+        if same:
+            z2 = z1
+        else:
+            x2 = eng.upload(spec.c2[b2[g]:b2[g + 1]])
+            z2 = sharded_normalize_prepare(eng, comm, x2, n_out, "Log2.none", False, False, keep_counts=False)[3]
+            z1, z2 = _match_pair(eng, x1, z1, x2, z2)
+        full = allgather_operand(eng, comm, z2, b2)
+    rows = hi - lo
+    height = stripe_height(rows, n_out, spec.out_dtype.itemsize, eng.free_bytes(), spec.stripe_rows)
+    bufs = [eng.block(height, n_out, spec.out_dtype) for _ in range(2 if rows > height else 1)] if rows else []
+    pending = None
+    for i, s0 in enumerate(range(0, rows, height)):
+        m, buf = min(height, rows - s0), bufs[i % 2]
+        g0 = lo + s0  # global index of the stripe's first row
+        if spec.f64:
+            a = eng.view_matrix(z1, s0, m)
+            if same:  # float64 products round once: any tiling gives the one-block call's bits
+                if g0:
+                    eng.gemm_f64(a, eng.view_matrix(full, 0, g0), buf, K)
+                eng.gemm_f64(a, a, buf, K, col0=g0, symmetric=True)
+                if g0 + m < n_out:
+                    eng.gemm_f64(a, eng.view_matrix(full, g0 + m, n_out - g0 - m), buf, K, col0=g0 + m)
+            else:
+                eng.gemm_f64(a, full, buf, K)
+        elif same:
+            eng.gemm_rows(eng.view(z1, s0, m), full, g0, buf)
+        else:
+            eng.gemm(eng.view(z1, s0, m), full, buf, 0)
+        mark = eng.mark()
+        if pending is not None:  # stripe s - 1 leaves while stripe s is contracted
+            spec.sink.put(*pending)
+        pending = (buf, m, g0, mark)
+    if pending is not None:
+        spec.sink.put(*pending)
+    return None
+
+
+class _Solo:
+    """The stripe loop on ONE GPU (r larger than its memory, or straight to a file): a 'group' of the default context."""
+    rank, size = 0, 1
+
+    def __init__(self, ctx):
+        self.ctx, self.comm = ctx, SingleComm()
+
+    def engine(self, precision=_lib.PREC_F16X3, row_standardize=True):
+        return ApiHipEngine(self.ctx, precision, row_standardize=row_standardize)
+
+
+def forced_stripe_rows():
+    v = os.environ.get("SEEKR_PEARSON_STRIPE_ROWS", "").strip()
+    return int(v) if v else None
+
+
+def run_pearson(c1, c2, w1, w2, row_standardize, precision, devices, out=None, outfile=None):
+    """pearson(c1, c2) by row stripes, on the GPUs of `devices` (None: the default context alone).  c2 None = the
+    self-comparison.  The result goes to `out` (a host array, created when None and no outfile) or to the .npy file."""
+    same = c2 is None
+    f64 = not (w1 == np.float32 and w2 == np.float32)
+    out_dtype = np.float64 if f64 else np.float32
+    m_rows, n_rows = c1.shape[0], (c1 if same else c2).shape[0]
+    size = len(devices) if devices else 1
+    # float64: skr_pearson pads standardised rows to whole 16-column stages — unless the two inputs differ in dtype (then
+    # the float32 one was standardised on its own and the product runs on the rows as they are)
+    pad = f64 and w1 == np.float64 and w2 == np.float64 and row_standardize
+    c1 = np.ascontiguousarray(c1, dtype=w1)
+    c2 = None if same else np.ascontiguousarray(c2, dtype=w2)
+    if outfile is not None and out is None:
+        sink = NpySink(outfile, out_dtype, m_rows, n_rows)
+    else:
+        out = np.empty((m_rows, n_rows), dtype=out_dtype) if out is None else out
+        sink = HostSink(out)
+    spec = PearsonSpec(c1, c2, shard_bounds(m_rows, size), shard_bounds(n_rows, size), f64, pad, precision, row_standardize,
+                       sink, forced_stripe_rows(), out_dtype)
+    if m_rows and n_rows:
+        if devices:
+            group_for(devices).run(pearson_job, spec)
+        else:
+            pearson_job(_Solo(_lib.default_context()), spec)
+    return out

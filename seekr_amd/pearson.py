@@ -19,7 +19,7 @@ import os
 
 import numpy as np
 
-from seekr_amd import _lib
+from seekr_amd import _lib, multi
 
 
 def _as_matrix(counts):
@@ -41,12 +41,7 @@ def _precision_for(dtype, row_standardize=True):
     return _lib.PRECISIONS[name]
 
 
-def pearson(counts1, counts2, row_standardize=True, outfile=None):
-    """Calculates a column standardized Pearson correlation matrix (pearson.py:32-44).
-
-    r[i, j] = <z1_i, z2_j> / K with z the row-standardised counts (population std, computed
-    on the centred row) when `row_standardize`, else the raw inner product / K.
-    """
+def _operands(counts1, counts2):
     c1, c2 = _as_matrix(counts1), _as_matrix(counts2)
     if c1.shape[1] != c2.shape[1]:
         raise ValueError("shapes {} and {} not aligned: {} (dim 1) != {} (dim 1)".format(
@@ -55,9 +50,44 @@ def pearson(counts1, counts2, row_standardize=True, outfile=None):
     # (np.mean of an integer matrix is float64)
     w1 = np.float32 if c1.dtype == np.float32 else np.float64
     w2 = np.float32 if c2.dtype == np.float32 else np.float64
-    ctx = _lib.default_context()
     same = c1 is c2 or (c1.shape == c2.shape and c1.dtype == c2.dtype and c1.ctypes.data == c2.ctypes.data
                         and c1.strides == c2.strides)
+    return c1, c2, w1, w2, same
+
+
+def _fits_one_block(ctx, c1, c2, same, w1, w2):
+    """Whether r, the inputs and their prepared operands fit the GPU at once (then: one upload, one launch, one download —
+    the path of rounds 1-4); otherwise r is produced in row stripes (multi.run_pearson)."""
+    out_item = 4 if (w1 == np.float32 and w2 == np.float32) else 8
+    rows_in = c1.shape[0] + (0 if same else c2.shape[0])
+    need = c1.shape[0] * c2.shape[0] * out_item + 2 * rows_in * (c1.shape[1] + 32) * out_item
+    return need <= 0.8 * ctx.mem_info()[0]
+
+
+def _striped(c1, c2, w1, w2, same, row_standardize, devices, outfile_only=None):
+    precision = _precision_for(np.dtype(np.float32 if (w1 == np.float32 and w2 == np.float32) else np.float64), row_standardize)
+    return multi.run_pearson(c1, None if same else c2, w1, w2, row_standardize, precision, devices, outfile=outfile_only)
+
+
+def pearson(counts1, counts2, row_standardize=True, outfile=None):
+    """Calculates a column standardized Pearson correlation matrix (pearson.py:32-44).
+
+    r[i, j] = <z1_i, z2_j> / K with z the row-standardised counts (population std, computed
+    on the centred row) when `row_standardize`, else the raw inner product / K.
+
+    SEEKR_DEVICES naming several GPUs: the rows of counts1 are cut into one range per GPU, every GPU uploads its range,
+    the prepared rows of counts2 are all-gathered, and every GPU writes its row block of r into the result over its own
+    PCIe link (seekr_amd.multi) — the same bits as on one GPU.  A result that does not fit the GPU's memory is produced
+    in row stripes (one GPU or several); SEEKR_PEARSON_STRIPE_ROWS forces a stripe height.
+    """
+    c1, c2, w1, w2, same = _operands(counts1, counts2)
+    devices = multi.requested_devices()
+    if devices or multi.forced_stripe_rows() or not _fits_one_block(_lib.default_context(), c1, c2, same, w1, w2):
+        dist = _striped(c1, c2, w1, w2, same, row_standardize, devices)
+        if outfile:
+            _lib.save_npy(outfile, dist)
+        return dist
+    ctx = _lib.default_context()
     d1 = ctx.from_numpy(c1.astype(w1, copy=False))
     d2 = d1 if same else ctx.from_numpy(c2.astype(w2, copy=False))
     if w1 == w2:
@@ -76,3 +106,11 @@ def pearson(counts1, counts2, row_standardize=True, outfile=None):
     if outfile:
         _lib.save_npy(outfile, dist)
     return dist
+
+
+def pearson_to_file(counts1, counts2, outfile, row_standardize=True):
+    """pearson(counts1, counts2, outfile=outfile) for a caller that does not want the matrix back (`seekr_pearson -bo`,
+    console_scripts.py:632-633): r goes from the GPU(s) to its place in the .npy file stripe by stripe and is never held in
+    host memory — neither once nor, as np.save of a returned array would, twice."""
+    c1, c2, w1, w2, same = _operands(counts1, counts2)
+    _striped(c1, c2, w1, w2, same, row_standardize, multi.requested_devices(), outfile_only=outfile)

@@ -55,6 +55,8 @@ class NumpyEngine:
 
     def min_nan(self, x, center, scale):
         z = self._z(x, center, scale)
+        if z.size == 0:  # a rank without rows: the identity of the minimum
+            return np.float32(np.inf), False
         return np.float32(np.min(z)), bool(np.isnan(z).any())
 
     def apply(self, x, center, scale, post, shift):
@@ -85,7 +87,7 @@ class NumpyEngine:
         has_nan = self.apply(y, center, scale, post, shift)
         return self.row_standardize(y, op), has_nan
 
-    def gemm(self, a, b, r, col0, symmetric=False):
+    def gemm(self, a, b, r, col0, symmetric=False, lower=False):
         r[:a.shape[0], col0:col0 + b.shape[0]] = np.inner(a, b) / a.shape[1]
 
     def empty_block(self, rows, cols):

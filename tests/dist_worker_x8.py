@@ -11,6 +11,9 @@ import numpy as np
 from dist_worker import GlooComm, NumpyEngine
 
 
+X8_MEANS_LIMIT = 0.6 * 2e-6  # kX8MeansLimit
+
+
 class FakeOperand:
     def __init__(self, z, kind, stats):
         self.z, self.kind, self.coherent, self._stats = z, kind, False, tuple(stats)
@@ -24,10 +27,12 @@ class FakeOperand:
     def x8_stats(self, v):
         self._stats = tuple(float(t) for t in v)
 
-    def x8_bound(self, stats=None):
-        d, l, dl = self._stats if stats is None else stats
+    def x8_pair_bound(self, other=None):
+        # the library's rule (skr_operand_x8_pair_bound, common.hpp: skr_x8_pair_bound / kX8MeansLimit) restated for the fake
+        d, l, dl = self._stats
         s = 2.0 ** math.floor(math.log2(32768.0 / math.sqrt(4096)))  # the rule is tested at the k = 6 scale whatever `cols` is
-        return 2.0 * (d * (l + dl) + (d + l) * dl) / (s * s)
+        bound = 2.0 * (d * (l + dl) + (d + l) * dl) / (s * s)
+        return bound, bound <= X8_MEANS_LIMIT
 
 
 class X8Engine(NumpyEngine):
@@ -76,7 +81,7 @@ def run(rank, size, port, out_dir, scenario):
         engine, comm = X8Engine(stats, kind), GlooComm(dist, torch)
         mean, std, has_nan, z = sharded_normalize_prepare(engine, comm, x, n_rows, "Log2.post", True, True)
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), kind=np.array(z.kind), stats=np.array(z.x8_stats),
-                 refilled=np.array(engine.refilled), own_bound=np.array(FakeOperand(z.z, 3, stats).x8_bound()))
+                 refilled=np.array(engine.refilled), own_bound=np.array(FakeOperand(z.z, 3, stats).x8_pair_bound()[0]))
         comm.barrier()
     finally:
         dist.destroy_process_group()

@@ -174,7 +174,7 @@ def test_f16f8_routing_is_decided_on_global_maxima(scenario, size, tmp_path):
         want = (1.0, 0.006, 0.0002)   # the element-wise maxima over the shards
         assert all(np.allclose(p["stats"], want) for p in parts)
     elif scenario == "pair":
-        assert all(float(p["own_bound"]) <= _lib.X8_MEANS_LIMIT for p in parts)     # every shard passes on its own
+        assert all(float(p["own_bound"]) <= dist_worker_x8.X8_MEANS_LIMIT for p in parts)     # every shard passes on its own
         assert all(int(p["kind"]) == 2 and bool(p["refilled"]) for p in parts)     # ... and none keeps the layout
     else:
         assert [int(p["kind"]) for p in parts] == [2, 2]

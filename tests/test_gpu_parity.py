@@ -1510,8 +1510,9 @@ def test_f16f8_operands_filled_separately_are_checked_as_a_pair(L, ctx, golden_d
     ob, _ = L.operand_fill(ctx, ctx.from_numpy(b), precision=L.PREC_F16F8, row_standardize=True)
     assert oa.kind == 3 and ob.kind == 3
     sa, sb = oa.x8_stats, ob.x8_stats
-    assert oa.x8_bound() <= L.X8_MEANS_LIMIT and ob.x8_bound() <= L.X8_MEANS_LIMIT
-    assert max(sa[0] * sb[1], sb[0] * sa[1]) / 256.0 ** 2 > L.X8_MEANS_LIMIT   # the cross product of their means is not
+    assert oa.x8_pair_bound()[1] and ob.x8_pair_bound()[1]    # each passes the rule on its own
+    assert not oa.x8_pair_bound(ob)[1]                         # the cross product of their means does not
+    assert max(sa[0] * sb[1], sb[0] * sa[1]) / 256.0 ** 2 > 0.6 * 2e-6
     r = ctx.empty(len(a), len(b))
     with pytest.raises(NotImplementedError, match="do not go together"):
         L.pearson_gemm_op(ctx, oa, ob, r)
