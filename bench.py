@@ -71,6 +71,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f16f8-arm", action="store_true", help="skip the opt-in two-product-unit contraction's extra measurement "
                     "after the timed region (f16f8_arm in the line)")
+    ap.add_argument("--no-target-200k", action="store_true", help="skip the 200 000-transcript sub-record after the timed region "
+                    "(target_200k in the line; default workload at --gpus 1 only)")
     ap.add_argument("--no-symmetry", action="store_true",
                     help="compute both triangles of the self-comparison block instead of mirroring one")
     ap.add_argument("--grouped-shifts", action="store_true",
@@ -178,10 +180,12 @@ def launch(args, argv):
     size = args.gpus
     symmetric = args.layout == "symmetric" and args.precision != "fp32" and not args.no_symmetry
     with tempfile.TemporaryDirectory(prefix="seekr_bench_") as log_dir:
-        # first attempt: the column sums travel over send/recv (the transport that has run); the peer-mailbox chain is
-        # measured next to it AFTER the timed region (chain_ab in the line).  Not under the test hooks by default: several
-        # ranks on one GPU need SEEKR_CHAIN_HOST_WAIT for the mailbox wait, which the tests that want it set themselves.
-        ab = os.environ.get("SEEKR_BENCH_CHAIN_AB", "0" if os.environ.get("SEEKR_TEST_HOOKS") == "1" else "1")
+        # the column sums travel over send/recv (the transport that has run).  The peer-mailbox chain can be measured next
+        # to it AFTER the timed region (chain_ab in the line), but only when asked for (SEEKR_BENCH_CHAIN_AB=1): its
+        # in-kernel wait has never met a second real GPU, and a hang there would discard the line already measured and —
+        # worse — send the launcher into the layout fallback below for a reason that has nothing to do with the layout
+        # (ADVICE r4).  A failure of the A/B that does return is reported inside chain_ab, never as a failed attempt.
+        ab = os.environ.get("SEEKR_BENCH_CHAIN_AB", "0")
         ok, payload, report = _run_rank_set(argv, size, args.launch_timeout, {"SEEKR_BENCH_CHAIN_AB": ab}, log_dir, 1)
         if not ok and symmetric:
             print(report, file=sys.stderr, flush=True)
@@ -279,6 +283,7 @@ def end_to_end(ctx, k, length, n_seqs, precision):
             c = BasicCounter(path, k=k, mean=False, std=False, log2="Log2.none", silent=True)
             c.get_counts()
             times.append(time.perf_counter() - t0)
+        devices = end_to_end_devices(path, k, length, n_seqs, min(12000, n_seqs))
     t_counts = float(np.median(times))
     n_p = min(12000, n_seqs)
     head = np.ascontiguousarray(c.counts[:n_p])
@@ -293,8 +298,114 @@ def end_to_end(ctx, k, length, n_seqs, precision):
             "fasta_to_host_counts_s": round(t_counts, 4),
             "host_to_host_pearson_mpairs_per_s": round(n_p * float(n_p) / t_p / 1e6, 1),
             "host_to_host_pearson_rows": n_p, "host_to_host_pearson_s": round(t_p, 4),
+            "seekr_devices_all": devices,
             "note": "median of 3; file read + pack + H2D + kernels + D2H through seekr_amd.BasicCounter / "
                     "seekr_amd.pearson (raw counts; Pearson result copied to the host: PCIe-bound)"}
+
+
+def target_200k(ctx, comm, engine, cb, peak_tf, n_total=200_000, length=2000, k=6, steps=3):
+    """BASELINE.json's target — ">= 100x the reference CPU BasicCounter + pearson throughput on 200k x 2kb synthetic
+    transcripts at k = 6" — at ITS size, in the driver's own run: after the timed region (never part of `value`), the same
+    step on 200 000 transcripts (160 GB of r + 6.6 GB of counts and operands: fits one GPU), `steps` timed steps, 32 rows x
+    200 000 columns of the r it produced against the oracle, and the speed-up against the CPU port's rates of this run."""
+    from seekr_amd import _lib
+    from seekr_amd.distributed import sharded_normalize_prepare, sharded_pearson_symmetric
+    from seekr_amd.synthetic import synthetic_ascii
+    t_all = time.perf_counter()
+    n_cols = 4 ** k
+    blob, offsets = synthetic_ascii(SEED, n_total, length)
+    packed = _lib.PackedSeqs.from_buffer(ctx, blob, offsets, "AGTC")
+    del blob
+    x, z, r = ctx.empty(n_total, n_cols), engine.empty_operand(n_total, n_cols), ctx.zeros(n_total, n_total)
+    bounds = [0, n_total]
+
+    def step():
+        _lib.count_per_kb(ctx, packed, k, out=x)
+        zz = sharded_normalize_prepare(engine, comm, x, n_total, "Log2.post", True, True, keep_counts=True, op=z)[3]
+        sharded_pearson_symmetric(engine, comm, zz, bounds, r, None, [None, None])
+
+    step()
+    ctx.sync()
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.sync()
+    elapsed = time.perf_counter() - t0
+    ctx.prof_enable(False)
+    gemm_ms = ctx.prof_query("pearson_gemm_f16x3")[0] / steps
+    count_ms = ctx.prof_query("count_kmers_f32")[0] / steps
+    ok, worst = verify_rows(ctx, r, x.to_numpy())
+    pairs = float(n_total) * n_total
+    value = pairs * steps / elapsed / 1e6
+    t_cpu = n_total * length / cb["rate_bases"] + pairs / cb["rate_pairs"]
+    out = {"workload": "{} synthetic {} nt transcripts, k={}, counts + Log2.post normalisation + self Pearson".format(n_total, length, k),
+           "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 2), "value": round(value, 2),
+           "unit": "M seq-pairs/s (whole step: count + normalise + Pearson)",
+           "pearson_kernel_ms": round(gemm_ms, 2), "count_kernel_ms": round(count_ms, 4),
+           "roofline_frac": round(2.0 * n_cols * pairs / (gemm_ms * 1e-3) / 1e12 / peak_tf, 4) if gemm_ms > 0 else None,
+           "verified": bool(ok), "verified_detail": {"rows": 32, "columns": n_total, "worst_error_over_bar": round(worst, 4)},
+           "cpu_port_m_pairs_per_s": round(pairs / t_cpu / 1e6, 3), "speedup_vs_cpu_port": round(value / (pairs / t_cpu / 1e6), 1),
+           "target": ">= 100x the CPU port at this size (BASELINE.json north_star)"}
+    for m in (x, z, r, packed):
+        m.free()
+    out["wall_s"] = round(time.perf_counter() - t_all, 1)
+    return out
+
+
+E2E_DEVICES_CHILD = r'''
+import json, os, sys, time
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from seekr_amd import multi
+from seekr_amd.kmer_counts import BasicCounter
+from seekr_amd.pearson import pearson
+path, k, n_p = sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+out = {"devices": len(multi.requested_devices() or [0])}
+t0 = time.perf_counter()
+c = BasicCounter(path, k=k, mean=False, std=False, log2="Log2.none", silent=True); c.get_counts()
+out["first_call_s"] = round(time.perf_counter() - t0, 3)  # includes the one-off RCCL set-up of the device group
+ts = []
+for _ in range(3):
+    t0 = time.perf_counter(); c = BasicCounter(path, k=k, mean=False, std=False, log2="Log2.none", silent=True); c.get_counts()
+    ts.append(time.perf_counter() - t0)
+out["fasta_to_host_counts_s"] = round(float(np.median(ts)), 4)
+out["n_seqs"], out["bases"] = int(c.counts.shape[0]), None
+head = np.ascontiguousarray(c.counts[:n_p])
+pearson(head[:512], head[:512])
+ts = []
+for _ in range(3):
+    t0 = time.perf_counter(); pearson(head, head); ts.append(time.perf_counter() - t0)
+out["host_to_host_pearson_s"] = round(float(np.median(ts)), 4)
+out["host_to_host_pearson_rows"] = int(n_p)
+print(json.dumps(out), flush=True)
+'''
+
+
+def end_to_end_devices(fasta_path, k, length, n_seqs, n_p, timeout_s=240):
+    """The same two host-to-host figures with SEEKR_DEVICES=all — every visible GPU behind BasicCounter / pearson()
+    (seekr_amd/multi.py: one host thread and one PCIe link per GPU) — measured in a CHILD process with a time limit, so that
+    nothing it does can cost the line measured above.  With one GPU visible there is nothing to compare."""
+    from seekr_amd import _lib
+    n_dev = _lib.device_count()
+    if n_dev < 2:
+        return {"devices": n_dev, "note": "one GPU visible: SEEKR_DEVICES has nothing to add here"}
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SEEKR_DEVICE")}
+    env.update(SEEKR_DEVICES="all", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    try:
+        res = subprocess.run([sys.executable, "-c", E2E_DEVICES_CHILD, ROOT, fasta_path, str(k), str(n_p)], env=env,
+                             capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"devices": n_dev, "error": "no result after {} s".format(timeout_s)}
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    if res.returncode != 0 or not lines:
+        return {"devices": n_dev, "error": "exit code {}: {}".format(res.returncode, res.stderr.strip()[-400:])}
+    got = json.loads(lines[-1])
+    got["fasta_to_host_counts_mbases_per_s"] = round(n_seqs * length / got["fasta_to_host_counts_s"] / 1e6, 1)
+    got["host_to_host_pearson_mpairs_per_s"] = round(n_p * float(n_p) / got["host_to_host_pearson_s"] / 1e6, 1)
+    got.pop("bases", None)
+    return got
 
 
 def kernel_symbols_sha256(lib_path):
@@ -454,23 +565,35 @@ def run_rank(args):
     rank, size, _ = skr_launch.world()
     if size != args.gpus:
         raise SystemExit("--gpus {} but WORLD_SIZE={}".format(args.gpus, size))
-    stage = ["start"]
+    stage = ["start", time.monotonic()]
+
+    def beat(name=None):
+        """Progress: a new stage, or one more step of the current one."""
+        if name is not None:
+            stage[0] = name
+        stage[1] = time.monotonic()
+
+    watching = [size > 1]
     if size > 1:
         # a rank that makes no progress (a collective one peer never enters) must not hold the whole job until the caller's
-        # own limit: after --launch-timeout seconds it says where it stood and leaves; torch.distributed.run (or this
-        # script's own launcher) then ends the other ranks
-        # (a timer THREAD, not SIGALRM: a Python signal handler only runs between bytecodes, and a stuck rank sits inside a
+        # own limit: --launch-timeout seconds WITHOUT A HEARTBEAT (a stage change or a finished step — not a cap on the run's
+        # total time: ADVICE r4) and it says where it stood and leaves; torch.distributed.run (or this script's own
+        # launcher) then ends the other ranks
+        # (a THREAD, not SIGALRM: a Python signal handler only runs between bytecodes, and a stuck rank sits inside a
         # ctypes call — which releases the GIL, so the thread does get to run)
         import threading
 
-        def give_up():
-            print("bench.py rank {}: no progress after {:.0f} s, last stage: {}".format(rank, args.launch_timeout, stage[0]),
-                  file=sys.stderr, flush=True)
-            os._exit(3)
-        watchdog = threading.Timer(max(1.0, float(args.launch_timeout)), give_up)
-        watchdog.daemon = True
-        watchdog.start()
-    stage[0] = "RCCL initialisation"
+        def watch():
+            limit = max(1.0, float(args.launch_timeout))
+            while watching[0]:
+                quiet = time.monotonic() - stage[1]
+                if quiet > limit:
+                    print("bench.py rank {}: no progress for {:.0f} s, last stage: {}".format(rank, quiet, stage[0]),
+                          file=sys.stderr, flush=True)
+                    os._exit(3)
+                time.sleep(min(1.0, limit / 4))
+        threading.Thread(target=watch, daemon=True, name="bench-watchdog").start()
+    beat("RCCL initialisation")
     ctx, comm = skr_launch.init()
     k, length = args.k, args.length
     generic = not (len(args.alphabet) == 4 and len(set(args.alphabet)) == 4)
@@ -482,7 +605,7 @@ def run_rank(args):
     engine = HipEngine(ctx, _lib.PRECISIONS[args.precision], use_symmetry=not args.no_symmetry)
     symmetric_layout = args.layout == "symmetric" and args.precision != "fp32" and not args.no_symmetry
 
-    stage[0] = "half-ring self-test"
+    beat("half-ring self-test")
     if size > 1 and symmetric_layout and not args.no_selftest:
         why = symmetric_selftest(ctx, comm, engine, k, args.grouped_shifts)
         if why:
@@ -523,23 +646,26 @@ def run_rank(args):
         else:
             sharded_pearson_rowblock(engine, comm, zz, bounds, r, recv[:2])
 
-    stage[0] = "warm-up steps"
+    beat("warm-up steps")
     for _ in range(args.warmup):
         step()
+        beat()
     ctx.sync()
     comm.barrier()
-    stage[0] = "timed steps"
+    beat("timed steps")
     ctx.prof_reset()
     ctx.prof_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+        if size > 1:
+            beat()  # (a store of two floats: nothing a step could notice)
     ctx.sync()
     comm.barrier()
     elapsed = time.perf_counter() - t0
     ctx.prof_enable(False)
     elapsed = comm.allreduce([elapsed], "max")[0]
-    stage[0] = "after the timed region (per-rank statistics, verification, chain A/B)"
+    beat("after the timed region (per-rank statistics, verification)")
 
     # ---- per-kernel device times of the timed region (HIP events on the ctx stream; comm_* on the communication stream)
     kern = exclusive_kernel_times(ctx)
@@ -599,14 +725,17 @@ def run_rank(args):
         multi_verified = comm.allreduce([worst], "max")[0]
     chain_ab = None
     if size > 1 and os.environ.get("SEEKR_BENCH_CHAIN_AB") == "1":
-        chain_ab = column_chain_ab(ctx, comm, engine, x, n_cols)
+        beat("chain A/B (opt-in)")
+        try:
+            chain_ab = column_chain_ab(ctx, comm, engine, x, n_cols)
+        except Exception as e:  # noqa: BLE001 - the line measured above is worth more than this extra
+            chain_ab = {"error": "{}: {}".format(type(e).__name__, e)}
     gemm_name = {"fp32": "pearson_gemm_f32", "bf16x3": "pearson_gemm_bf16x3", "bf16x4": "pearson_gemm_bf16x4",
                  "f16x3": "pearson_gemm_f16x3", "f16f8": "pearson_gemm_f16f8"}[args.precision]
     gemm = kern.get(gemm_name, {"ms_total": 0.0, "launches": 0})
     count = kern.get("count_generic" if generic else "count_kmers_f32", {"ms_total": 0.0, "launches": 0})
 
-    if size > 1:
-        watchdog.cancel()
+    watching[0] = False
     if rank != 0:
         return
     pairs_per_step = float(n_total) * n_total
@@ -770,6 +899,10 @@ def run_rank(args):
         out["speedup_vs_cpu_port"] = round(value / out["cpu_baseline"]["value"], 1)
         del x_host, head
         r.free()
+        if k == 6 and length == 2000 and n_total == 50000 and args.precision == "f16x3" and not args.no_target_200k:
+            for m in (x, z, packed):
+                m.free()
+            out["target_200k"] = target_200k(ctx, comm, engine, cb, peak_tf)
         out["e2e"] = end_to_end(ctx, k, length, min(n_total, 50000 if k <= 6 else 12000), args.precision)
     print(json.dumps(out), flush=True)
 

@@ -30,7 +30,8 @@ def mock_lib(tmp_path_factory):
 
 def run_worker(out_dir, scale="full", **env):
     os.makedirs(str(out_dir), exist_ok=True)
-    full = {k: v for k, v in os.environ.items() if k not in ("SEEKR_DEVICES", "SEEKR_PEARSON_STRIPE_ROWS", "SEEKR_PRECISION")}
+    full = {k: v for k, v in os.environ.items() if k not in ("SEEKR_DEVICES", "SEEKR_PEARSON_STRIPE_ROWS", "SEEKR_PRECISION",
+                                                             "SEEKR_TEST_HOOKS", "SEEKR_RCCL_LIB", "SEEKR_DEVICE")}
     full.update({k: str(v) for k, v in env.items()})
     proc = subprocess.run([sys.executable, os.path.join(HERE, "multi_devices_worker.py"), str(out_dir), scale], env=full,
                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)

@@ -67,6 +67,7 @@ def test_mailbox_chain_between_four_real_gpus(tmp_path):
 def test_bench_reports_the_chain_ab_between_two_real_gpus():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR",
                                                                "SEEKR_TEST_HOOKS", "SEEKR_RCCL_LIB", "SEEKR_FORCE_DEVICE", "SEEKR_CHAIN")}
+    env["SEEKR_BENCH_CHAIN_AB"] = "1"  # opt-in since round 5: a hang in the A/B must not cost the headline line
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "12000",
            "--length", "500"]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
@@ -95,3 +96,21 @@ def test_bench_starts_two_real_ranks(extra):
     out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
     assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["value"] > 0 and "layout_fallback" not in out
     assert len(out["per_rank"]["comm_ms"]) == 2
+
+
+@needs2
+@pytest.mark.parametrize("devices,stripe", [("all", None), ("0,1", 256)])
+def test_seekr_devices_behind_the_api_on_real_gpus(devices, stripe, tmp_path):
+    """SEEKR_DEVICES over the REAL librccl — one host thread per GPU, ncclCommInitRank per thread — through BasicCounter,
+    pearson() and the three commands: every output byte-identical to the run with SEEKR_DEVICES unset (the comparison of
+    tests/test_gpu_multi_devices.py, which has only mock ranks on one GPU to offer on the pool's boxes)."""
+    from test_gpu_multi_devices import run_worker, same_outputs
+    baseline = run_worker(tmp_path / "one_gpu")
+    env = {"SEEKR_DEVICES": devices}
+    if stripe:
+        env["SEEKR_PEARSON_STRIPE_ROWS"] = stripe
+    got = run_worker(tmp_path / "devices", **env)
+    with open(os.path.join(got, "info.json")) as fh:
+        info = json.load(fh)
+    assert info["group_size"] == (_gpus() if devices == "all" else 2) and info["group_broken"] is False
+    same_outputs(baseline, got)
