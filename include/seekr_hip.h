@@ -185,8 +185,8 @@ int skr_colsum_seq(skr_ctx* ctx, const skr_mat* x, const skr_mat* center, const 
 /* skr_colsum_seq's first pass (no centre) that also returns the column minima of the raw matrix: colmin is
  * float32 [4, cols], the minimum over its four rows is the column's (NaN where the column holds one).  Float32
  * rounding is monotone, so min_i z[i,j] = z(min_i x[i,j]) for scale >= 0 and skr_min_nan over `colmin` gives the
- * Log2.post shift of kmer_counts.py:208 without a pass over the matrix.  The column count must be a multiple of 16
- * (SKR_ERR_UNSUPPORTED otherwise: use skr_colsum_seq + skr_min_nan on x).                                          */
+ * Log2.post shift of kmer_counts.py:208 without a pass over the matrix.  Any column count since round 5 (a matrix
+ * without rows: SKR_ERR_UNSUPPORTED — use skr_colsum_seq + skr_min_nan on x).                                       */
 int skr_colsum_seq_colmin(skr_ctx* ctx, const skr_mat* x, skr_mat* acc, skr_mat* colmin);
 /* The same chain across the GPUs of a node WITHOUT a transfer between two kernels (one process per GPU).  Every rank
  * creates a chain (a mailbox in uncached device memory for up to cols_cap columns), exports it as a 64-byte HIP IPC

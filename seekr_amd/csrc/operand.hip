@@ -384,10 +384,15 @@ __global__ __launch_bounds__(256) void operand_fill_kernel(FillArgs a) {
 // memory, where it stays in the L2.  A thread owns the same groups of 8 consecutive columns in every
 // pass, so what it parked (in LDS, or in `y`) in pass 1 is its own later on; without `y` and without
 // LDS the normalisation tail is simply recomputed from x.
-template <typename T, bool IN_LDS>
-__global__ __launch_bounds__(256) void operand_fill_block_kernel(FillArgs a) {
+// THREADS: 256, or 1 024 (round 5) for the rows this kernel was slowest on — widths that are not a multiple of 8 and rows
+// too wide for the LDS (k >= 8).  A row is a chain of passes, each ending in a workgroup-wide sum: with four waves a pass
+// is many rounds of a few loads per thread and the chain's latency is the kernel (49 us per 62 KB row at 2 workgroups per
+// CU); sixteen waves put the whole row in flight at once.
+template <typename T, bool IN_LDS, int THREADS = 256>
+__global__ __launch_bounds__(THREADS) void operand_fill_block_kernel(FillArgs a) {
     extern __shared__ __attribute__((aligned(16))) float rowbuf[];
-    __shared__ float red[4];
+    constexpr int WAVES = THREADS / 64;
+    __shared__ float red[WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t K = a.cols, Kp = a.kt * 32, groups = a.kt * 4;
     const bool vec = (K & 7) == 0;
@@ -396,7 +401,8 @@ __global__ __launch_bounds__(256) void operand_fill_block_kernel(FillArgs a) {
         v = wave_sum(v);
         if (lane == 0) red[wave] = v;
         __syncthreads();
-        const float t = (red[0] + red[1]) + (red[2] + red[3]);
+        float t = (red[0] + red[1]) + (red[2] + red[3]);
+        if (WAVES == 16) t = (t + ((red[4] + red[5]) + (red[6] + red[7]))) + (((red[8] + red[9]) + (red[10] + red[11])) + ((red[12] + red[13]) + (red[14] + red[15])));
         __syncthreads();
         return t;
     };
@@ -413,8 +419,11 @@ __global__ __launch_bounds__(256) void operand_fill_block_kernel(FillArgs a) {
         // the end of the row read as 0 and are never used
         auto load8 = [&](int64_t g, float (&v)[8]) {
             const int64_t c0 = g * 8;
-            if (vec && (IN_LDS || yr)) {
-                const float* src = IN_LDS ? rowbuf + c0 : yr + c0;
+            if (IN_LDS && c0 + 8 <= K) {  // the LDS copy of the row starts at a 16-byte boundary whatever the width
+                const float4 u = *reinterpret_cast<const float4*>(rowbuf + c0), w = *reinterpret_cast<const float4*>(rowbuf + c0 + 4);
+                v[0] = u.x, v[1] = u.y, v[2] = u.z, v[3] = u.w, v[4] = w.x, v[5] = w.y, v[6] = w.z, v[7] = w.w;
+            } else if (vec && yr) {
+                const float* src = yr + c0;
                 const float4 u = *reinterpret_cast<const float4*>(src), w = *reinterpret_cast<const float4*>(src + 4);
                 v[0] = u.x, v[1] = u.y, v[2] = u.z, v[3] = u.w, v[4] = w.x, v[5] = w.y, v[6] = w.z, v[7] = w.w;
             } else {
@@ -423,7 +432,56 @@ __global__ __launch_bounds__(256) void operand_fill_block_kernel(FillArgs a) {
             }
         };
         float s = 0.f, vmin = INFINITY, vmax = -INFINITY;
-        for (int64_t g = tid; g < groups; g += 256) {
+        if (!vec && IN_LDS) {
+            // A width that is not a multiple of 8 (5^6, 7^4 ... columns: rows start at 4-byte boundaries only).  Round 5: the
+            // row comes in — and the normalised counts go out — in 16-byte pieces, lane after lane (a dword-aligned
+            // global_load_dwordx4 is as good as an aligned one), four pieces in flight per thread, and is parked in the
+            // LDS; the sums are then taken from the LDS copy in the order they always were (a thread's groups of 8
+            // cells, cell by cell): same bits, 8.4 -> 2.x ms per 50 000 x 15 625 (0.14 -> 0.4x of the HBM peak).
+            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+            const int64_t n4 = K >> 2;
+            for (int64_t i0 = tid; i0 < n4; i0 += 4 * THREADS) {
+                f4u q[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int64_t i = i0 + THREADS * u < n4 ? i0 + THREADS * u : n4 - 1;  // past the end: re-read the last piece
+                    q[u] = *reinterpret_cast<const f4u*>(xr + 4 * i);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int64_t i = i0 + THREADS * u;
+                    if (i < n4) {
+                        const int64_t c = 4 * i;
+                        f4u w;
+                        w[0] = fill_tail(a, q[u][0], c, any_nan);
+                        w[1] = fill_tail(a, q[u][1], c + 1, any_nan);
+                        w[2] = fill_tail(a, q[u][2], c + 2, any_nan);
+                        w[3] = fill_tail(a, q[u][3], c + 3, any_nan);
+                        if (yr) *reinterpret_cast<f4u*>(yr + c) = w;
+                        *reinterpret_cast<float4*>(rowbuf + c) = make_float4(w[0], w[1], w[2], w[3]);
+                    }
+                }
+            }
+            if (tid < (K & 3)) {  // the last one to three cells
+                const int64_t c = 4 * n4 + tid;
+                const float v = fill_tail(a, xr[c], c, any_nan);
+                if (yr) yr[c] = v;
+                rowbuf[c] = v;
+            }
+            __syncthreads();
+            for (int64_t g = tid; g < groups; g += THREADS) {
+                float v8[8];
+                load8(g, v8);
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++)
+                    if (g * 8 + jj < K) {
+                        s += v8[jj];
+                        vmin = fminf(vmin, v8[jj]);
+                        vmax = fmaxf(vmax, v8[jj]);
+                    }
+            }
+        } else
+        for (int64_t g = tid; g < groups; g += THREADS) {
             const int64_t c0 = g * 8;
             if (vec) {
                 float4 u = *reinterpret_cast<const float4*>(xr + c0), w = *reinterpret_cast<const float4*>(xr + c0 + 4);
@@ -476,10 +534,14 @@ __global__ __launch_bounds__(256) void operand_fill_block_kernel(FillArgs a) {
             if (lane == 0) red[wave] = vmin;
             __syncthreads();
             vmin = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+#pragma unroll
+            for (int w = 4; w < WAVES; w++) vmin = fminf(vmin, red[w]);
             __syncthreads();
             if (lane == 0) red[wave] = vmax;
             __syncthreads();
             vmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+#pragma unroll
+            for (int w = 4; w < WAVES; w++) vmax = fmaxf(vmax, red[w]);
             __syncthreads();
         }
         float same = 0.f, adj = 0.f;
@@ -500,7 +562,7 @@ __global__ __launch_bounds__(256) void operand_fill_block_kernel(FillArgs a) {
             const float kf = (float)K;
             mean = block_sum(s) / kf;
             s = 0.f;
-            for (int64_t g = tid; g < groups; g += 256) {
+            for (int64_t g = tid; g < groups; g += THREADS) {
                 float v[8];
                 load8(g, v);
 #pragma unroll
@@ -510,7 +572,7 @@ __global__ __launch_bounds__(256) void operand_fill_block_kernel(FillArgs a) {
             }
             const float m2 = block_sum(s) / kf;
             s = 0.f;
-            for (int64_t g = tid; g < groups; g += 256) {
+            for (int64_t g = tid; g < groups; g += THREADS) {
                 float v[8];
                 load8(g, v);
 #pragma unroll
@@ -522,7 +584,7 @@ __global__ __launch_bounds__(256) void operand_fill_block_kernel(FillArgs a) {
             }
             sd = sqrtf(block_sum(s) / kf);
         } else if (sizeof(T) != 4) {
-            for (int64_t g = tid; g < groups; g += 256) {
+            for (int64_t g = tid; g < groups; g += THREADS) {
                 float v[8];
                 load8(g, v);
                 count_repeats(g, v);
@@ -541,7 +603,7 @@ __global__ __launch_bounds__(256) void operand_fill_block_kernel(FillArgs a) {
             if (n_same >= 0.85f * (float)K || n_adj >= 0.70f * (float)(K - 1)) coherent = true;
         }
         float sq = 0.f, m3 = 0.f, m4 = 0.f;
-        for (int64_t g = tid; g < groups; g += 256) {
+        for (int64_t g = tid; g < groups; g += THREADS) {
             const int64_t tile = g >> 2, sub = g & 3, k0 = g * 8;
             float z[8];
             load8(g, z);
@@ -1005,10 +1067,15 @@ int launch_fill(skr_ctx* ctx, const skr_operand* op, const FillArgs& a_in) {
         const size_t blds = wide ? 0 : row_floats * 4;
         const int64_t bper_cu = wide ? 8 : std::max<int64_t>(1, (int64_t)((150 * 1024) / blds));
         const unsigned wgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(a.rows, (int64_t)ctx->num_cu * bper_cu));
+        // sixteen-wave workgroups: two per CU at most (2 048 threads), one when the row takes more than half the LDS
+        const unsigned wgrid16 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(a.rows, (int64_t)ctx->num_cu * std::min<int64_t>(2, bper_cu)));
 #define LAUNCH_BLOCK(T)                                                                                           \
     do {                                                                                                          \
         if (wide) {                                                                                               \
-            hipLaunchKernelGGL((operand_fill_block_kernel<T, false>), dim3(wgrid), dim3(256), 0, ctx->stream, a);  \
+            hipLaunchKernelGGL((operand_fill_block_kernel<T, false, 1024>), dim3(wgrid16), dim3(1024), 0, ctx->stream, a); \
+        } else if ((a.cols & 7) != 0) {                                                                            \
+            SKR_TRY(skr_kernel_lds(ctx, reinterpret_cast<const void*>(operand_fill_block_kernel<T, true, 1024>), blds)); \
+            hipLaunchKernelGGL((operand_fill_block_kernel<T, true, 1024>), dim3(wgrid16), dim3(1024), blds, ctx->stream, a); \
         } else {                                                                                                  \
             SKR_TRY(skr_kernel_lds(ctx, reinterpret_cast<const void*>(operand_fill_block_kernel<T, true>), blds)); \
             hipLaunchKernelGGL((operand_fill_block_kernel<T, true>), dim3(wgrid), dim3(256), blds, ctx->stream, a); \

@@ -75,9 +75,9 @@ class HipEngine:
         chain.colsum(x, acc, center, center2, square, colmin)
 
     def colmin_buffer(self, x):
-        """A [4, cols] buffer for the raw column minima the first column-sum pass can produce on the way (None when
-        the column count does not allow it: then the Log2.post minimum is scanned from the matrix)."""
-        return self.ctx.empty(4, x.cols) if x.cols % 16 == 0 and x.rows > 0 else None
+        """A [4, cols] buffer for the raw column minima the first column-sum pass can produce on the way (None for a
+        shard without rows: then the Log2.post minimum is scanned from the — empty — matrix).  Any width since round 5."""
+        return self.ctx.empty(4, x.cols) if x.rows > 0 else None
 
     def finish(self, v, n, take_sqrt=False):
         _lib.vec_finish(self.ctx, v, n, take_sqrt)
@@ -555,6 +555,16 @@ def sharded_pearson_symmetric(engine, comm, z, bounds, r_row, r_col, recv_bufs, 
         halves = [(0, peer_h, comm.shift_part(z, 0, own_h, dst, buf_of(0), 0, peer_h, peer)),
                   (peer_h, n_of(peer) - peer_h,
                    comm.shift_part(z, own_h, n_of(rank) - own_h, dst, buf_of(0), peer_h, n_of(peer) - peer_h, peer))]
+    def cross(a, a0, b, p0, peer):
+        """The block (rows a0.. of this shard) x (rows of shard `peer` starting at global row p0) and its mirror.  The rows
+        that come FIRST in the matrix take the A side of the contraction — as in the one-GPU self-comparison, whose cell
+        (i, j) and its mirror both carry the value computed with row min(i, j) as A (the split contraction names A's halves
+        first in the order of its cross products): every cell is then the one-GPU result bit for bit (round 5)."""
+        if peer > rank:
+            engine.gemm_mirror(a, b, r_row, a0, p0, r_col, p0, a0)
+        else:
+            engine.gemm_mirror(b, a, r_col, p0, a0, r_row, a0, p0)
+
     group_ticket = None
     if grouped:
         group_ticket = comm.shift_all([(z, (rank - s) % size, buf_of(i), n_of(peer), peer)
@@ -570,7 +580,7 @@ def sharded_pearson_symmetric(engine, comm, z, bounds, r_row, r_col, recv_bufs, 
                 if j == len(halves) - 1 and len(plan) > 1:
                     post(1)
                 if hn:
-                    engine.gemm_mirror(z, engine.view(buf_of(0), h0, hn), r_row, 0, p0 + h0, r_col, p0 + h0, 0)
+                    cross(z, 0, engine.view(buf_of(0), h0, hn), p0 + h0, peer)
             continue
         if grouped:
             if i == 0:
@@ -582,8 +592,7 @@ def sharded_pearson_symmetric(engine, comm, z, bounds, r_row, r_col, recv_bufs, 
         if an and bn:
             a = z if an == engine.rows(z) else engine.view(z, a0, an)
             b = engine.view(buf_of(i), b0, bn)
-            p0 = bounds[peer] + b0
-            engine.gemm_mirror(a, b, r_row, a0, p0, r_col, p0, a0)
+            cross(a, a0, b, bounds[peer] + b0, peer)
     return owned_blocks(size, rank, bounds)
 
 

@@ -80,18 +80,30 @@ def gen_case_wide(rng):
     return a, b, True, dict(K=K, M=a.shape[0], N=b.shape[0], dt="f32", same=same, rs=True, kind=kind)
 
 
+LAYOUT_WIDTHS = [4096, 4096, 16384]
+if os.environ.get("SEEKR_FUZZ_LAYOUT_WIDTHS"):  # e.g. 64,256,1024,4096,16384,65536: every width the split-fp16 kernel serves
+    LAYOUT_WIDTHS = [int(t) for t in os.environ["SEEKR_FUZZ_LAYOUT_WIDTHS"].split(",")]
+LAYOUT_CROSS_STRUCTURE = os.environ.get("SEEKR_FUZZ_LAYOUT_CROSS", "0") == "1"  # b drawn from ANOTHER structure class than a
+
+
 def gen_case_layout(rng):
-    """Rows with STRUCTURE at the two widths that can take the opt-in f16f8 operand layout (4 096 / 16 384 columns, float32,
-    row-standardised): short periods, a few jittered levels, few distinct values, levels aligned between rows, quantised
-    values, and mixtures of those with plain gaussian rows — the inputs on which the fp8 roundings of that layout do not
-    average out and its fill has to route the operand back to the three-product split (tools/f8_cross_study.py).  Under
-    the default precision the same cases exercise the coherent-row flag and the accumulator chunks."""
-    K = int(rng.choice([4096, 4096, 16384]))
-    M, N = int(rng.integers(2, 48)), int(rng.integers(2, 48))
+    """Rows with STRUCTURE (float32, row-standardised): short periods, a few jittered levels, few distinct values, levels
+    aligned between rows, quantised values, and mixtures of those with plain gaussian rows — the inputs on which the fp8
+    roundings of the opt-in f16f8 layout do not average out and its fill has to route the operand back to the three-product
+    split (tools/f8_cross_study.py), and on which, under the default precision, the coherent-row flag and the accumulator
+    chunks earn their keep.  By default at the two widths that can take the f16f8 layout (4 096 / 16 384 columns: the
+    stream tests/golden and the round-4 soaks were drawn from); SEEKR_FUZZ_LAYOUT_WIDTHS names any others (round 5: every
+    width the split-fp16 kernel serves, 64 ... 65 536), SEEKR_FUZZ_LAYOUT_CROSS=1 draws the second operand of a cross
+    comparison from a different structure class than the first."""
+    K = int(rng.choice(LAYOUT_WIDTHS))
+    cap = 48 if K <= 16384 else 20
+    M, N = int(rng.integers(2, cap)), int(rng.integers(2, cap))
     same = bool(rng.integers(0, 2))
     kind = int(rng.integers(0, 7))
     jit = float(10.0 ** rng.uniform(-6.5, -1.0))
+    kinds = [kind]
     def make(rows):
+        kind = kinds[0]
         if kind == 0:    # periodic rows, shifted copies of one sequence
             P = int(rng.integers(2, 6000))
             vals = rng.standard_normal(P)
@@ -121,8 +133,11 @@ def gen_case_layout(rng):
             x[plain] = rng.standard_normal((int(plain.sum()), K))
         return x.astype(np.float32)
     a = make(M)
+    if not same and LAYOUT_CROSS_STRUCTURE:
+        kinds[0] = int(rng.integers(0, 7))
     b = a if same else make(N)
-    return a, b, True, dict(K=K, M=a.shape[0], N=b.shape[0], dt="f32", same=same, rs=True, kind=100 + kind, jitter=jit)
+    return a, b, True, dict(K=K, M=a.shape[0], N=b.shape[0], dt="f32", same=same, rs=True, kind=100 + kind, kind_b=100 + kinds[0],
+                            jitter=jit)
 
 
 LAYOUT_EVERY = 3 if os.environ.get("SEEKR_PRECISION", "") == "f16f8" else 40

@@ -115,7 +115,8 @@ def check_ranks(size, asynchronous, mock_lib, single, tmp_path, extra_env=None):
             hits[gr:gr + nr, gc:gc + nc] += 1
     assert (hits == 1).all()
     assert np.array_equal(bits(full), bits(full.T.copy()))
-    assert np.allclose(full, single["r"], rtol=1e-6, atol=1e-6)
+    # ... and the one-GPU result bit for bit: in every cross block the rows that come first in the matrix take the A side
+    assert np.array_equal(bits(full), bits(single["r"]))
     # striped edge lists: the union over the ranks = upper triangle of the thresholded single-GPU matrix
     want = np.triu(np.where(single["r"] < 0.05, 0, single["r"]), 1)
     got = np.zeros_like(want)
@@ -259,7 +260,7 @@ def test_bench_rank_gives_up_when_a_peer_never_arrives(mock_lib):
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--rows", "4000",
                           "--length", "400", "--launch-timeout", "6"], env=env, capture_output=True, text=True, timeout=120)
     assert res.returncode == 3, (res.returncode, res.stderr[-1500:])
-    assert "no progress after 6 s, last stage:" in res.stderr and time.time() - t0 < 60
+    assert "no progress for 6 s, last stage:" in res.stderr and time.time() - t0 < 60
     assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
 
 
