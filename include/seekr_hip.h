@@ -53,7 +53,8 @@ enum {
     SKR_PREC_FP32 = 0,   /* v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulate           */
     SKR_PREC_BF16X3 = 1, /* split-bf16: hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16       */
     SKR_PREC_F64 = 2,    /* v_mfma_f64_16x16x4_f64 (float64 inputs: CSV / integer count files)   */
-    SKR_PREC_BF16X4 = 3, /* split-bf16 with the lo*lo term as well                                */
+    SKR_PREC_BF16X4 = 3, /* RETIRED in round 5 (split-bf16 with the lo*lo term: 25 % slower than BF16X3 with the same
+                          * 16-bit residual, no use left): the value stays reserved, every entry point answers SKR_ERR_INVALID */
     SKR_PREC_F16F8 = 5,  /* opt-in (round 4): hi*hi on v_mfma_f32_16x16x32_f16, the two cross terms as ONE block-scaled
                           * fp8 product (v_mfma_scale_f32_16x16x128_f8f6f4): 2 product-units per k instead of 3; for
                           * row-standardised rows of 4 096 / 16 384 columns (k = 6, 7); any other shape and rows flagged as

@@ -20,7 +20,7 @@ F32, F64, U32 = 0, 1, 2
 LOG2_NONE, LOG2_PRE, LOG2_POST = 0, 1, 2
 PREC_FP32, PREC_BF16X3, PREC_F64, PREC_BF16X4, PREC_F16X3, PREC_F16F8 = 0, 1, 2, 3, 4, 5
 LOG2_CODES = {"Log2.none": LOG2_NONE, "Log2.pre": LOG2_PRE, "Log2.post": LOG2_POST}
-PRECISIONS = {"fp32": PREC_FP32, "bf16x3": PREC_BF16X3, "bf16x4": PREC_BF16X4, "f16x3": PREC_F16X3, "f64": PREC_F64,
+PRECISIONS = {"fp32": PREC_FP32, "bf16x3": PREC_BF16X3, "f16x3": PREC_F16X3, "f64": PREC_F64,  # (bf16x4 = 3: retired in round 5)
               "f16f8": PREC_F16F8}  # f16f8: opt-in, two product-units per k; degrades to f16x3 by itself
 _NP_OF = {F32: np.float32, F64: np.float64, U32: np.uint32}
 _CODE_OF = {np.dtype(np.float32): F32, np.dtype(np.float64): F64, np.dtype(np.uint32): U32}
@@ -295,6 +295,25 @@ class Context:
 
 
 _default_ctx = {}
+# A skr_ctx is ONE stream plus its scratch (flag words, workspaces): calls through one ctx from several host threads are
+# not safe against each other inside the library.  The drop-in API (BasicCounter's computing methods, pearson(),
+# pearson_to_file()) works on the process-wide default context, so its entry points take this lock: two Python threads
+# may call them freely, the calls run one after the other (the reference is "not re-entrant, no globals": SURVEY 8b).
+# Code that drives device handles itself (Context / Matrix / Operand, seekr_amd.consumers) from several threads holds
+# it too, or gives every thread its own Context.
+API_LOCK = threading.RLock()
+
+
+def api_call(fn):
+    """Decorator: run the function under API_LOCK (see above)."""
+    import functools
+
+    @functools.wraps(fn)
+    def locked(*args, **kwargs):
+        with API_LOCK:
+            return fn(*args, **kwargs)
+    return locked
+
 
 
 def default_context():

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void operand_fill_kernel(FillArgs a) {
 // too wide for the LDS (k >= 8).  A row is a chain of passes, each ending in a workgroup-wide sum: with four waves a pass
 // is many rounds of a few loads per thread and the chain's latency is the kernel (49 us per 62 KB row at 2 workgroups per
 // CU); sixteen waves put the whole row in flight at once.
-template <typename T, bool IN_LDS, int THREADS = 256>
+template <typename T, bool IN_LDS, int THREADS = 256, int PRE = 1>
 __global__ __launch_bounds__(THREADS) void operand_fill_block_kernel(FillArgs a) {
     extern __shared__ __attribute__((aligned(16))) float rowbuf[];
     constexpr int WAVES = THREADS / 64;
@@ -406,6 +406,23 @@ __global__ __launch_bounds__(THREADS) void operand_fill_block_kernel(FillArgs a)
         __syncthreads();
         return t;
     };
+    // Odd widths staged through the LDS (below): the NEXT row's pieces are requested as soon as this row's have been parked,
+    // and arrive while this row's statistics — a chain of workgroup-wide sums during which the memory system would
+    // otherwise idle — and its stores are under way.  kPre pieces per thread cover the widest row the LDS takes.
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    constexpr int kPre = PRE;  // 4: rows of up to 16 384 cells (the register budget of sixteen waves is 128); 10: up to 40 960
+    const bool staged = !vec && IN_LDS && THREADS == 1024;
+    const int64_t n4 = K >> 2;
+    f4u pre[kPre];
+    auto prefetch = [&](int64_t row) {
+        const float* src = a.x + (size_t)row * K;
+#pragma unroll
+        for (int u = 0; u < kPre; u++) {
+            const int64_t i = tid + (int64_t)THREADS * u;
+            if (i < n4) pre[u] = *reinterpret_cast<const f4u*>(src + 4 * i);
+        }
+    };
+    if (staged && (int64_t)blockIdx.x < a.rows) prefetch(blockIdx.x);
     for (int64_t r = blockIdx.x; r < a.rows; r += gridDim.x) {
         const float* xr = a.x + (size_t)r * K;
         float* yr = a.y ? a.y + (size_t)r * K : nullptr;
@@ -438,8 +455,25 @@ __global__ __launch_bounds__(THREADS) void operand_fill_block_kernel(FillArgs a)
             // global_load_dwordx4 is as good as an aligned one), four pieces in flight per thread, and is parked in the
             // LDS; the sums are then taken from the LDS copy in the order they always were (a thread's groups of 8
             // cells, cell by cell): same bits, 8.4 -> 2.x ms per 50 000 x 15 625 (0.14 -> 0.4x of the HBM peak).
-            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-            const int64_t n4 = K >> 2;
+            if (staged) {
+#pragma unroll
+                for (int u = 0; u < kPre; u++) {
+                    const int64_t i = tid + (int64_t)THREADS * u;
+                    if (i < n4) {
+                        const int64_t c = 4 * i;
+                        f4u w;
+                        w[0] = fill_tail(a, pre[u][0], c, any_nan);
+                        w[1] = fill_tail(a, pre[u][1], c + 1, any_nan);
+                        w[2] = fill_tail(a, pre[u][2], c + 2, any_nan);
+                        w[3] = fill_tail(a, pre[u][3], c + 3, any_nan);
+                        if (yr) *reinterpret_cast<f4u*>(yr + c) = w;
+                        *reinterpret_cast<float4*>(rowbuf + c) = make_float4(w[0], w[1], w[2], w[3]);
+                    }
+                    // one piece at a time: left to itself the scheduler hoists the centre / scale loads of all pieces to the
+                    // top (8 registers each, on top of the prefetched row) and the sixteen-wave budget of 128 spills
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else
             for (int64_t i0 = tid; i0 < n4; i0 += 4 * THREADS) {
                 f4u q[4];
 #pragma unroll
@@ -469,6 +503,7 @@ __global__ __launch_bounds__(THREADS) void operand_fill_block_kernel(FillArgs a)
                 rowbuf[c] = v;
             }
             __syncthreads();
+            if (staged && r + gridDim.x < a.rows) prefetch(r + gridDim.x);
             for (int64_t g = tid; g < groups; g += THREADS) {
                 float v8[8];
                 load8(g, v8);
@@ -653,13 +688,256 @@ __global__ __launch_bounds__(THREADS) void operand_fill_block_kernel(FillArgs a)
     if (coherent) atomicOr(&a.flags[5], 1u);
 }
 
+template <typename T>
+using vec4h = T __attribute__((ext_vector_type(4)));
+
+// ---- round 5: ANY width up to VPT * 4 096 columns, the row in the registers of a sixteen-wave workgroup ------------------
+// The block kernel above parks a row in the LDS (or re-reads it from the L2) and walks it once per statistic, four waves a
+// row: a chain of passes during which nothing of the next row is on its way — 26 us per 62 KB row, 1.1 TB/s on 5^6 columns,
+// 1.5 TB/s on 4^8.  Here thread t of 1 024 owns the 16-byte pieces t, t + 1 024, ... of the row (VPT of them: 4 for rows
+// of up to 16 384 cells, 16 up to 65 536), all loads of a row in flight at once and — VPT = 4 — the NEXT row's pieces
+// requested as soon as this row's have been taken over, so that they arrive under this row's statistics and stores; rows
+// start on 4-byte boundaries only when the width is odd, which a dword-aligned global_load_dwordx4 does not mind.  Every
+// statistic is one wave sum + ONE barrier (two alternating slots of partials).  MODE as in the register kernel below
+// (0: rows as they are, 1: float32 centre + scale, 2: + the Log2.post tail); anything else stays with the block kernel.
+// The arithmetic per cell is the block kernel's; the row SUMS are taken in another order (16 waves, pieces lane after
+// lane), so mean and std of a row — and with them the last bits of r — are those of this kernel wherever it serves.
+template <typename T, int VPT, int MODE, bool HASY>
+__global__ __launch_bounds__(1024) void operand_fill_rowreg_kernel(FillArgs a) {
+    constexpr int THREADS = 1024, WAVES = 16;
+    constexpr bool PREFETCH = VPT <= 4;
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    __shared__ float red[2][3][WAVES];
+    __shared__ float edge[VPT][WAVES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // (32-bit column arithmetic: the widest row this kernel takes has 65 536 cells)
+    const int K = (int)a.cols, Kp = (int)a.kt * 32;
+    const int n4 = K >> 2, n4p = Kp >> 2;  // whole pieces inside the row; pieces of the padded operand row
+    const float kf = (float)K;
+    bool any_nan = false, overflow = false, outlier = false, coherent = false;
+    int phase = 0;
+    // up to three sums (or maxima) over the workgroup with one barrier: the partials of consecutive calls alternate slots
+    auto reduce3 = [&](float& p0, float& p1, float& p2, bool is_max) {
+        if (is_max) {
+            p0 = wave_max(p0), p1 = wave_max(p1), p2 = wave_max(p2);
+        } else {
+            p0 = wave_sum(p0), p1 = wave_sum(p1), p2 = wave_sum(p2);
+        }
+        float(*slot)[WAVES] = red[phase & 1];
+        phase++;
+        if (lane == 0) slot[0][wave] = p0, slot[1][wave] = p1, slot[2][wave] = p2;
+        __syncthreads();
+        // every group of 16 lanes folds the 16 partials by itself — one LDS read and four shuffles per quantity (reading all
+        // 48 partials into registers, on top of this row and the next, is what made the kernel spill)
+        float t[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            float x = slot[q][lane & 15];
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) {
+                const float o = __shfl_xor(x, off, 64);
+                x = is_max ? fmaxf(x, o) : x + o;
+            }
+            t[q] = x;
+        }
+        p0 = t[0], p1 = t[1], p2 = t[2];
+    };
+    f4u nx[VPT];
+    auto fetch = [&](int64_t row, f4u (&dst)[VPT]) {
+        const float* src = a.x + (size_t)row * K;
+#pragma unroll
+        for (int u = 0; u < VPT; u++) {
+            const int i = tid + THREADS * u;
+            f4u q = {0.f, 0.f, 0.f, 0.f};
+            if (i < n4) {
+                q = *reinterpret_cast<const f4u*>(src + 4 * i);
+            } else if (4 * i < K) {  // the row's last one to three cells
+                q[0] = src[4 * i];
+                if (4 * i + 1 < K) q[1] = src[4 * i + 1];
+                if (4 * i + 2 < K) q[2] = src[4 * i + 2];
+            }
+            dst[u] = q;
+        }
+    };
+    if (PREFETCH && (int64_t)blockIdx.x < a.rows) fetch(blockIdx.x, nx);
+    for (int64_t r = blockIdx.x; r < a.rows; r += gridDim.x) {
+        float v[VPT][4];
+        if (PREFETCH) {
+#pragma unroll
+            for (int u = 0; u < VPT; u++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) v[u][j] = nx[u][j];
+            if (r + gridDim.x < a.rows) fetch(r + gridDim.x, nx);
+        } else {
+            fetch(r, nx);
+#pragma unroll
+            for (int u = 0; u < VPT; u++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) v[u][j] = nx[u][j];
+        }
+        // ---- the elementwise tail of the normalisation (kmer_counts.py:169,175,208-209) and the optional write-back
+        float s = 0.f, vmin = INFINITY, vmax = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < VPT; u++) {
+            const int c = 4 * (tid + THREADS * u);
+            if (MODE >= 1 && c < K) {
+                float m[4] = {0.f, 0.f, 0.f, 0.f}, d[4] = {1.f, 1.f, 1.f, 1.f};
+                if (c + 3 < K) {  // the vectors start on 16-byte boundaries and c is a multiple of four
+                    const float4 mm = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.center) + c);
+                    const float4 dd = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.scale) + c);
+                    m[0] = mm.x, m[1] = mm.y, m[2] = mm.z, m[3] = mm.w, d[0] = dd.x, d[1] = dd.y, d[2] = dd.z, d[3] = dd.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (c + j < K) m[j] = reinterpret_cast<const float*>(a.center)[c + j], d[j] = reinterpret_cast<const float*>(a.scale)[c + j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (c + j < K) {
+                        float t = __fdiv_rn(__fsub_rn(v[u][j], m[j]), d[j]);
+                        if (t != t) any_nan = true;
+                        if (MODE == 2) t = skr_log2_of_sum1(__fadd_rn(t, a.shift));
+                        v[u][j] = t;
+                    }
+            }
+            if (HASY && c < K) {
+                float* yr = a.y + (size_t)r * K + c;
+                if (c + 3 < K) {
+                    *reinterpret_cast<f4u*>(yr) = f4u{v[u][0], v[u][1], v[u][2], v[u][3]};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 3; j++)
+                        if (c + j < K) yr[j] = v[u][j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (c + j < K) {
+                    s += v[u][j];
+                    vmin = fminf(vmin, v[u][j]);
+                    vmax = fmaxf(vmax, v[u][j]);
+                }
+            if (sizeof(T) != 4 && lane == 0) edge[u][wave] = v[u][0];  // the first cell of this wave's piece: the wave before needs it
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- row statistics in the order pearson.py:35-38 computes them; minimum and maximum ride on the first barrier
+        float nmin = -vmin, dummy = 0.f;
+        if (sizeof(T) != 4) reduce3(nmin, vmax, dummy, true);
+        vmin = -nmin;
+        float mean = 0.f, sd = 1.f;
+        float same = 0.f, adj = 0.f;
+        if (sizeof(T) != 4) {
+            // how much of the row one value holds: its minimum, or — neighbouring cells equal — any value (block kernel)
+#pragma unroll
+            for (int u = 0; u < VPT; u++) {
+                const int c = 4 * (tid + THREADS * u);
+                // the cell after this piece: the next lane's first one; lane 63: the next wave's (the last wave: piece u + 1 of wave 0)
+                float nxt = __shfl_down(v[u][0], 1, 64);
+                if (lane == 63) nxt = wave + 1 < WAVES ? edge[u][wave + 1] : (u + 1 < VPT ? edge[u + 1 < VPT ? u + 1 : u][0] : 0.f);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (c + j < K) {
+                        same += (float)(v[u][j] == vmin);
+                        const float after = j < 3 ? v[u][j + 1] : nxt;
+                        if (c + j + 1 < K) adj += (float)(v[u][j] == after);
+                    }
+            }
+        }
+        if (a.row_standardize) {
+            float z0 = 0.f, z1 = 0.f;
+            reduce3(s, z0, z1, false);
+            mean = s / kf;
+            s = 0.f;
+#pragma unroll
+            for (int u = 0; u < VPT; u++) {
+                const int c = 4 * (tid + THREADS * u);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (c + j < K) s += v[u][j] - mean;
+            }
+            reduce3(s, same, adj, false);
+            const float m2 = s / kf;
+            s = 0.f;
+#pragma unroll
+            for (int u = 0; u < VPT; u++) {
+                const int c = 4 * (tid + THREADS * u);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (c + j < K) {
+                        const float dd = (v[u][j] - mean) - m2;
+                        s += dd * dd;
+                    }
+            }
+            float z2 = 0.f, z3 = 0.f;
+            reduce3(s, z2, z3, false);
+            sd = sqrtf(s / kf);
+        } else if (sizeof(T) != 4) {
+            float z0 = 0.f;
+            reduce3(same, adj, z0, false);
+        }
+        float zmax2 = 0.f;
+        if (sizeof(T) != 4) {
+            if (vmin <= vmax) {
+                const float z_lo = (vmin - mean) / sd, z_hi = (vmax - mean) / sd;
+                zmax2 = fmaxf(z_lo * z_lo, z_hi * z_hi);
+                if (!(zmax2 == zmax2)) zmax2 = 0.f;
+            }
+            if (same >= 0.85f * kf || adj >= 0.70f * (float)(K - 1)) coherent = true;
+        }
+        // ---- standardise, split, store (operand rows are zero-padded to whole 32-column tiles)
+        float sq = 0.f, m3 = 0.f, m4 = 0.f;
+#pragma unroll
+        for (int u = 0; u < VPT; u++) {
+            const int i = tid + THREADS * u, k0 = 4 * i;
+            if (i >= n4p) continue;
+            float z[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float t = k0 + j < K ? v[u][j] : 0.f;
+                if (a.row_standardize && k0 + j < K) t = __fdiv_rn(__fsub_rn(t, mean), sd);
+                z[j] = t;
+                sq = __fmaf_rn(t, t, sq);
+                if (sizeof(T) != 4) {
+                    const float t2 = t * t;
+                    m3 = fmaf(t2, t, m3);
+                    m4 = fmaf(t2, t2, m4);
+                }
+            }
+            if (sizeof(T) == 4) {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + (size_t)r * Kp + k0) = make_float4(z[0], z[1], z[2], z[3]);
+            } else {
+                vec4h<T> hi, lo;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float zs = z[j] * a.out_scale;
+                    if (fabsf(zs) > 65504.f) overflow = true;
+                    const T hh = split_hi<T>(zs, k0 + j);
+                    hi[j] = hh;
+                    lo[j] = (T)(zs - (float)hh);
+                }
+                T* dst = reinterpret_cast<T*>(a.out) + ((size_t)r * a.kt + (k0 >> 5)) * 64 + (k0 & 31);
+                *reinterpret_cast<vec4h<T>*>(dst) = hi;
+                *reinterpret_cast<vec4h<T>*>(dst + 32) = lo;
+            }
+            __builtin_amdgcn_sched_barrier(0);  // one piece at a time: interleaved, the splits of all pieces are alive at once
+        }
+        reduce3(sq, m3, m4, false);
+        if (tid == 0) a.diag[r] = sq / kf;
+        if (sizeof(T) != 4 && a.row_standardize && row_on_two_levels(sq / kf, m3 / kf, m4 / kf)) coherent = true;
+        if (sizeof(T) != 4 && row_needs_fp32(zmax2, kf)) outlier = true;
+    }
+    if (any_nan) atomicOr(&a.flags[1], 1u);
+    if (overflow) atomicOr(&a.flags[3], 1u);
+    if (outlier) atomicOr(&a.flags[4], 1u);
+    if (coherent) atomicOr(&a.flags[5], 1u);
+}
+
 // Register-resident variant for K = VPL * 256 columns (k = 5: VPL 4, k = 6: VPL 16): a wave keeps
 // its whole row in VPL float4 registers per lane — all loads of a row are in flight together, no
 // LDS, no barrier, ~100 VGPRs so 20 waves per CU stay resident.  Lane l owns columns
 // 256 i + 4 l .. +3, so its halves go out as 8-byte pieces (8 lanes fill the 64-byte hi part of a
 // 32-k tile; the lo store fills the other half of the same 128-byte line).
-template <typename T>
-using vec4h = T __attribute__((ext_vector_type(4)));
 
 // MODE 0: rows as they are; 1: float32 center + scale; 2: center + scale + Log2.post tail.
 // (Compile-time modes: with the runtime ck/sk/post switches of fill_tail inside the unrolled
@@ -999,7 +1277,7 @@ __global__ void recip64_kernel(const float* __restrict__ v, double* __restrict__
 }
 
 bool is_f32_precision(int p) {
-    return p == SKR_PREC_FP32 || p == SKR_PREC_BF16X3 || p == SKR_PREC_BF16X4 || p == SKR_PREC_F16X3 || p == SKR_PREC_F16F8;
+    return p == SKR_PREC_FP32 || p == SKR_PREC_BF16X3 || p == SKR_PREC_F16X3 || p == SKR_PREC_F16F8;
 }
 
 // launches the fill kernel that suits the row width and the operand's storage kind
@@ -1062,6 +1340,27 @@ int launch_fill(skr_ctx* ctx, const skr_operand* op, const FillArgs& a_in) {
 #undef LAUNCH_REG
 #undef LAUNCH_REG2
         SKR_HIP(hipGetLastError());
+    } else if (reg_mode >= 0 && op->kind != 3 && (a.cols & 7) != 0 && a.cols > 8192 && a.cols <= 16384) {
+        // round 5: odd widths of 8 193 .. 16 384 columns (5^6, 7^5 ...) — the row in the registers of a sixteen-wave
+        // workgroup (operand_fill_rowreg_kernel); widths below stay with the wave-per-row kernel and its numpy-ordered
+        // sums, everything else with the block kernel (a 65 536-cell row in registers, 64 per thread, spills: measured)
+        SkrProfScope prof(ctx, "operand_fill");
+        const unsigned rgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(a.rows, (int64_t)ctx->num_cu * 2));
+#define LAUNCH_ROWREG2(T, V)                                                                                                \
+    do {                                                                                                                    \
+        if (reg_mode == 0) hipLaunchKernelGGL((operand_fill_rowreg_kernel<T, V, 0, false>), dim3(rgrid), dim3(1024), 0, ctx->stream, a);      \
+        else if (reg_mode == 1 && a.y) hipLaunchKernelGGL((operand_fill_rowreg_kernel<T, V, 1, true>), dim3(rgrid), dim3(1024), 0, ctx->stream, a); \
+        else if (reg_mode == 1) hipLaunchKernelGGL((operand_fill_rowreg_kernel<T, V, 1, false>), dim3(rgrid), dim3(1024), 0, ctx->stream, a); \
+        else if (a.y) hipLaunchKernelGGL((operand_fill_rowreg_kernel<T, V, 2, true>), dim3(rgrid), dim3(1024), 0, ctx->stream, a);             \
+        else hipLaunchKernelGGL((operand_fill_rowreg_kernel<T, V, 2, false>), dim3(rgrid), dim3(1024), 0, ctx->stream, a);                    \
+    } while (0)
+#define LAUNCH_ROWREG(T) LAUNCH_ROWREG2(T, 4)
+        if (op->kind == 0) LAUNCH_ROWREG(float);
+        else if (op->kind == 1) LAUNCH_ROWREG(__bf16);
+        else LAUNCH_ROWREG(_Float16);
+#undef LAUNCH_ROWREG
+#undef LAUNCH_ROWREG2
+        SKR_HIP(hipGetLastError());
     } else if (row_floats * 4 >= 32 * 1024) {  // k >= 7: one workgroup per row
         SkrProfScope prof(ctx, "operand_fill");
         const size_t blds = wide ? 0 : row_floats * 4;
@@ -1073,9 +1372,12 @@ int launch_fill(skr_ctx* ctx, const skr_operand* op, const FillArgs& a_in) {
     do {                                                                                                          \
         if (wide) {                                                                                               \
             hipLaunchKernelGGL((operand_fill_block_kernel<T, false, 1024>), dim3(wgrid16), dim3(1024), 0, ctx->stream, a); \
+        } else if ((a.cols & 7) != 0 && a.cols <= 16384) {                                                          \
+            SKR_TRY(skr_kernel_lds(ctx, reinterpret_cast<const void*>(operand_fill_block_kernel<T, true, 1024, 4>), blds)); \
+            hipLaunchKernelGGL((operand_fill_block_kernel<T, true, 1024, 4>), dim3(wgrid16), dim3(1024), blds, ctx->stream, a); \
         } else if ((a.cols & 7) != 0) {                                                                            \
-            SKR_TRY(skr_kernel_lds(ctx, reinterpret_cast<const void*>(operand_fill_block_kernel<T, true, 1024>), blds)); \
-            hipLaunchKernelGGL((operand_fill_block_kernel<T, true, 1024>), dim3(wgrid16), dim3(1024), blds, ctx->stream, a); \
+            SKR_TRY(skr_kernel_lds(ctx, reinterpret_cast<const void*>(operand_fill_block_kernel<T, true, 1024, 10>), blds)); \
+            hipLaunchKernelGGL((operand_fill_block_kernel<T, true, 1024, 10>), dim3(wgrid16), dim3(1024), blds, ctx->stream, a); \
         } else {                                                                                                  \
             SKR_TRY(skr_kernel_lds(ctx, reinterpret_cast<const void*>(operand_fill_block_kernel<T, true>), blds)); \
             hipLaunchKernelGGL((operand_fill_block_kernel<T, true>), dim3(wgrid), dim3(256), blds, ctx->stream, a); \
@@ -1561,7 +1863,7 @@ extern "C" int skr_pearson_gemm(skr_ctx* ctx, const skr_mat* a, const skr_mat* b
                                    b->cols, r->cols, (double)a->cols, symmetric && row0 == col0);
     }
     SKR_REQUIRE(is_f32_precision(precision),
-                "float32 operands need SKR_PREC_FP32, SKR_PREC_BF16X3, SKR_PREC_BF16X4 or SKR_PREC_F16X3");
+                "float32 operands need SKR_PREC_FP32, SKR_PREC_BF16X3, SKR_PREC_F16X3 or SKR_PREC_F16F8");
     const bool same = a->data == b->data && a->rows == b->rows;
     skr_operand *oa = nullptr, *ob = nullptr;
     int rc = skr_operand_create(ctx, a->rows, a->cols, precision, &oa);

@@ -796,9 +796,6 @@ int skr_launch_gemm_split(skr_ctx* ctx, int precision, const void* As, const voi
         case SKR_PREC_BF16X3:
             return gemm_split<__bf16, 3>(ctx, (const __bf16*)As, (const __bf16*)Bs, o, M, N, kt, K, mode,
                                          "pearson_gemm_bf16x3", coherent);
-        case SKR_PREC_BF16X4:
-            return gemm_split<__bf16, 4>(ctx, (const __bf16*)As, (const __bf16*)Bs, o, M, N, kt, K, mode,
-                                         "pearson_gemm_bf16x4", coherent);
         case SKR_PREC_F16X3:
             return gemm_split<_Float16, 3>(ctx, (const _Float16*)As, (const _Float16*)Bs, o, M, N, kt, K, mode,
                                            "pearson_gemm_f16x3", coherent);
@@ -817,9 +814,6 @@ int skr_launch_gemm_edges(skr_ctx* ctx, int precision, const void* As, const voi
     switch (precision) {
         case SKR_PREC_BF16X3:
             return gemm_split<__bf16, 3>(ctx, (const __bf16*)As, (const __bf16*)Bs, o, M, N, kt, K, EDGES, "pearson_gemm_bf16x3",
-                                         coherent, &sink);
-        case SKR_PREC_BF16X4:
-            return gemm_split<__bf16, 4>(ctx, (const __bf16*)As, (const __bf16*)Bs, o, M, N, kt, K, EDGES, "pearson_gemm_bf16x4",
                                          coherent, &sink);
         case SKR_PREC_F16X3:
             return gemm_split<_Float16, 3>(ctx, (const _Float16*)As, (const _Float16*)Bs, o, M, N, kt, K, EDGES,

@@ -60,6 +60,7 @@ class BasicCounter:
                                    2-bit kernels, any other string the general counting kernel
     """
 
+    @_lib.api_call
     def __init__(self, infasta=None, outfile=None, k=6, binary=True, mean=True, std=True, log2="Log2.post",
                  leave=True, silent=False, label=False, alphabet="AGTC"):
         self.infasta = infasta
@@ -147,6 +148,7 @@ class BasicCounter:
             raise ValueError("k must be a positive integer")
 
     # ---- kmer_counts.py:140-151 -----------------------------------------------------------
+    @_lib.api_call
     def occurrences(self, row, seq):
         """Counts k-mers of one sequence on a per-kilobase scale into `row` (any float dtype).
 
@@ -208,6 +210,7 @@ class BasicCounter:
         else:
             self.counts = dev.to_numpy()
 
+    @_lib.api_call
     def center(self):
         """Mean center counts by column (:165-169)."""
         ctx = self._ctx()
@@ -223,6 +226,7 @@ class BasicCounter:
         _lib.apply(ctx, dev, center=mean_dev)
         self._store(dev)
 
+    @_lib.api_call
     def standardize(self):
         """Divide out the standard deviations from columns of the count matrix (:171-187)."""
         ctx = self._ctx()
@@ -243,6 +247,7 @@ class BasicCounter:
         if has_nan:
             print(NAN_WARNING)
 
+    @_lib.api_call
     def log2_norm(self):
         """Apply a log2 transform to the count matrix (:189-192): counts += 1; log2."""
         ctx = self._ctx()
@@ -251,6 +256,7 @@ class BasicCounter:
         self.counts = dev.to_numpy()
 
     # ---- kmer_counts.py:194-209 -------------------------------------------------------------
+    @_lib.api_call
     def get_counts(self):
         """Generates k-mer counts for the sequences: count -> Log2.pre -> centre ->
         standardise -> Log2.post, all on the GPU; `self.counts` receives the float32 result."""

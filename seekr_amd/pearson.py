@@ -9,9 +9,9 @@ float32 inputs run on the matrix cores in the arithmetic named by `SEEKR_PRECISI
   bf16x3            split-bf16, 3 products/k: ~5 % faster, but two 8-bit halves carry 16 bits
                     and the residual adds up on rows with few distinct values (raw counts of
                     short sequences): up to ~2e-6 off the diagonal, 1e-5 on it
-  bf16x4            bf16x3 + lo*lo, ~25 % slower than bf16x3, same 16-bit residual
   fp32              f32-input MFMA, blocked accumulation: 5e-7 on smooth data, ~6x slower
-(tools/adversarial.py prints the errors of all four on worst-case inputs; the bf16 choices use
+(tools/adversarial.py prints the errors of the three on worst-case inputs; bf16x3 is kept as the CONTROL arm of that
+choice — the accuracy tables of DESIGN section 2 are measured against it — not as a recommendation; bf16x4 was retired in round 5; the bf16 choices use
 the fp32 kernel below 1024 columns, f16x3 below 64).  Anything else (float64, integers, DataFrames read from
 CSV) is promoted to float64 like numpy does and runs on the f64 MFMA.
 """
@@ -34,8 +34,8 @@ def _precision_for(dtype, row_standardize=True):
     if dtype == np.float64:
         return _lib.PREC_F64
     name = os.environ.get("SEEKR_PRECISION", "f16x3").lower()
-    if name not in ("fp32", "bf16x3", "bf16x4", "f16x3", "f16f8"):
-        raise ValueError("SEEKR_PRECISION must be fp32, bf16x3, bf16x4, f16x3 or f16f8, got {!r}".format(name))
+    if name not in ("fp32", "bf16x3", "f16x3", "f16f8"):
+        raise ValueError("SEEKR_PRECISION must be fp32, bf16x3, f16x3 or f16f8, got {!r}".format(name))
     if name in ("f16x3", "f16f8") and not row_standardize:
         name = "fp32"  # arbitrary magnitudes: outside fp16's range / inside its subnormals
     return _lib.PRECISIONS[name]
@@ -69,6 +69,7 @@ def _striped(c1, c2, w1, w2, same, row_standardize, devices, outfile_only=None):
     return multi.run_pearson(c1, None if same else c2, w1, w2, row_standardize, precision, devices, outfile=outfile_only)
 
 
+@_lib.api_call
 def pearson(counts1, counts2, row_standardize=True, outfile=None):
     """Calculates a column standardized Pearson correlation matrix (pearson.py:32-44).
 
@@ -108,6 +109,7 @@ def pearson(counts1, counts2, row_standardize=True, outfile=None):
     return dist
 
 
+@_lib.api_call
 def pearson_to_file(counts1, counts2, outfile, row_standardize=True):
     """pearson(counts1, counts2, outfile=outfile) for a caller that does not want the matrix back (`seekr_pearson -bo`,
     console_scripts.py:632-633): r goes from the GPU(s) to its place in the .npy file stripe by stripe and is never held in

@@ -21,6 +21,13 @@ under OPENBLAS_CORETYPE / thread count / operand order, up to 2.3 bars apart on 
 
 A cell that fails strict and is not order-sensitive is a FAILURE (no slack proportional to the reference's error any
 more).  `order_sensitivity` is only evaluated for cells that fail strict, so the fuzzers keep their throughput.
+
+The reach of the clause (measured numbers in DESIGN.md section 2): it is evaluated ONLY on
+cells that already failed strict parity, so what matters is not how many cells of an input would qualify (0 % on
+config-2 normalised counts, about a third on raw counts, nearly all wide r ~ 1 cells) but how many strict failures it
+excuses and what a stricter TAU would do to them: every excused cell is kept with its sensitivity (judge()["excused"]),
+the tally (tests/strict_tally.py) reports per width the share of strict-failing cells that used the clause and, for
+TAU' = 0.1 / 0.2 / 0.5 / 1.0, how many of them would turn into failures — the TAU sweep of a recorded soak.
 """
 import numpy as np
 
@@ -99,7 +106,8 @@ def judge(got, ref, truth, ok, a, b, row_standardize=True, unit=1.0):
     with np.errstate(all="ignore"):
         strict = np.where(ok, np.abs(got - ref) / bar_of(np.where(ok, ref, 0.0), unit), 0.0)
     res = {"strict_ratio": float(strict.max()) if strict.size else 0.0, "n_strict_fail": 0, "n_order_sensitive": 0,
-           "failures": [], "worst_sensitivity": 0.0, "worst_vs_f64": 0.0}
+           "failures": [], "worst_sensitivity": 0.0, "worst_vs_f64": 0.0, "n_cells": int(np.count_nonzero(ok)),
+           "excused": []}  # (strict ratio, sensitivity, device vs float64, REFERENCE vs float64) of every cell the clause let through
     cells = np.argwhere(strict > 1.0)
     if not len(cells):
         return res
@@ -111,6 +119,8 @@ def judge(got, ref, truth, ok, a, b, row_standardize=True, unit=1.0):
             res["n_order_sensitive"] += 1
             res["worst_sensitivity"] = max(res["worst_sensitivity"], float(s))
             res["worst_vs_f64"] = max(res["worst_vs_f64"], float(e64))
+            res["excused"].append((float(strict[i, j]), float(s), float(e64),
+                                   float(abs(ref[i, j] - truth[i, j]) / bar_of(truth[i, j], unit))))
             if not e64 <= 1.0:
                 res["failures"].append((int(i), int(j), "order-sensitive cell, but not within the bar of float64",
                                         dict(got=got[i, j], ref=ref[i, j], f64=truth[i, j], vs_f64=e64, sensitivity=float(s))))

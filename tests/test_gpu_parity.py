@@ -508,7 +508,17 @@ def test_cfg2_full_size_properties(L, ctx):
     # Pearson on a 4096-row slab against float64 truth, plus structural properties
     slab = ctx.from_numpy(x.to_numpy(0, 4096))
     r = L.pearson(ctx, slab, slab).to_numpy()
+    # NOTE: the diagonal of a SELF-comparison is not the contraction's value — patch_diag_kernel
+    # (operand.hip) overwrites r[i, i] with the float32 tree sum of z^2 taken while the operand was filled (inside the bar,
+    # closer to 1 than the reference's own chain).  So this assertion is met by the patch; what the contraction itself does
+    # on r ~ 1 cells is asserted where no patch reaches: the cross comparison of a matrix with a COPY of itself below, and
+    # the near-copy pairs of the regression fixtures (tests/test_gpu_fuzz.py: regress_r4_two_level_rows.npz,
+    # regress_sparse_rows.json, test_constructed_worst_case_*).
     assert np.allclose(np.diag(r), 1.0, atol=2e-6)
+    twin = ctx.from_numpy(x.to_numpy(0, 4096))  # the same rows as another matrix: PLAIN mode, nothing patched
+    r_twin = L.pearson(ctx, slab, twin).to_numpy()
+    assert np.abs(np.diag(r_twin) - 1.0).max() <= 2e-6 + 1e-5  # the unpatched r = 1 cells: within the bar
+    assert np.abs(np.diag(r_twin) - 1.0).max() > 0              # ... and really the contraction's own sums, not the patch
     assert np.array_equal(r, r.T)  # same products, same k order: exactly symmetric
     xs = slab.to_numpy()
     truth = orc.pearson_f64_truth(xs[:512], xs[:700])
@@ -860,7 +870,7 @@ def test_default_precision_on_few_valued_rows(L, ctx):
 
 
 # ------------------------------------------------------------------ split-bf16 MFMA path
-@pytest.mark.parametrize("prec", ["bf16x3", "bf16x4", "f16x3"])
+@pytest.mark.parametrize("prec", ["bf16x3", "f16x3"])
 @pytest.mark.parametrize("shape", [(5, 7, 16), (130, 257, 64), (300, 200, 100), (640, 515, 4096), (1000, 1000, 1024)])
 def test_pearson_split_bf16_vs_oracle(prec, shape, L, ctx):
     m, n, k = shape
@@ -977,7 +987,7 @@ def test_rows_dominated_by_one_column_take_the_fp32_kernel(L, ctx):
 def test_pearson_split_bf16_nan_rows(L, ctx):
     m = np.array([[1, 2, 3, 4], [5, 5, 5, 5], [4, 1, 3, 2]], dtype=np.float32)
     ref = orc.pearson(m, m)
-    for prec in ("bf16x3", "bf16x4", "f16x3"):
+    for prec in ("bf16x3", "f16x3"):
         d = ctx.from_numpy(m)
         got = L.pearson(ctx, d, d, precision=L.PRECISIONS[prec]).to_numpy()
         assert np.array_equal(np.isnan(got), np.isnan(ref))
@@ -985,7 +995,7 @@ def test_pearson_split_bf16_nan_rows(L, ctx):
 
 
 def test_cfg2_slab_split_bf16(L, ctx):
-    """8192 normalised 2 kb transcripts (config-2 data): bf16x3 / bf16x4 against float64 truth."""
+    """8192 normalised 2 kb transcripts (config-2 data): bf16x3 / f16x3 / fp32 against float64 truth."""
     n_seqs, length, k = 8192, 2000, 6
     blob, offsets = __import__("seekr_amd.synthetic", fromlist=["x"]).synthetic_ascii(2, n_seqs, length)
     packed = L.PackedSeqs.from_buffer(ctx, blob, offsets, "AGTC")
@@ -996,7 +1006,7 @@ def test_cfg2_slab_split_bf16(L, ctx):
     ref = orc.pearson(xs[:1024], xs[:2048])
     # bound = worst |r - truth|, reached on the r = 1 diagonal (4096 positive terms chained in one
     # float32 accumulator); off-diagonal errors are ~1e-7
-    for prec, bound in (("bf16x3", 6e-6), ("bf16x4", 6e-6), ("f16x3", 6e-6), ("fp32", 1.2e-6)):
+    for prec, bound in (("bf16x3", 6e-6), ("f16x3", 6e-6), ("fp32", 1.2e-6)):
         r = L.pearson(ctx, x, x, precision=L.PRECISIONS[prec]).to_numpy()
         assert np.array_equal(r, r.T)
         blk = r[:1024, :2048]
@@ -1004,7 +1014,8 @@ def test_cfg2_slab_split_bf16(L, ctx):
         off = ~np.eye(1024, 2048, dtype=bool)
         assert np.abs(blk - truth)[off].max() < 1.2e-6, (prec, np.abs(blk - truth)[off].max())
         assert np.allclose(blk, ref, rtol=RTOL, atol=ATOL_R), prec
-        assert np.allclose(np.diag(r), 1.0, atol=4e-6)
+        assert np.allclose(np.diag(r), 1.0, atol=4e-6)  # met by patch_diag_kernel, not by the kernel under test (see the
+        # note in test_cfg2_full_size_properties: the unpatched r = 1 cells are asserted there and in the regression fixtures)
 
 
 def test_cfg3_like_pipeline():

@@ -43,3 +43,19 @@ def test_strict_parity_grid_with_the_two_product_unit_precision(tmp_path):
             assert c["f16f8"]["strict"] <= 0.6, c
         else:
             assert c["f16f8"]["strict"] == c["f16x3"]["strict"] or c["f16f8"]["operand_kind"] == 0, c
+
+
+def test_levels_sweep_default_precision():
+    """tools/levels_sweep.py: rows on L = 2 ... 32 levels and their near / scaled / sign-flipped / shifted
+    copies, jitter 0 ... 1e-2, at every width the split-fp16 kernel serves (64 ... 65 536 columns), self and cross: every
+    cell strictly inside the bar of the reference, and inside 0.6 of it from float64 (profiles/r5_levels_sweep_default.log:
+    worst 0.46 / 0.43 — three tight levels at 16 384 columns, where the two-level rule of the fill does not apply)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import levels_sweep
+    table, failures = levels_sweep.sweep(verbose=False)
+    assert not failures, failures[:3]
+    assert len(table) == len(levels_sweep.WIDTHS) * len(levels_sweep.LEVELS)
+    assert max(t["strict"] for t in table) <= 1.0 and max(t["vs_f64"] for t in table) <= 0.6, max(table, key=lambda t: t["vs_f64"])
+    assert sum(t["order_sensitive"] for t in table) == 0   # not one cell needed the order-sensitivity clause

@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--length", type=int, default=2000)
     ap.add_argument("-k", type=int, default=6)
     ap.add_argument("--seed", type=int, default=0, help="default: 2 at 50 000 rows (config 2), else 4 (config 4)")
-    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "bf16x3", "bf16x4", "fp32", "f16f8"])
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "bf16x3", "fp32", "f16f8"])
     ap.add_argument("--sample-rows", type=int, default=64)
     args = ap.parse_args()
     n, length, k = args.rows, args.length, args.k

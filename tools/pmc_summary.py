@@ -11,7 +11,7 @@ import bench  # noqa: E402  (stdlib + numpy only at import time)
 
 out_dir, prec = sys.argv[1], sys.argv[2]
 extra = sys.argv[3:]  # the extra bench.py arguments the passes ran with (tools/profile.sh)
-is_bench = prec in ("fp32", "bf16x3", "bf16x4", "f16x3", "f16f8")  # else: the passes ran another program (tools/pmc_gemm.sh)
+is_bench = prec in ("fp32", "bf16x3", "f16x3", "f16f8")  # else: the passes ran another program (tools/pmc_gemm.sh)
 b_args = bench.parse(["--precision", prec] + extra) if is_bench else None
 rows = (b_args.rows or 50000) if is_bench else 0
 acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
@@ -35,7 +35,8 @@ if is_bench:
     print("# rocprofv3 --pmc passes (separate runs, --kernel-trace only) of: python3 bench.py --steps 2 --warmup 1 "
           "--no-cpu-baseline --precision {} {}".format(prec, " ".join(extra)).rstrip())
     # what bench.py's pmc_traffic() matches before it quotes a number from this file
-    print("# workload: " + bench.workload_key(rows, b_args.length, b_args.k, prec, 1))
+    generic = not (len(b_args.alphabet) == 4 and len(set(b_args.alphabet)) == 4)
+    print("# workload: " + bench.workload_key(rows, b_args.length, b_args.k, prec, 1) + (" alphabet=" + b_args.alphabet if generic else ""))
 else:
     print("# rocprofv3 --pmc passes (separate runs, --kernel-trace only): " + " ".join([prec] + extra))
 print("# kernel_symbols_sha256: " + bench.kernel_symbols_sha256(os.path.join(bench.ROOT, "seekr_amd", "libseekr_hip.so")))
