@@ -727,25 +727,22 @@ constexpr int64_t kGenLdsBins = 16384;
 constexpr int kGenThreads = 1024;  // two workgroups of 16 waves per CU at 62.5 KiB of bins: the flush is a latency-bound loop of
                                    // dword stores, so what counts is how many of them are in flight (256 threads: 1.32 ms for
                                    // 50 000 x 5^6 rows = 0.31 of HBM)
-// Round 5: BinT = uint16_t, two bins to a word (the counting kernel's own trick), whenever no sequence of the set has more
-// than 65 535 windows — the host knows the lengths.  Half the LDS per sequence means FOUR workgroups of eight waves per CU
-// instead of two of sixteen: the same number of threads, but four sequences per CU in different phases — one waiting
-// for its characters (offsets -> bases: two dependent global loads in front of every sequence), one counting, two flushing
-// — where two workgroups left the store stream idle a good part of the time (0.75 -> 0.6x ms per 50 000 x 5^6 rows).
-template <typename OutT, bool LOG2, typename BinT, int THREADS>
-__global__ __launch_bounds__(THREADS) void count_generic_lds_kernel(const unsigned char* __restrict__ bases,
+// (Round 5 measured 16-bit bins, two to a word, with four 512-thread workgroups per CU instead of two of 1 024: 1.16 ms against
+// 0.76 ms — the sub-dword LDS reads and writes of the flush cost more than the halved footprint buys;
+// profiles/r5_generic_width_arms.log.  Not kept.)
+template <typename OutT, bool LOG2>
+__global__ __launch_bounds__(kGenThreads) void count_generic_lds_kernel(const unsigned char* __restrict__ bases,
                                                                   const int64_t* __restrict__ offsets, int64_t n_seqs, int k,
                                                                   int alen, uint32_t nbins, GenericLut lut,
                                                                   OutT* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) uint32_t glds[];
-    constexpr bool PACKED = sizeof(BinT) == 2;
-    const uint32_t words_pad = PACKED ? (((nbins + 1u) >> 1) + 3u) & ~3u : (nbins + 3u) & ~3u;
-    BinT* bins = reinterpret_cast<BinT*>(glds);                             // [nbins], PACKED: two to a word
+    const uint32_t words_pad = (nbins + 3u) & ~3u;
+    uint32_t* bins = glds;                                                 // [nbins]
     float* tab = reinterpret_cast<float*>(glds + words_pad);               // [16]
     int8_t* lutb = reinterpret_cast<int8_t*>(glds + words_pad + kTabSize);  // [256]
     int8_t* codes = lutb + 256;                                            // [kGenChunk + 64]
     const int tid = threadIdx.x;
-    for (uint32_t b = tid; b < words_pad; b += THREADS) glds[b] = 0;
+    for (uint32_t b = tid; b < words_pad; b += kGenThreads) glds[b] = 0;
     if (tid < 256) lutb[tid] = lut.code[tid];
     __syncthreads();
     for (int64_t s = blockIdx.x; s < n_seqs; s += gridDim.x) {
@@ -762,10 +759,10 @@ __global__ __launch_bounds__(THREADS) void count_generic_lds_kernel(const unsign
                           // no chunk, hence no other barrier in between; found by the differential fuzzer)
         for (int64_t c0 = 0; c0 < W; c0 += kGenChunk) {
             const int64_t n_char = std::min<int64_t>(len - c0, kGenChunk + k - 1);
-            for (int64_t i = tid; i < n_char; i += THREADS) codes[i] = lutb[seq[c0 + i]];
+            for (int64_t i = tid; i < n_char; i += kGenThreads) codes[i] = lutb[seq[c0 + i]];
             __syncthreads();
             const int64_t n_win = std::min<int64_t>(W - c0, kGenChunk);
-            for (int64_t w = tid; w < n_win; w += THREADS) {
+            for (int64_t w = tid; w < n_win; w += kGenThreads) {
                 uint32_t idx = 0;
                 int bad = 0;
                 for (int p = 0; p < k; p++) {
@@ -773,12 +770,7 @@ __global__ __launch_bounds__(THREADS) void count_generic_lds_kernel(const unsign
                     bad |= c;  // the sign bit survives: any letter outside the alphabet
                     idx = idx * (uint32_t)alen + (uint32_t)(c & 127);
                 }
-                if (bad >= 0) {
-                    if (PACKED)  // no carry into the neighbour: the host chose this form for sets without a sequence of > 65 535 windows
-                        (void)__hip_atomic_fetch_add(&glds[idx >> 1], 1u << ((idx & 1u) * 16u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    else
-                        (void)__hip_atomic_fetch_add(&glds[idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
+                if (bad >= 0) (void)__hip_atomic_fetch_add(&bins[idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             __syncthreads();
         }
@@ -802,7 +794,7 @@ __global__ __launch_bounds__(THREADS) void count_generic_lds_kernel(const unsign
             typedef OutT v4 __attribute__((ext_vector_type(4)));
             const uint32_t head = std::min<uint32_t>(nbins, (4u - (uint32_t)((reinterpret_cast<uintptr_t>(row) >> 2) & 3u)) & 3u);
             const uint32_t groups = (nbins - head) >> 2;
-            for (uint32_t g = tid; g < groups; g += THREADS) {
+            for (uint32_t g = tid; g < groups; g += kGenThreads) {
                 const uint32_t b = head + 4 * g;
                 const uint32_t n0 = bins[b], n1 = bins[b + 1], n2 = bins[b + 2], n3 = bins[b + 3];
                 bins[b] = 0, bins[b + 1] = 0, bins[b + 2] = 0, bins[b + 3] = 0;
@@ -818,7 +810,7 @@ __global__ __launch_bounds__(THREADS) void count_generic_lds_kernel(const unsign
                 }
             }
         } else {
-            for (uint32_t b = tid; b < nbins; b += THREADS) {
+            for (uint32_t b = tid; b < nbins; b += kGenThreads) {
                 const uint32_t n = bins[b];
                 bins[b] = 0;
                 __builtin_nontemporal_store(value_of(n), row + b);
@@ -907,32 +899,21 @@ extern "C" int skr_count_generic_dev(skr_ctx* ctx, const skr_aseqs* a, const cha
     SKR_TRY(skr_activate(ctx));
     if (nbins <= kGenLdsBins && k <= 64 && !ctx->knobs.count_generic_global) {
         // the histogram fits the LDS: one pass, the row write is the only traffic (kernel comment above)
-        int64_t max_len = 0;
-        for (int64_t L : a->h_len) max_len = std::max(max_len, L);
-        const bool packed = max_len - k + 1 <= 65535;  // sixteen-bit bins, two to a word: no bin can overflow
-        const int threads = packed ? 512 : kGenThreads;
-        const size_t words = packed ? (size_t)((((nbins + 1) >> 1) + 3) & ~(int64_t)3) : (size_t)((nbins + 3) & ~(int64_t)3);
-        const size_t lds = words * 4 + kTabSize * 4 + 256 + kGenChunk + 64;
-        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / threads, ((size_t)160 * 1024) / lds));
+        const size_t lds = (size_t)((nbins + 3) & ~(int64_t)3) * 4 + kTabSize * 4 + 256 + kGenChunk + 64;
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / kGenThreads, ((size_t)160 * 1024) / lds));
         const unsigned grid = (unsigned)std::min<int64_t>(n, (int64_t)ctx->num_cu * per_cu);
         SkrProfScope prof(ctx, "count_generic");
-#define SKR_GEN_LAUNCH2(T, LG, B, TH)                                                                                      \
+#define SKR_GEN_LAUNCH(T, LG)                                                                                              \
     do {                                                                                                                   \
-        auto kern = count_generic_lds_kernel<T, LG, B, TH>;                                                                \
+        auto kern = count_generic_lds_kernel<T, LG>;                                                                       \
         SKR_TRY(skr_kernel_lds(ctx, reinterpret_cast<const void*>(kern), lds));                                            \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(TH), lds, ctx->stream, a->d_bases, a->d_off, n, k, alen, (uint32_t)nbins, \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kGenThreads), lds, ctx->stream, a->d_bases, a->d_off, n, k, alen, (uint32_t)nbins, \
                            lut, (T*)out->data);                                                                            \
-    } while (0)
-#define SKR_GEN_LAUNCH(T, LG)                                  \
-    do {                                                       \
-        if (packed) SKR_GEN_LAUNCH2(T, LG, uint16_t, 512);     \
-        else SKR_GEN_LAUNCH2(T, LG, uint32_t, kGenThreads);    \
     } while (0)
         if (out->dtype == SKR_U32) SKR_GEN_LAUNCH(uint32_t, false);
         else if (out->dtype == SKR_F64) SKR_GEN_LAUNCH(double, false);
         else if (log2_pre) SKR_GEN_LAUNCH(float, true);
         else SKR_GEN_LAUNCH(float, false);
-#undef SKR_GEN_LAUNCH2
 #undef SKR_GEN_LAUNCH
         SKR_HIP(hipGetLastError());
         return SKR_OK;

@@ -384,11 +384,10 @@ __global__ __launch_bounds__(256) void operand_fill_kernel(FillArgs a) {
 // memory, where it stays in the L2.  A thread owns the same groups of 8 consecutive columns in every
 // pass, so what it parked (in LDS, or in `y`) in pass 1 is its own later on; without `y` and without
 // LDS the normalisation tail is simply recomputed from x.
-// THREADS: 256, or 1 024 (round 5) for the rows this kernel was slowest on — widths that are not a multiple of 8 and rows
-// too wide for the LDS (k >= 8).  A row is a chain of passes, each ending in a workgroup-wide sum: with four waves a pass
+// THREADS: 256, or 1 024 (round 5) for rows too wide for the LDS (k >= 8: 10.3 -> 9.0 ms per 20 000 x 65 536).  A row is a chain of passes, each ending in a workgroup-wide sum: with four waves a pass
 // is many rounds of a few loads per thread and the chain's latency is the kernel (49 us per 62 KB row at 2 workgroups per
 // CU); sixteen waves put the whole row in flight at once.
-template <typename T, bool IN_LDS, int THREADS = 256, int PRE = 1>
+template <typename T, bool IN_LDS, int THREADS = 256>
 __global__ __launch_bounds__(THREADS) void operand_fill_block_kernel(FillArgs a) {
     extern __shared__ __attribute__((aligned(16))) float rowbuf[];
     constexpr int WAVES = THREADS / 64;
@@ -406,23 +405,8 @@ __global__ __launch_bounds__(THREADS) void operand_fill_block_kernel(FillArgs a)
         __syncthreads();
         return t;
     };
-    // Odd widths staged through the LDS (below): the NEXT row's pieces are requested as soon as this row's have been parked,
-    // and arrive while this row's statistics — a chain of workgroup-wide sums during which the memory system would
-    // otherwise idle — and its stores are under way.  kPre pieces per thread cover the widest row the LDS takes.
     typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-    constexpr int kPre = PRE;  // 4: rows of up to 16 384 cells (the register budget of sixteen waves is 128); 10: up to 40 960
-    const bool staged = !vec && IN_LDS && THREADS == 1024;
     const int64_t n4 = K >> 2;
-    f4u pre[kPre];
-    auto prefetch = [&](int64_t row) {
-        const float* src = a.x + (size_t)row * K;
-#pragma unroll
-        for (int u = 0; u < kPre; u++) {
-            const int64_t i = tid + (int64_t)THREADS * u;
-            if (i < n4) pre[u] = *reinterpret_cast<const f4u*>(src + 4 * i);
-        }
-    };
-    if (staged && (int64_t)blockIdx.x < a.rows) prefetch(blockIdx.x);
     for (int64_t r = blockIdx.x; r < a.rows; r += gridDim.x) {
         const float* xr = a.x + (size_t)r * K;
         float* yr = a.y ? a.y + (size_t)r * K : nullptr;
@@ -455,25 +439,6 @@ __global__ __launch_bounds__(THREADS) void operand_fill_block_kernel(FillArgs a)
             // global_load_dwordx4 is as good as an aligned one), four pieces in flight per thread, and is parked in the
             // LDS; the sums are then taken from the LDS copy in the order they always were (a thread's groups of 8
             // cells, cell by cell): same bits, 8.4 -> 2.x ms per 50 000 x 15 625 (0.14 -> 0.4x of the HBM peak).
-            if (staged) {
-#pragma unroll
-                for (int u = 0; u < kPre; u++) {
-                    const int64_t i = tid + (int64_t)THREADS * u;
-                    if (i < n4) {
-                        const int64_t c = 4 * i;
-                        f4u w;
-                        w[0] = fill_tail(a, pre[u][0], c, any_nan);
-                        w[1] = fill_tail(a, pre[u][1], c + 1, any_nan);
-                        w[2] = fill_tail(a, pre[u][2], c + 2, any_nan);
-                        w[3] = fill_tail(a, pre[u][3], c + 3, any_nan);
-                        if (yr) *reinterpret_cast<f4u*>(yr + c) = w;
-                        *reinterpret_cast<float4*>(rowbuf + c) = make_float4(w[0], w[1], w[2], w[3]);
-                    }
-                    // one piece at a time: left to itself the scheduler hoists the centre / scale loads of all pieces to the
-                    // top (8 registers each, on top of the prefetched row) and the sixteen-wave budget of 128 spills
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else
             for (int64_t i0 = tid; i0 < n4; i0 += 4 * THREADS) {
                 f4u q[4];
 #pragma unroll
@@ -503,7 +468,6 @@ __global__ __launch_bounds__(THREADS) void operand_fill_block_kernel(FillArgs a)
                 rowbuf[c] = v;
             }
             __syncthreads();
-            if (staged && r + gridDim.x < a.rows) prefetch(r + gridDim.x);
             for (int64_t g = tid; g < groups; g += THREADS) {
                 float v8[8];
                 load8(g, v8);
@@ -702,10 +666,12 @@ using vec4h = T __attribute__((ext_vector_type(4)));
 // (0: rows as they are, 1: float32 centre + scale, 2: + the Log2.post tail); anything else stays with the block kernel.
 // The arithmetic per cell is the block kernel's; the row SUMS are taken in another order (16 waves, pieces lane after
 // lane), so mean and std of a row — and with them the last bits of r — are those of this kernel wherever it serves.
-template <typename T, int VPT, int MODE, bool HASY>
-__global__ __launch_bounds__(1024) void operand_fill_rowreg_kernel(FillArgs a) {
-    constexpr int THREADS = 1024, WAVES = 16;
-    constexpr bool PREFETCH = VPT <= 4;
+template <typename T, int VPT, int MODE, bool HASY, int THREADS>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) void operand_fill_rowreg_kernel(FillArgs a) {
+    constexpr int WAVES = THREADS / 64;
+    // 1 024 threads: one workgroup per CU (128 registers a thread), the next row prefetched; 512 threads: two workgroups per
+    // CU, each on its own row and in its own phase — no prefetch needed, the other workgroup fills the waits
+    constexpr bool PREFETCH = THREADS == 1024;
     typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
     __shared__ float red[2][3][WAVES];
     __shared__ float edge[VPT][WAVES];
@@ -728,14 +694,14 @@ __global__ __launch_bounds__(1024) void operand_fill_rowreg_kernel(FillArgs a) {
         phase++;
         if (lane == 0) slot[0][wave] = p0, slot[1][wave] = p1, slot[2][wave] = p2;
         __syncthreads();
-        // every group of 16 lanes folds the 16 partials by itself — one LDS read and four shuffles per quantity (reading all
+        // every group of WAVES lanes folds the WAVES partials by itself — one LDS read and four shuffles per quantity (reading all
         // 48 partials into registers, on top of this row and the next, is what made the kernel spill)
         float t[3];
 #pragma unroll
         for (int q = 0; q < 3; q++) {
-            float x = slot[q][lane & 15];
+            float x = slot[q][lane & (WAVES - 1)];
 #pragma unroll
-            for (int off = 8; off > 0; off >>= 1) {
+            for (int off = WAVES / 2; off > 0; off >>= 1) {
                 const float o = __shfl_xor(x, off, 64);
                 x = is_max ? fmaxf(x, o) : x + o;
             }
@@ -1345,21 +1311,21 @@ int launch_fill(skr_ctx* ctx, const skr_operand* op, const FillArgs& a_in) {
         // workgroup (operand_fill_rowreg_kernel); widths below stay with the wave-per-row kernel and its numpy-ordered
         // sums, everything else with the block kernel (a 65 536-cell row in registers, 64 per thread, spills: measured)
         SkrProfScope prof(ctx, "operand_fill");
-        const unsigned rgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(a.rows, (int64_t)ctx->num_cu * 2));
-#define LAUNCH_ROWREG2(T, V)                                                                                                \
+        // one sixteen-wave workgroup per CU (128 registers a thread) that prefetches its next row; two eight-wave workgroups
+        // per CU without prefetch were slower (4.18 against 3.47 ms: profiles/r5_generic_width_arms.log)
+        const unsigned rgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(a.rows, (int64_t)ctx->num_cu));
+#define LAUNCH_ROWREG(T)                                                                                                    \
     do {                                                                                                                    \
-        if (reg_mode == 0) hipLaunchKernelGGL((operand_fill_rowreg_kernel<T, V, 0, false>), dim3(rgrid), dim3(1024), 0, ctx->stream, a);      \
-        else if (reg_mode == 1 && a.y) hipLaunchKernelGGL((operand_fill_rowreg_kernel<T, V, 1, true>), dim3(rgrid), dim3(1024), 0, ctx->stream, a); \
-        else if (reg_mode == 1) hipLaunchKernelGGL((operand_fill_rowreg_kernel<T, V, 1, false>), dim3(rgrid), dim3(1024), 0, ctx->stream, a); \
-        else if (a.y) hipLaunchKernelGGL((operand_fill_rowreg_kernel<T, V, 2, true>), dim3(rgrid), dim3(1024), 0, ctx->stream, a);             \
-        else hipLaunchKernelGGL((operand_fill_rowreg_kernel<T, V, 2, false>), dim3(rgrid), dim3(1024), 0, ctx->stream, a);                    \
+        if (reg_mode == 0) hipLaunchKernelGGL((operand_fill_rowreg_kernel<T, 4, 0, false, 1024>), dim3(rgrid), dim3(1024), 0, ctx->stream, a);      \
+        else if (reg_mode == 1 && a.y) hipLaunchKernelGGL((operand_fill_rowreg_kernel<T, 4, 1, true, 1024>), dim3(rgrid), dim3(1024), 0, ctx->stream, a); \
+        else if (reg_mode == 1) hipLaunchKernelGGL((operand_fill_rowreg_kernel<T, 4, 1, false, 1024>), dim3(rgrid), dim3(1024), 0, ctx->stream, a); \
+        else if (a.y) hipLaunchKernelGGL((operand_fill_rowreg_kernel<T, 4, 2, true, 1024>), dim3(rgrid), dim3(1024), 0, ctx->stream, a);             \
+        else hipLaunchKernelGGL((operand_fill_rowreg_kernel<T, 4, 2, false, 1024>), dim3(rgrid), dim3(1024), 0, ctx->stream, a);                    \
     } while (0)
-#define LAUNCH_ROWREG(T) LAUNCH_ROWREG2(T, 4)
         if (op->kind == 0) LAUNCH_ROWREG(float);
         else if (op->kind == 1) LAUNCH_ROWREG(__bf16);
         else LAUNCH_ROWREG(_Float16);
 #undef LAUNCH_ROWREG
-#undef LAUNCH_ROWREG2
         SKR_HIP(hipGetLastError());
     } else if (row_floats * 4 >= 32 * 1024) {  // k >= 7: one workgroup per row
         SkrProfScope prof(ctx, "operand_fill");
@@ -1372,12 +1338,6 @@ int launch_fill(skr_ctx* ctx, const skr_operand* op, const FillArgs& a_in) {
     do {                                                                                                          \
         if (wide) {                                                                                               \
             hipLaunchKernelGGL((operand_fill_block_kernel<T, false, 1024>), dim3(wgrid16), dim3(1024), 0, ctx->stream, a); \
-        } else if ((a.cols & 7) != 0 && a.cols <= 16384) {                                                          \
-            SKR_TRY(skr_kernel_lds(ctx, reinterpret_cast<const void*>(operand_fill_block_kernel<T, true, 1024, 4>), blds)); \
-            hipLaunchKernelGGL((operand_fill_block_kernel<T, true, 1024, 4>), dim3(wgrid16), dim3(1024), blds, ctx->stream, a); \
-        } else if ((a.cols & 7) != 0) {                                                                            \
-            SKR_TRY(skr_kernel_lds(ctx, reinterpret_cast<const void*>(operand_fill_block_kernel<T, true, 1024, 10>), blds)); \
-            hipLaunchKernelGGL((operand_fill_block_kernel<T, true, 1024, 10>), dim3(wgrid16), dim3(1024), blds, ctx->stream, a); \
         } else {                                                                                                  \
             SKR_TRY(skr_kernel_lds(ctx, reinterpret_cast<const void*>(operand_fill_block_kernel<T, true>), blds)); \
             hipLaunchKernelGGL((operand_fill_block_kernel<T, true>), dim3(wgrid), dim3(256), blds, ctx->stream, a); \
