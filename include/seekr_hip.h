@@ -480,6 +480,20 @@ int skr_comm_wait(skr_ctx* ctx, int64_t ticket);
 int skr_comm_allreduce_f64(skr_ctx* ctx, double* values, int n, int op);
 
 
+/* One host process, several GPUs (SEEKR_DEVICES with SEEKR_TRANSPORT=peer, or when RCCL cannot be set up): rows move
+ * between two ctxs of the SAME process by a peer copy over xGMI on the receiving ctx's communication stream — no RCCL, no
+ * CU taken from the contraction.  Ordering is by events either ctx's streams may wait for; the host threads hand each other
+ * the handles in memory.  skr_event_record: an event at the current end of the ctx's compute (0) or communication (1)
+ * stream; skr_event_wait: that stream of `ctx` waits for an event of ANY ctx of this process; skr_peer_copy_rows: enqueued
+ * on dst's ctx's communication stream (direct peer access is switched on for the pair where the hardware offers it).
+ * The receiver's sequence: skr_event_wait(dst ctx, 1, source's "rows are ready" event); skr_peer_copy_rows;
+ * skr_event_record(dst ctx, 1) -> what the receiver's compute stream (and, before it overwrites the rows, the source) waits for. */
+typedef struct skr_event skr_event;
+int skr_event_record(skr_ctx* ctx, int on_comm_stream, skr_event** out);
+int skr_event_wait(skr_ctx* ctx, int on_comm_stream, const skr_event* ev);
+int skr_event_free(skr_event* ev);
+int skr_peer_copy_rows(skr_mat* dst, int64_t drow0, const skr_mat* src, int64_t srow0, int64_t nrows);
+
 /* ---------------------------------------------------------------- diagnostics ------------- */
 /* NOT part of libseekr_hip.so.  A second library, libseekr_hip_diag.so (python -m seekr_amd.build --diag: the same
  * sources with -DSEEKR_DIAG), additionally holds a build of the split-fp16 contraction whose workgroups stamp

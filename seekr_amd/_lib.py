@@ -127,6 +127,10 @@ SIGNATURES = {
     "skr_csv_values": (_int, [_p, _p]),
     "skr_csv_labels": (_int, [_p, _int, C.c_char_p, _i64, C.POINTER(_i64)]),
     "skr_csv_free": (_int, [_p]),
+    "skr_event_record": (_int, [_p, _int, C.POINTER(_p)]),
+    "skr_event_wait": (_int, [_p, _int, _p]),
+    "skr_event_free": (_int, [_p]),
+    "skr_peer_copy_rows": (_int, [_p, _i64, _p, _i64, _i64]),
     "skr_comm_unique_id": (_int, [C.c_char_p]),
     "skr_comm_init": (_int, [_p, _int, _int, C.c_char_p]),
     "skr_comm_destroy": (_int, [_p]),
@@ -921,6 +925,35 @@ def load_csv_labelled(path, threads=0):
         return values, labels[0], labels[1]
     finally:
         lib().skr_csv_free(handle)
+
+
+# ----------------------------------------------------------------------------- peer copies --
+class Event:
+    """A point in a ctx's compute or communication stream that any ctx of this process can wait for (skr_event)."""
+
+    def __init__(self, ctx, comm=False):
+        self._h = _p()
+        check(lib().skr_event_record(ctx._h, 1 if comm else 0, C.byref(self._h)))
+
+    def wait_on(self, ctx, comm=False):
+        """ctx's compute (or communication) stream waits for this event."""
+        check(lib().skr_event_wait(ctx._h, 1 if comm else 0, self._h))
+
+    def free(self):
+        if getattr(self, "_h", None) and not _shutdown:
+            lib().skr_event_free(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def peer_copy_rows(dst, drow0, src, srow0, nrows):
+    """Rows of `src` (a Matrix of any Context of this process) -> rows of `dst`, on dst's ctx's communication stream."""
+    check(lib().skr_peer_copy_rows(dst._h, int(drow0), src._h, int(srow0), int(nrows)))
 
 
 # ----------------------------------------------------------------------------- RCCL --------

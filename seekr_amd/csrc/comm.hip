@@ -293,3 +293,76 @@ extern "C" int skr_comm_barrier(skr_ctx* ctx) {
     SKR_TRY(skr_ctx_sync(ctx));
     return skr_comm_allreduce_f64(ctx, &v, 1, 0);
 }
+
+
+// ---------------------------------------------------------------------------------------
+// One host process, several GPUs (seekr_amd/multi.py): rows can move between two ctxs of the SAME process without RCCL —
+// a peer copy over xGMI on the receiving ctx's communication stream (SDMA: no CU is taken from the contraction), ordered by
+// events that either ctx's streams may wait for.  The host threads hand each other the handles (matrix, event) in memory.
+struct skr_event {
+    hipEvent_t ev = nullptr;
+    int device = 0;
+};
+
+// An event at the current end of the ctx's compute (on_comm_stream == 0) or communication stream.
+extern "C" int skr_event_record(skr_ctx* ctx, int on_comm_stream, skr_event** out) {
+    SKR_REQUIRE(ctx && out, "NULL argument");
+    *out = nullptr;
+    SKR_TRY(skr_activate(ctx));
+    skr_event* e = new skr_event();
+    e->device = ctx->device;
+    hipError_t rc = hipEventCreateWithFlags(&e->ev, hipEventDisableTiming);
+    if (rc == hipSuccess) rc = hipEventRecord(e->ev, on_comm_stream ? ctx->comm_stream : ctx->stream);
+    if (rc != hipSuccess) {
+        if (e->ev) (void)hipEventDestroy(e->ev);
+        delete e;
+        return skr_set_error(SKR_ERR_HIP, "recording an event failed: %s", hipGetErrorString(rc));
+    }
+    *out = e;
+    return SKR_OK;
+}
+
+// The ctx's compute (0) or communication (1) stream waits for the event — which may have been recorded on another ctx,
+// i.e. another GPU of this process.
+extern "C" int skr_event_wait(skr_ctx* ctx, int on_comm_stream, const skr_event* ev) {
+    SKR_REQUIRE(ctx && ev && ev->ev, "NULL argument");
+    SKR_TRY(skr_activate(ctx));
+    SKR_HIP(hipStreamWaitEvent(on_comm_stream ? ctx->comm_stream : ctx->stream, ev->ev, 0));
+    return SKR_OK;
+}
+
+extern "C" int skr_event_free(skr_event* ev) {
+    if (!ev) return SKR_OK;
+    (void)hipSetDevice(ev->device);
+    if (ev->ev) (void)hipEventDestroy(ev->ev);  // an event still being waited for is released when it completes
+    delete ev;
+    return SKR_OK;
+}
+
+// Rows [srow0, srow0 + nrows) of `src` (a matrix of ANOTHER ctx of this process, or of the same one) -> rows drow0.. of
+// `dst`, enqueued on dst's ctx's communication stream.  Direct peer access is switched on for the pair on first use where
+// the hardware offers it (xGMI); the copy itself works either way.  The caller orders it: skr_event_wait(dst ctx, 1, the
+// source's "rows are ready" event) before, skr_event_record(dst ctx, 1) after.
+extern "C" int skr_peer_copy_rows(skr_mat* dst, int64_t drow0, const skr_mat* src, int64_t srow0, int64_t nrows) {
+    SKR_REQUIRE(dst && src, "NULL argument");
+    SKR_REQUIRE((size_t)dst->cols * dst->elem() == (size_t)src->cols * src->elem(), "rows of different byte length");
+    SKR_REQUIRE(drow0 >= 0 && srow0 >= 0 && nrows >= 0 && drow0 + nrows <= dst->rows && srow0 + nrows <= src->rows,
+                "row range outside the matrices");
+    skr_ctx* dctx = dst->ctx;
+    SKR_TRY(skr_activate(dctx));
+    if (nrows == 0) return SKR_OK;
+    const size_t rb = (size_t)dst->cols * dst->elem();
+    const int sdev = src->ctx->device, ddev = dctx->device;
+    if (sdev != ddev) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, ddev, sdev) == hipSuccess && can) {
+            const hipError_t e = hipDeviceEnablePeerAccess(sdev, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();  // staged copies still work
+            else (void)hipGetLastError();
+        }
+    }
+    SkrProfScope prof(dctx, nrows <= 1 ? "comm_vec" : "comm_xfer", dctx->comm_stream);
+    SKR_HIP(hipMemcpyPeerAsync((char*)dst->data + (size_t)drow0 * rb, ddev, (const char*)src->data + (size_t)srow0 * rb, sdev,
+                               (size_t)nrows * rb, dctx->comm_stream));
+    return SKR_OK;
+}

@@ -202,6 +202,8 @@ struct skr_operand {
     skr_ctx* ctx = nullptr;
     int64_t rows = 0, cols = 0, kt = 0;
     int precision = SKR_PREC_FP32;
+    int created_precision = SKR_PREC_FP32;  // what skr_operand_create was asked for (a fill may route an f16f8 operand back to f16x3)
+    bool x8_routed_back = false;  // ... and did so for the rows it saw LAST: the next fill tries the f16f8 layout again (not after skr_operand_adopt_layout: an explicit choice)
     int kind = 0;  // 0 = float32 padded, 1 = bf16 halves, 2 = fp16 halves
     void* data = nullptr;
     float scale = 1.f;        // stored values = z * scale (fp16 halves only; a function of cols)

@@ -745,9 +745,30 @@ __global__ __launch_bounds__(kGenThreads) void count_generic_lds_kernel(const un
     for (uint32_t b = tid; b < words_pad; b += kGenThreads) glds[b] = 0;
     if (tid < 256) lutb[tid] = lut.code[tid];
     __syncthreads();
+    // Round 5: the characters of the NEXT sequence's first chunk are requested before this sequence's flush (offsets -> bases:
+    // two dependent global loads that used to stand in front of every sequence, ~3 of the 7.7 us a 2 kb sequence took) and
+    // sit in kGenPre registers per thread until the next turn of the loop translates them.
+    constexpr int kGenPre = (kGenChunk + 64 + kGenThreads - 1) / kGenThreads;
+    unsigned char pre[kGenPre];
+    int64_t pre_off = 0, pre_len = 0;
+    auto prefetch = [&](int64_t sn) {
+        if (sn >= n_seqs) return;
+        pre_off = offsets[sn];
+        pre_len = offsets[sn + 1] - pre_off;
+        const int64_t n_first = std::min<int64_t>(pre_len, kGenChunk + k - 1);
+#pragma unroll
+        for (int j = 0; j < kGenPre; j++) {
+            const int64_t i = tid + (int64_t)kGenThreads * j;
+            pre[j] = i < n_first && i < kGenChunk + 64 ? bases[pre_off + i] : 0;
+        }
+    };
+    prefetch(blockIdx.x);
     for (int64_t s = blockIdx.x; s < n_seqs; s += gridDim.x) {
-        const unsigned char* seq = bases + offsets[s];
-        const int64_t len = offsets[s + 1] - offsets[s];
+        const unsigned char* seq = bases + pre_off;
+        const int64_t len = pre_len;
+        unsigned char mine[kGenPre];
+#pragma unroll
+        for (int j = 0; j < kGenPre; j++) mine[j] = pre[j];
         const int64_t W = len - k + 1;  // windows, counting every character (kmer_counts.py:143-144)
         const double inc = W > 0 ? 1000.0 / (double)W : 0.0;
         if (!std::is_same<OutT, uint32_t>::value && sizeof(OutT) == 4 && tid < kTabSize) {
@@ -758,8 +779,16 @@ __global__ __launch_bounds__(kGenThreads) void count_generic_lds_kernel(const un
         __syncthreads();  // the table is read by every wave's flush — also for a sequence without a single window (W <= 0:
                           // no chunk, hence no other barrier in between; found by the differential fuzzer)
         for (int64_t c0 = 0; c0 < W; c0 += kGenChunk) {
-            const int64_t n_char = std::min<int64_t>(len - c0, kGenChunk + k - 1);
-            for (int64_t i = tid; i < n_char; i += kGenThreads) codes[i] = lutb[seq[c0 + i]];
+            const int64_t n_char = std::min<int64_t>(std::min<int64_t>(len - c0, kGenChunk + k - 1), kGenChunk + 64);
+            if (c0 == 0) {
+#pragma unroll
+                for (int j = 0; j < kGenPre; j++) {
+                    const int64_t i = tid + (int64_t)kGenThreads * j;
+                    if (i < n_char) codes[i] = lutb[mine[j]];
+                }
+            } else {
+                for (int64_t i = tid; i < n_char; i += kGenThreads) codes[i] = lutb[seq[c0 + i]];
+            }
             __syncthreads();
             const int64_t n_win = std::min<int64_t>(W - c0, kGenChunk);
             for (int64_t w = tid; w < n_win; w += kGenThreads) {
@@ -774,6 +803,7 @@ __global__ __launch_bounds__(kGenThreads) void count_generic_lds_kernel(const un
             }
             __syncthreads();
         }
+        prefetch(s + gridDim.x);  // in flight during the flush below
         OutT* row = out + (size_t)s * nbins;
         auto value_of = [&](uint32_t n) -> OutT {
             if (std::is_same<OutT, uint32_t>::value) return (OutT)n;

@@ -1393,6 +1393,7 @@ extern "C" int skr_operand_create(skr_ctx* ctx, int64_t rows, int64_t cols, int 
     op->cols = cols;
     op->kt = (cols + 31) / 32;
     op->precision = precision;
+    op->created_precision = precision;
     // bf16 halves: the split error averages out like 1/sqrt(K): at K >= 1024 (k >= 5) it is inside the parity bar
     // (|dr| <= 2e-6 + 1e-5 |r|); below that the exact-product fp32 MFMA is used.  fp16 halves keep 22 bits of z, so
     // the dropped lo*lo term is bounded by 2^-21 sum|z_i z_j| / K <= 5e-7 whatever K is: the split kernel is used
@@ -1508,6 +1509,13 @@ extern "C" int skr_operand_fill(skr_ctx* ctx, const skr_mat* x, const skr_mat* c
     SKR_HIP(hipMemsetAsync(ctx->d_flags + 3, 0, 16, ctx->stream));  // [6]: neighbouring cells repeat each other (f16f8 only)
     SKR_HIP(hipMemsetAsync(ctx->d_flags + 24, 0, 16, ctx->stream));  // [24..27]: f16f8's maxima of the row means (float bits)
     op->coherent = false;
+    // an operand created for the opt-in f16f8 layout whose EARLIER contents were routed back to the three-product split
+    // tries its own layout again on new data (the downgrade used to stick for the life of the operand)
+    if (op->owner && op->x8_routed_back && op->created_precision == SKR_PREC_F16F8 && op->kind == 2) {
+        op->kind = 3;
+        op->precision = SKR_PREC_F16F8;
+    }
+    op->x8_routed_back = false;
     if (op->kind == 3) {
         // the H / X line layout is written by the register kernels alone: float32 vectors computed on the device (or none),
         // rows standardised here (their values are then bounded by sqrt(K): the fp8 copies cannot overflow)
@@ -1515,6 +1523,7 @@ extern "C" int skr_operand_fill(skr_ctx* ctx, const skr_mat* x, const skr_mat* c
         if (!reg_path || !a.row_standardize) {
             op->kind = 2;
             op->precision = SKR_PREC_F16X3;
+            op->x8_routed_back = true;
         }
     }
     SKR_TRY(launch_fill(ctx, op, a));
@@ -1574,6 +1583,7 @@ extern "C" int skr_operand_fill(skr_ctx* ctx, const skr_mat* x, const skr_mat* c
                                                           "of the operand it belongs to: fill whole operands with SKR_PREC_F16F8");
             op->kind = 2;
             op->precision = SKR_PREC_F16X3;
+            op->x8_routed_back = true;
             FillArgs b = a;
             if (a.y) {  // the normalised counts are already in y: refill from them as they are
                 b.x = a.y;
@@ -1637,6 +1647,7 @@ extern "C" int skr_operand_adopt_layout(skr_operand* op, const skr_operand* like
     op->scale = like->scale;
     op->precision = like->precision;
     op->coherent = like->coherent;
+    op->x8_routed_back = false;
     op->diag_valid = false;
     for (int q = 0; q < 3; q++) op->x8_stat[q] = like->x8_stat[q];  // a receive buffer: the caller has made these global
     op->x8_root = like->x8_root;

@@ -252,8 +252,9 @@ class RcclComm:
                                              for s, dst, r, rows, src in shifts])
 
     def allgather_rows(self, shard, full, bounds):
-        """shard: this rank's Operand; full: an Operand of bounds[-1] rows; returns a ticket."""
-        return _lib.comm_allgather_rows(self.ctx, shard.as_matrix(), full.as_matrix(), bounds)
+        """shard: this rank's Operand (or Matrix); full: an Operand (Matrix) of bounds[-1] rows; returns a ticket."""
+        as_mat = lambda m: m.as_matrix() if hasattr(m, "as_matrix") else m  # noqa: E731
+        return _lib.comm_allgather_rows(self.ctx, as_mat(shard), as_mat(full), bounds)
 
     def wait(self, ticket):
         _lib.comm_wait(self.ctx, ticket)

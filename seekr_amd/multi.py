@@ -18,6 +18,9 @@ on the number of GPUs: it is the one-GPU result bit for bit, as the counts and t
 The same stripe loop serves ONE GPU when r would not fit its memory (pearson.py:41 is limited by host RAM only) or goes
 straight to a file: `pearson()` picks it by itself, SEEKR_PEARSON_STRIPE_ROWS forces a stripe height (tests).
 
+Device data moves over RCCL (SEEKR_TRANSPORT=rccl) or as peer copies pulled by the receiver and ordered by events
+(SEEKR_TRANSPORT=peer: PeerComm — no RCCL, the SDMA engines); unset = RCCL, and peer copies when RCCL cannot be set up.
+
 Errors keep the reference's types: what one GPU's range raises (a sequence of length k - 1: ZeroDivisionError,
 kmer_counts.py:144) is agreed on by all GPU threads before any of them enters a collective, every thread leaves the job,
 and the caller sees that one exception, once.
@@ -119,6 +122,97 @@ class GroupRcclComm(HostCollectives, RcclComm):
         HostCollectives.barrier(self)
 
 
+class PeerComm(HostCollectives):
+    """The communicator of the in-process group WITHOUT RCCL (SEEKR_TRANSPORT=peer, or RCCL could not be set up): every
+    transfer is a peer copy over xGMI PULLED by the receiver on its own communication stream (skr_peer_copy_rows:
+    hipMemcpyPeerAsync — the SDMA engines, no CU taken from the contraction), ordered by events (skr_event_*).  The sender's
+    half of an exchange is a note in the receiver's mailbox: (the matrix, an event behind the kernels that produced its
+    rows).  Same interface as RcclComm where seekr_amd.multi / distributed use it: send_vec / recv_vec (the column-sum
+    chain), allgather_rows (the prepared operands), wait, allreduce / barrier (host, HostCollectives)."""
+    SEND_TICKET_OPTIONAL = True
+
+    def __init__(self, group, ctx, rank, size):
+        self.group, self.ctx, self.rank, self.size = group, ctx, rank, size
+        self._tickets, self._next, self._unacked = {}, 0, []
+        self._chain_note = "peer copies (one process drives all GPUs)"
+
+    def _post(self, dst, mat, rows, ack):
+        self.group.mail[(self.rank, dst)].put((mat, rows, _lib.Event(self.ctx, comm=False), ack))
+        if ack:
+            self._unacked.append(dst)
+
+    def _pull(self, src, dst_mat, drow0):
+        """The next note of `src`: its rows into dst_mat[drow0:] on my communication stream; returns the rows copied."""
+        try:
+            mat, rows, ready, ack = self.group.mail[(src, self.rank)].get(timeout=self.group.mail_timeout)
+        except queue.Empty:
+            raise GroupBroken("GPU thread {} waited {} s for rows of GPU thread {}".format(self.rank, self.group.mail_timeout, src)) from None
+        ready.wait_on(self.ctx, comm=True)
+        _lib.peer_copy_rows(dst_mat, drow0, mat, 0, rows)
+        if ack:  # the sender may want to overwrite its rows: tell it where my copy ends
+            self.group.acks[(src, self.rank)].put(_lib.Event(self.ctx, comm=True))
+        return rows
+
+    def _drain_acks(self):
+        """My compute stream waits for every peer's copy of the vectors I sent (they may be overwritten after this)."""
+        for dst in self._unacked:
+            try:
+                done = self.group.acks[(self.rank, dst)].get(timeout=self.group.mail_timeout)
+            except queue.Empty:
+                raise GroupBroken("GPU thread {} waited {} s for GPU thread {} to fetch a vector".format(self.rank, self.group.mail_timeout, dst)) from None
+            done.wait_on(self.ctx, comm=False)
+        self._unacked = []
+
+    def _ticket(self):
+        self._next += 1
+        self._tickets[self._next] = _lib.Event(self.ctx, comm=True)
+        return self._next
+
+    def send_vec(self, v, dst, want_ticket=True):
+        """The receiver pulls; a ticket, when waited for, makes my compute stream wait for EVERY peer's copy of the vectors
+        sent so far (RcclComm's send ticket, for transfers that run on the receivers' streams).  Without a ticket the
+        acknowledgement is collected at the next ticketed wait or barrier."""
+        self._post(dst, v, 1, ack=True)
+        if not want_ticket:
+            return None
+        self._next += 1
+        self._tickets[self._next] = None  # a send ticket: drain the acknowledgements
+        return self._next
+
+    def recv_vec(self, v, src):
+        self._pull(src, v, 0)
+        self.wait(self._ticket())
+
+    def allgather_rows(self, shard, full, bounds):
+        """shard / full: Operands (their float32-typed storage travels) or Matrices."""
+        s = shard.as_matrix() if hasattr(shard, "as_matrix") else shard
+        f = full.as_matrix() if hasattr(full, "as_matrix") else full
+        for step in range(1, self.size):  # (no acknowledgement: the shards live until the job's closing barrier)
+            self._post((self.rank - step) % self.size, s, s.rows, ack=False)
+        if s.rows:  # the own shard: a device copy, behind the kernels that produced it
+            _lib.Event(self.ctx, comm=False).wait_on(self.ctx, comm=True)
+            _lib.peer_copy_rows(f, bounds[self.rank], s, 0, s.rows)
+        for step in range(1, self.size):
+            src = (self.rank + step) % self.size
+            got = self._pull(src, f, bounds[src])
+            assert got == bounds[src + 1] - bounds[src]
+        return self._ticket()
+
+    def wait(self, ticket):
+        if ticket is None:
+            return
+        ev = self._tickets.pop(ticket)
+        if ev is None:
+            self._drain_acks()
+        else:
+            ev.wait_on(self.ctx, comm=False)
+
+    def barrier(self):
+        self._drain_acks()
+        self.ctx.sync()
+        HostCollectives.barrier(self)
+
+
 class Rank:
     """What a job sees of its GPU: ctx, comm, and the agreement primitive."""
 
@@ -147,19 +241,29 @@ class Rank:
 
 def _hip_backend(group, rank):
     ctx = _lib.Context(group.devices[rank])
-    _lib.comm_init(ctx, group.size, rank, group.uid)
-    comm = GroupRcclComm(group, ctx, rank, group.size)
+    size = group.size
+    if group.transport == "rccl":
+        _lib.comm_init(ctx, size, rank, group.uid)
+        comm = GroupRcclComm(group, ctx, rank, size)
+    else:
+        comm = PeerComm(group, ctx, rank, size)
     st = Rank(group, rank, ctx, comm)
 
-    def ring():  # one send/recv round the ring, checked: the first multi-GPU call diagnoses itself instead of hanging later
+    def ring():  # one vector round the ring, checked: the first multi-GPU call diagnoses itself instead of hanging later
         send = ctx.from_numpy(np.full((1, 256), float(rank + 1), np.float32))
         recv = ctx.zeros(1, 256)
-        t = _lib.comm_sendrecv(ctx, send, 0, 1, (rank + 1) % group.size, recv, 0, 1, (rank - 1) % group.size)
-        _lib.comm_wait(ctx, t)
-        got, want = recv.to_numpy(), float((rank - 1) % group.size + 1)
+        if group.transport == "rccl":
+            t = _lib.comm_sendrecv(ctx, send, 0, 1, (rank + 1) % size, recv, 0, 1, (rank - 1) % size)
+            _lib.comm_wait(ctx, t)
+        else:
+            t = comm.send_vec(send, (rank + 1) % size)
+            comm.recv_vec(recv, (rank - 1) % size)
+            comm.wait(t)
+        got, want = recv.to_numpy(), float((rank - 1) % size + 1)
         if not (got == want).all():
-            raise _lib.SeekrHipError("GPU {} (rank {} of {}): the RCCL ring self-test delivered {} instead of {}".format(
-                group.devices[rank], rank, group.size, got[0, 0], want))
+            raise _lib.SeekrHipError("GPU {} (rank {} of {}): the {} ring self-test delivered {} instead of {}".format(
+                group.devices[rank], rank, size, group.transport, got[0, 0], want))
+        comm.barrier()  # (peer transport: `send` is read by the neighbour's copy until here)
     st.phase(ring)
     return st
 
@@ -169,9 +273,13 @@ class DeviceGroup:
     executes fn(rank_state, spec) on every thread and returns the results in rank order; the lowest rank's exception, if
     any, is re-raised in the caller."""
 
-    def __init__(self, devices, backend=None, uid=None):
+    def __init__(self, devices, backend=None, uid=None, transport="rccl"):
         self.devices, self.size = list(devices), len(devices)
-        self.uid = uid
+        self.uid, self.transport = uid, transport
+        # peer transport: one mailbox per ordered pair of GPU threads (the sender's half of a transfer is a note in it)
+        self.mail = {(a, b): queue.Queue() for a in range(self.size) for b in range(self.size) if a != b}
+        self.acks = {(a, b): queue.Queue() for a in range(self.size) for b in range(self.size) if a != b}  # (sender, receiver)
+        self.mail_timeout = 120.0
         self.broken = False
         self._backend = backend or _hip_backend
         self._barrier = threading.Barrier(self.size)
@@ -259,17 +367,38 @@ _group = None
 _group_lock = threading.Lock()
 
 
+def requested_transport():
+    """SEEKR_TRANSPORT: 'rccl' (ncclSend / ncclRecv between the GPU threads: what the north_star names), 'peer' (peer copies
+    over xGMI pulled by the receiver, no RCCL: PeerComm), or unset = 'auto': RCCL, and if it cannot be set up — the library
+    is missing, ncclCommInitRank or the ring self-test fails — peer copies, with one line on stderr saying so."""
+    t = os.environ.get("SEEKR_TRANSPORT", "auto").strip().lower() or "auto"
+    if t not in ("auto", "rccl", "peer"):
+        raise ValueError("SEEKR_TRANSPORT must be rccl, peer or auto, got {!r}".format(t))
+    return t
+
+
 def group_for(devices):
-    """The process-wide DeviceGroup for this device list (created on first use, replaced when the list changes or the
-    group broke)."""
+    """The process-wide DeviceGroup for this device list (created on first use, replaced when the list, the transport
+    asked for changes or the group broke)."""
     global _group
+    want = requested_transport()
     with _group_lock:
-        if _group is not None and (_group.broken or _group.devices != list(devices)):
+        if _group is not None and (_group.broken or _group.devices != list(devices) or (want != "auto" and _group.transport != want)):
             _group.close()
             _group = None
         if _group is None:
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's peer-to-peer set-up needs it here
-            _group = DeviceGroup(devices, uid=_lib.comm_unique_id())
+            if want in ("auto", "rccl"):
+                try:
+                    _group = DeviceGroup(devices, uid=_lib.comm_unique_id(), transport="rccl")
+                except Exception as e:  # noqa: BLE001
+                    if want == "rccl":
+                        raise
+                    import sys
+                    print("seekr_amd: RCCL could not be set up between the GPUs of SEEKR_DEVICES ({}: {}); using peer copies "
+                          "(SEEKR_TRANSPORT=peer)".format(type(e).__name__, e), file=sys.stderr)
+            if _group is None:
+                _group = DeviceGroup(devices, transport="peer")
         return _group
 
 
@@ -325,7 +454,7 @@ class ApiHipEngine(HipEngine):
         if comm.size == 1:
             return z
         full = self.ctx.empty(bounds[-1], z.cols, z.dtype)
-        comm.wait(_lib.comm_allgather_rows(self.ctx, z, full, bounds))
+        comm.wait(comm.allgather_rows(z, full, bounds))
         return full
 
     def gemm_f64(self, a, b, r, K, col0=0, symmetric=False):
@@ -387,6 +516,7 @@ def counts_job(st, spec):
     log2 = "Log2.post" if spec.log2 == "Log2.post" else "Log2.none"
     center, scale, has_nan = sharded_normalize(eng, st.comm, x, n_total, log2, mean, std)
     eng.download(x, spec.out[lo:hi])
+    st.comm.barrier()  # nothing of this job is freed while a peer may still be copying from it (peer transport)
     first = st.rank == 0
     return (eng.vec_to_host(center) if first and spec.mean is True else None,
             eng.vec_to_host(scale) if first and spec.std is True else None, bool(has_nan))
@@ -511,6 +641,7 @@ def pearson_job(st, spec):
         pending = (buf, m, g0, mark)
     if pending is not None:
         spec.sink.put(*pending)
+    st.comm.barrier()  # the operand shards stay alive until every GPU has pulled them (peer transport)
     return None
 
 

@@ -149,6 +149,7 @@ def main():
     with open(path("info.json"), "w") as fh:
         json.dump({"devices": multi.requested_devices(), "group_size": multi._group.size if multi._group else 0,
                    "group_broken": bool(multi._group.broken) if multi._group else None,
+                   "transport": multi._group.transport if multi._group else None,
                    "threads": sorted(t.name for t in multi._group._threads) if multi._group else [],
                    "stripe_rows": multi.forced_stripe_rows()}, fh)
     for name in ("example.fa", "s1.fa", "s2.fa", "big.fa", "blank.fa"):

@@ -101,3 +101,30 @@ def test_ranks_on_one_gpu_behind_the_api(baseline, mock_lib, tmp_path, size, str
     with open(os.path.join(baseline, "info.json")) as fh:
         assert json.load(fh)["group_size"] == 0
     same_outputs(baseline, got)
+
+
+@pytest.mark.parametrize("size,stripe", [(2, 256), (3, None), (8, None)])
+def test_gpu_threads_over_peer_copies(baseline, tmp_path, size, stripe):
+    """SEEKR_TRANSPORT=peer: the in-process group WITHOUT RCCL — every transfer a peer copy pulled by the receiver on its own
+    communication stream, ordered by events (skr_event_*, skr_peer_copy_rows).  No mock here: this is the production
+    transport, its 'peers' all being GPU 0 (a same-device hipMemcpyPeerAsync); what a multi-GPU box adds is xGMI under
+    the same calls.  Every output byte-identical to the one-GPU run."""
+    env = dict(SEEKR_DEVICES=",".join(["0"] * size), SEEKR_TEST_HOOKS=1, SEEKR_TRANSPORT="peer")
+    if stripe:
+        env["SEEKR_PEARSON_STRIPE_ROWS"] = stripe
+    got = run_worker(tmp_path / ("peer%d" % size), **env)
+    with open(os.path.join(got, "info.json")) as fh:
+        info = json.load(fh)
+    assert info["group_size"] == size and info["group_broken"] is False and info["transport"] == "peer"
+    same_outputs(baseline, got)
+
+
+def test_rccl_that_cannot_be_set_up_falls_back_to_peer_copies(baseline, tmp_path):
+    """SEEKR_TRANSPORT unset (auto): RCCL first — here its library cannot be loaded — then peer copies, with one line on
+    stderr; the results are the same bytes."""
+    got = run_worker(tmp_path / "fallback", scale="small", SEEKR_DEVICES="0,0", SEEKR_TEST_HOOKS=1,
+                     SEEKR_RCCL_LIB=str(tmp_path / "no_such_librccl.so"))
+    with open(os.path.join(got, "info.json")) as fh:
+        info = json.load(fh)
+    assert info["transport"] == "peer" and info["group_size"] == 2 and info["group_broken"] is False
+    same_outputs(run_worker(tmp_path / "small_ref", scale="small"), got)
