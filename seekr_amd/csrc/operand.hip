@@ -6,6 +6,7 @@
 #include <cmath>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -655,6 +656,32 @@ __global__ __launch_bounds__(THREADS) void operand_fill_block_kernel(FillArgs a)
 template <typename T>
 using vec4h = T __attribute__((ext_vector_type(4)));
 
+// Wave-wide sums and maxima on the DPP network instead of ds_bpermute (what __shfl_xor compiles to: an LDS operation a
+// step, 6 dependent steps a sum — sixteen waves folding three quantities five times a row kept the LDS pipe busy for
+// ~1 us per fold).  Four DPP steps leave every lane of a 16-lane row with its row's total; the four row totals are read
+// with v_readlane and added.  (Used by operand_fill_rowreg_kernel only: the other fills keep the butterfly whose
+// summation order their results were pinned with.)
+template <bool IS_MAX, int CTRL>
+__device__ __forceinline__ float dpp_step_c(float v) {
+    const float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+    return IS_MAX ? fmaxf(v, o) : v + o;
+}
+template <bool IS_MAX>
+__device__ __forceinline__ float row16_all(float v) {  // every lane: the reduction over its row of 16 lanes
+    v = dpp_step_c<IS_MAX, 0xB1>(v);   // quad_perm [1,0,3,2]
+    v = dpp_step_c<IS_MAX, 0x4E>(v);   // quad_perm [2,3,0,1]
+    v = dpp_step_c<IS_MAX, 0x141>(v);  // row_half_mirror
+    v = dpp_step_c<IS_MAX, 0x140>(v);  // row_mirror
+    return v;
+}
+template <bool IS_MAX>
+__device__ __forceinline__ float wave64_all(float v) {  // every lane: the reduction over the wave
+    v = row16_all<IS_MAX>(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return IS_MAX ? fmaxf(fmaxf(r0, r1), fmaxf(r2, r3)) : (r0 + r1) + (r2 + r3);
+}
+
 // ---- round 5: ANY width up to VPT * 4 096 columns, the row in the registers of a sixteen-wave workgroup ------------------
 // The block kernel above parks a row in the LDS (or re-reads it from the L2) and walks it once per statistic, four waves a
 // row: a chain of passes during which nothing of the next row is on its way — 26 us per 62 KB row, 1.1 TB/s on 5^6 columns,
@@ -679,89 +706,93 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // (32-bit column arithmetic: the widest row this kernel takes has 65 536 cells)
     const int K = (int)a.cols, Kp = (int)a.kt * 32;
-    const int n4 = K >> 2, n4p = Kp >> 2;  // whole pieces inside the row; pieces of the padded operand row
+    const int n4p = Kp >> 2;  // pieces of the padded operand row
     const float kf = (float)K;
     bool any_nan = false, overflow = false, outlier = false, coherent = false;
     int phase = 0;
     // up to three sums (or maxima) over the workgroup with one barrier: the partials of consecutive calls alternate slots
-    auto reduce3 = [&](float& p0, float& p1, float& p2, bool is_max) {
-        if (is_max) {
-            p0 = wave_max(p0), p1 = wave_max(p1), p2 = wave_max(p2);
-        } else {
-            p0 = wave_sum(p0), p1 = wave_sum(p1), p2 = wave_sum(p2);
-        }
+    auto reduce3 = [&](float& p0, float& p1, float& p2, auto m0, auto m1, auto m2) {  // m*: std::true_type = maximum, false_type = sum
+        constexpr bool M0 = decltype(m0)::value, M1 = decltype(m1)::value, M2 = decltype(m2)::value;
+        p0 = wave64_all<M0>(p0), p1 = wave64_all<M1>(p1), p2 = wave64_all<M2>(p2);
         float(*slot)[WAVES] = red[phase & 1];
         phase++;
         if (lane == 0) slot[0][wave] = p0, slot[1][wave] = p1, slot[2][wave] = p2;
-        __syncthreads();
-        // every group of WAVES lanes folds the WAVES partials by itself — one LDS read and four shuffles per quantity (reading all
+        // A barrier for the LDS only.  __syncthreads() is a workgroup-scope release + acquire around s_barrier, which on
+        // gfx9 means s_waitcnt vmcnt(0): every wave would sit at the FIRST barrier of a row until the next row's prefetch
+        // — issued a few instructions earlier — had landed, and at every later one until its stores had drained (~1 us a
+        // barrier: the fixed 5 us per row this kernel had).  The partials only travel through the LDS.
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // every row of 16 lanes folds the 16 partials by itself — one LDS read and four DPP steps per quantity (reading all
         // 48 partials into registers, on top of this row and the next, is what made the kernel spill)
-        float t[3];
+        static_assert(WAVES == 16, "a row of 16 lanes folds the 16 partials");
+        p0 = row16_all<M0>(slot[0][lane & 15]);
+        p1 = row16_all<M1>(slot[1][lane & 15]);
+        p2 = row16_all<M2>(slot[2][lane & 15]);
+    };
+    const std::true_type kMax;
+    const std::false_type kSum;
+    // rounding direction of the hi half of each of this thread's VPT * 4 cells, one bit per cell (a hash of the COLUMN: the
+    // same for every row)
+    uint32_t dir = 0;
+    if (sizeof(T) == 2) {
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-            float x = slot[q][lane & (WAVES - 1)];
+        for (int u = 0; u < VPT; u++)
 #pragma unroll
-            for (int off = WAVES / 2; off > 0; off >>= 1) {
-                const float o = __shfl_xor(x, off, 64);
-                x = is_max ? fmaxf(x, o) : x + o;
-            }
-            t[q] = x;
-        }
-        p0 = t[0], p1 = t[1], p2 = t[2];
+            for (int j = 0; j < 4; j++) dir |= (split_flip(4 * (tid + THREADS * u) + j) >> 31) << (u * 4 + j);
+    }
+    static_assert(VPT * 4 <= 32, "one bit per cell in a 32-bit word");
+    // Cells c .. c + 3 of a K-cell float vector WITHOUT a branch: hipcc answers a load inside a branch with s_waitcnt
+    // vmcnt(0) right behind it — the four pieces of a row came in one after the other, each at full latency, and the
+    // "prefetch" of the next row was waited for on the spot (the fixed ~5 us per row this kernel had).  The address is
+    // clamped into the vector (the ragged last piece reads the vector's LAST four cells, pieces past the end likewise) and
+    // the lanes are rotated into place; cells at or past K come back as anything — every user masks them with c + j < K.
+    auto load4 = [&](const float* base, int c) -> f4u {
+        const int cc = c + 3 < K ? c : K - 4;
+        const f4u q = *reinterpret_cast<const f4u*>(base + cc);
+        const int sh = c - cc;  // 0: a whole piece; 1 .. 3: the ragged one
+        f4u r;
+        r[0] = sh == 0 ? q[0] : (sh == 1 ? q[1] : (sh == 2 ? q[2] : q[3]));
+        r[1] = sh == 0 ? q[1] : (sh == 1 ? q[2] : q[3]);
+        r[2] = sh == 0 ? q[2] : q[3];
+        r[3] = q[3];
+        return r;
     };
     f4u nx[VPT];
     auto fetch = [&](int64_t row, f4u (&dst)[VPT]) {
         const float* src = a.x + (size_t)row * K;
 #pragma unroll
-        for (int u = 0; u < VPT; u++) {
-            const int i = tid + THREADS * u;
-            f4u q = {0.f, 0.f, 0.f, 0.f};
-            if (i < n4) {
-                q = *reinterpret_cast<const f4u*>(src + 4 * i);
-            } else if (4 * i < K) {  // the row's last one to three cells
-                q[0] = src[4 * i];
-                if (4 * i + 1 < K) q[1] = src[4 * i + 1];
-                if (4 * i + 2 < K) q[2] = src[4 * i + 2];
-            }
-            dst[u] = q;
-        }
+        for (int u = 0; u < VPT; u++) dst[u] = load4(src, 4 * (tid + THREADS * u));
     };
     if (PREFETCH && (int64_t)blockIdx.x < a.rows) fetch(blockIdx.x, nx);
     for (int64_t r = blockIdx.x; r < a.rows; r += gridDim.x) {
         float v[VPT][4];
-        if (PREFETCH) {
+        if (!PREFETCH) fetch(r, nx);
 #pragma unroll
-            for (int u = 0; u < VPT; u++)
+        for (int u = 0; u < VPT; u++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) v[u][j] = nx[u][j];
-            if (r + gridDim.x < a.rows) fetch(r + gridDim.x, nx);
-        } else {
-            fetch(r, nx);
-#pragma unroll
-            for (int u = 0; u < VPT; u++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) v[u][j] = nx[u][j];
-        }
+            for (int j = 0; j < 4; j++) v[u][j] = 4 * (tid + THREADS * u) + j < K ? nx[u][j] : 0.f;
         // ---- the elementwise tail of the normalisation (kmer_counts.py:169,175,208-209) and the optional write-back
         float s = 0.f, vmin = INFINITY, vmax = -INFINITY;
 #pragma unroll
         for (int u = 0; u < VPT; u++) {
             const int c = 4 * (tid + THREADS * u);
-            if (MODE >= 1 && c < K) {
-                float m[4] = {0.f, 0.f, 0.f, 0.f}, d[4] = {1.f, 1.f, 1.f, 1.f};
-                if (c + 3 < K) {  // the vectors start on 16-byte boundaries and c is a multiple of four
-                    const float4 mm = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.center) + c);
-                    const float4 dd = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.scale) + c);
-                    m[0] = mm.x, m[1] = mm.y, m[2] = mm.z, m[3] = mm.w, d[0] = dd.x, d[1] = dd.y, d[2] = dd.z, d[3] = dd.w;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        if (c + j < K) m[j] = reinterpret_cast<const float*>(a.center)[c + j], d[j] = reinterpret_cast<const float*>(a.scale)[c + j];
-                }
+            if (MODE >= 1) {
+                // x / scale as float(double(x) * (1 / double(scale))): three instructions instead of an IEEE division, the same
+                // bits (the register kernel's div_by_recip; the reciprocals are made once per launch: recip64_kernel)
+                const f4u m = load4(reinterpret_cast<const float*>(a.center), c);
+                // the reciprocals (float64): the same clamping, two 16-byte loads, rotated by the same shift
+                const int cc = c + 3 < K ? c : K - 4, sh = c - cc;
+                typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+                const d2u e0 = *reinterpret_cast<const d2u*>(a.scale_recip + cc), e1 = *reinterpret_cast<const d2u*>(a.scale_recip + cc + 2);
+                double d[4];
+                d[0] = sh == 0 ? e0[0] : (sh == 1 ? e0[1] : (sh == 2 ? e1[0] : e1[1]));
+                d[1] = sh == 0 ? e0[1] : (sh == 1 ? e1[0] : e1[1]);
+                d[2] = sh == 0 ? e1[0] : e1[1];
+                d[3] = e1[1];
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                     if (c + j < K) {
-                        float t = __fdiv_rn(__fsub_rn(v[u][j], m[j]), d[j]);
+                        float t = div_by_recip(__fsub_rn(v[u][j], m[j]), d[j]);
                         if (t != t) any_nan = true;
                         if (MODE == 2) t = skr_log2_of_sum1(__fadd_rn(t, a.shift));
                         v[u][j] = t;
@@ -787,11 +818,17 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
             if (sizeof(T) != 4 && lane == 0) edge[u][wave] = v[u][0];  // the first cell of this wave's piece: the wave before needs it
             __builtin_amdgcn_sched_barrier(0);
         }
+        // The next row's pieces, requested HERE: behind this row's centre / scale loads (vmcnt counts in order — a wait for
+        // those would otherwise sit out the prefetch too) and in front of everything that only computes and stores.  The last
+        // iteration re-reads its own row: an unconditional load (load4).
+        if (PREFETCH) fetch(r + gridDim.x < a.rows ? r + gridDim.x : r, nx);
         // ---- row statistics in the order pearson.py:35-38 computes them; minimum and maximum ride on the first barrier
-        float nmin = -vmin, dummy = 0.f;
-        if (sizeof(T) != 4) reduce3(nmin, vmax, dummy, true);
+        // the row sum, minimum and maximum ride on ONE barrier
+        float nmin = -vmin;
+        if (sizeof(T) != 4 || a.row_standardize) reduce3(s, nmin, vmax, kSum, kMax, kMax);
         vmin = -nmin;
         float mean = 0.f, sd = 1.f;
+        double rsd = 1.0;
         float same = 0.f, adj = 0.f;
         if (sizeof(T) != 4) {
             // how much of the row one value holds: its minimum, or — neighbouring cells equal — any value (block kernel)
@@ -811,8 +848,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
             }
         }
         if (a.row_standardize) {
-            float z0 = 0.f, z1 = 0.f;
-            reduce3(s, z0, z1, false);
             mean = s / kf;
             s = 0.f;
 #pragma unroll
@@ -822,7 +857,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
                 for (int j = 0; j < 4; j++)
                     if (c + j < K) s += v[u][j] - mean;
             }
-            reduce3(s, same, adj, false);
+            reduce3(s, same, adj, kSum, kSum, kSum);
             const float m2 = s / kf;
             s = 0.f;
 #pragma unroll
@@ -836,11 +871,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
                     }
             }
             float z2 = 0.f, z3 = 0.f;
-            reduce3(s, z2, z3, false);
+            reduce3(s, z2, z3, kSum, kSum, kSum);
             sd = sqrtf(s / kf);
+            rsd = 1.0 / (double)sd;  // once per row: the quotients below cost three instructions each (div_by_recip)
         } else if (sizeof(T) != 4) {
             float z0 = 0.f;
-            reduce3(same, adj, z0, false);
+            reduce3(same, adj, z0, kSum, kSum, kSum);
         }
         float zmax2 = 0.f;
         if (sizeof(T) != 4) {
@@ -861,7 +897,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 float t = k0 + j < K ? v[u][j] : 0.f;
-                if (a.row_standardize && k0 + j < K) t = __fdiv_rn(__fsub_rn(t, mean), sd);
+                if (a.row_standardize && k0 + j < K) t = div_by_recip(__fsub_rn(t, mean), rsd);
                 z[j] = t;
                 sq = __fmaf_rn(t, t, sq);
                 if (sizeof(T) != 4) {
@@ -878,7 +914,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
                 for (int j = 0; j < 4; j++) {
                     const float zs = z[j] * a.out_scale;
                     if (fabsf(zs) > 65504.f) overflow = true;
-                    const T hh = split_hi<T>(zs, k0 + j);
+                    const T hh = split_hi_flip<T>(zs, ((dir >> (u * 4 + j)) & 1u) << 31);
                     hi[j] = hh;
                     lo[j] = (T)(zs - (float)hh);
                 }
@@ -888,7 +924,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
             }
             __builtin_amdgcn_sched_barrier(0);  // one piece at a time: interleaved, the splits of all pieces are alive at once
         }
-        reduce3(sq, m3, m4, false);
+        reduce3(sq, m3, m4, kSum, kSum, kSum);
         if (tid == 0) a.diag[r] = sq / kf;
         if (sizeof(T) != 4 && a.row_standardize && row_on_two_levels(sq / kf, m3 / kf, m4 / kf)) coherent = true;
         if (sizeof(T) != 4 && row_needs_fp32(zmax2, kf)) outlier = true;
@@ -1310,6 +1346,19 @@ int launch_fill(skr_ctx* ctx, const skr_operand* op, const FillArgs& a_in) {
         // round 5: odd widths of 8 193 .. 16 384 columns (5^6, 7^5 ...) — the row in the registers of a sixteen-wave
         // workgroup (operand_fill_rowreg_kernel); widths below stay with the wave-per-row kernel and its numpy-ordered
         // sums, everything else with the block kernel (a 65 536-cell row in registers, 64 per thread, spills: measured)
+        FillArgs a = a_in;
+        if (reg_mode >= 1) {  // float64 reciprocals of the scale vector (as for the register kernels above)
+            if (ctx->d_recip_len < (size_t)a.cols) {
+                if (ctx->d_recip) SKR_HIP(hipFree(ctx->d_recip));
+                ctx->d_recip = nullptr;
+                ctx->d_recip_len = 0;
+                SKR_HIP(hipMalloc((void**)&ctx->d_recip, (size_t)a.cols * sizeof(double)));
+                ctx->d_recip_len = (size_t)a.cols;
+            }
+            hipLaunchKernelGGL(recip64_kernel, dim3((unsigned)((a.cols + 255) / 256)), dim3(256), 0, ctx->stream,
+                               reinterpret_cast<const float*>(a.scale), ctx->d_recip, a.cols);
+            a.scale_recip = ctx->d_recip;
+        }
         SkrProfScope prof(ctx, "operand_fill");
         // one sixteen-wave workgroup per CU (128 registers a thread) that prefetches its next row; two eight-wave workgroups
         // per CU without prefetch were slower (4.18 against 3.47 ms: profiles/r5_generic_width_arms.log)
