@@ -64,15 +64,32 @@ __device__ __forceinline__ float div_by_recip(float x, double r) { return (float
 template <typename T>
 using vec8 = T __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ float wave_sum(float v) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;  // every lane holds the total
+// Wave-wide sums and maxima on the DPP network (round 5; until then a __shfl_xor butterfly, i.e. a ds_bpermute — an LDS
+// operation — per step, six dependent steps a sum): four DPP steps leave every lane of a 16-lane row with its row's total,
+// the four row totals are read with v_readlane and added.  Every lane holds the result.  (The summation order differs from
+// the butterfly's: the row statistics of the fills, and with them the last bits of r, are round 5's.)
+template <bool IS_MAX, int CTRL>
+__device__ __forceinline__ float dpp_step_c(float v) {
+    const float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+    return IS_MAX ? fmaxf(v, o) : v + o;
 }
-
-__device__ __forceinline__ float wave_max(float v) {
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+template <bool IS_MAX>
+__device__ __forceinline__ float row16_all(float v) {  // every lane: the reduction over its row of 16 lanes
+    v = dpp_step_c<IS_MAX, 0xB1>(v);   // quad_perm [1,0,3,2]
+    v = dpp_step_c<IS_MAX, 0x4E>(v);   // quad_perm [2,3,0,1]
+    v = dpp_step_c<IS_MAX, 0x141>(v);  // row_half_mirror
+    v = dpp_step_c<IS_MAX, 0x140>(v);  // row_mirror
     return v;
 }
+template <bool IS_MAX>
+__device__ __forceinline__ float wave64_all(float v) {  // every lane: the reduction over the wave
+    v = row16_all<IS_MAX>(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return IS_MAX ? fmaxf(fmaxf(r0, r1), fmaxf(r2, r3)) : (r0 + r1) + (r2 + r3);
+}
+__device__ __forceinline__ float wave_sum(float v) { return wave64_all<false>(v); }
+__device__ __forceinline__ float wave_max(float v) { return wave64_all<true>(v); }
 
 // Dynamic range a single float32 accumulator per cell can take.  The MFMA adds each product into the
 // accumulator aligned to the accumulator's exponent: once a huge product (two rows sharing one
@@ -655,32 +672,6 @@ __global__ __launch_bounds__(THREADS) void operand_fill_block_kernel(FillArgs a)
 
 template <typename T>
 using vec4h = T __attribute__((ext_vector_type(4)));
-
-// Wave-wide sums and maxima on the DPP network instead of ds_bpermute (what __shfl_xor compiles to: an LDS operation a
-// step, 6 dependent steps a sum — sixteen waves folding three quantities five times a row kept the LDS pipe busy for
-// ~1 us per fold).  Four DPP steps leave every lane of a 16-lane row with its row's total; the four row totals are read
-// with v_readlane and added.  (Used by operand_fill_rowreg_kernel only: the other fills keep the butterfly whose
-// summation order their results were pinned with.)
-template <bool IS_MAX, int CTRL>
-__device__ __forceinline__ float dpp_step_c(float v) {
-    const float o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-    return IS_MAX ? fmaxf(v, o) : v + o;
-}
-template <bool IS_MAX>
-__device__ __forceinline__ float row16_all(float v) {  // every lane: the reduction over its row of 16 lanes
-    v = dpp_step_c<IS_MAX, 0xB1>(v);   // quad_perm [1,0,3,2]
-    v = dpp_step_c<IS_MAX, 0x4E>(v);   // quad_perm [2,3,0,1]
-    v = dpp_step_c<IS_MAX, 0x141>(v);  // row_half_mirror
-    v = dpp_step_c<IS_MAX, 0x140>(v);  // row_mirror
-    return v;
-}
-template <bool IS_MAX>
-__device__ __forceinline__ float wave64_all(float v) {  // every lane: the reduction over the wave
-    v = row16_all<IS_MAX>(v);
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-    return IS_MAX ? fmaxf(fmaxf(r0, r1), fmaxf(r2, r3)) : (r0 + r1) + (r2 + r3);
-}
 
 // ---- round 5: ANY width up to VPT * 4 096 columns, the row in the registers of a sixteen-wave workgroup ------------------
 // The block kernel above parks a row in the LDS (or re-reads it from the L2) and walks it once per statistic, four waves a
