@@ -587,13 +587,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
             const float send = (j & 1) ? v[e] : v[e + 1];
             // lane ^ 1 / lane ^ 2 inside a quad: one DPP move (quad_perm) instead of the ds_bpermute __shfl_xor compiles to —
             // 128 LDS operations per wave and tile less in an epilogue that shares the LDS pipe with the next tile's staging
-            const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0xB1, 0xf, 0xf, false));
+            const float recv = __shfl_xor(send, 1, 64);
             if (j & 1) v[e] = recv; else v[e + 1] = recv;
         }
 #pragma unroll
         for (int e = 0; e < 2; e++) {
             const float send = (j & 2) ? v[e] : v[e + 2];
-            const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x4E, 0xf, 0xf, false));
+            const float recv = __shfl_xor(send, 2, 64);
             if (j & 2) v[e] = recv; else v[e + 2] = recv;
         }
     };
