@@ -818,26 +818,23 @@ __global__ __launch_bounds__(kGenThreads) void count_generic_lds_kernel(const un
             return (OutT)t;
         };
         if (sizeof(OutT) == 4) {
-            // 16-byte stores: rows of A^k four-byte cells start on a 4-byte boundary only, so the first `head` cells and the
-            // last few go out one by one and the body in aligned groups of four (four LDS reads: the group's bins are
-            // not 16-byte aligned in the LDS)
-            typedef OutT v4 __attribute__((ext_vector_type(4)));
-            const uint32_t head = std::min<uint32_t>(nbins, (4u - (uint32_t)((reinterpret_cast<uintptr_t>(row) >> 2) & 3u)) & 3u);
-            const uint32_t groups = (nbins - head) >> 2;
+            // Round 5: a group is four bins that are ALIGNED IN THE LDS (b = 4 g: one ds_read_b128, one ds_write_b128 of
+            // zeros) and goes out as one 16-byte store to wherever the row puts it — rows of A^k four-byte cells start on
+            // 4-byte boundaries only, and a dword-aligned global_store_dwordx4 is as good as an aligned one.  Until now the
+            // groups were aligned in MEMORY instead: four ds_read_b32 + four ds_write_b32 each, and a head / tail path.
+            typedef OutT v4u __attribute__((ext_vector_type(4), aligned(4)));
+            const uint32_t groups = nbins >> 2;
             for (uint32_t g = tid; g < groups; g += kGenThreads) {
-                const uint32_t b = head + 4 * g;
-                const uint32_t n0 = bins[b], n1 = bins[b + 1], n2 = bins[b + 2], n3 = bins[b + 3];
-                bins[b] = 0, bins[b + 1] = 0, bins[b + 2] = 0, bins[b + 3] = 0;
-                __builtin_nontemporal_store(v4{value_of(n0), value_of(n1), value_of(n2), value_of(n3)}, reinterpret_cast<v4*>(row + b));
+                const uint32_t b = 4 * g;
+                const uint4 n = *reinterpret_cast<const uint4*>(bins + b);
+                *reinterpret_cast<uint4*>(bins + b) = make_uint4(0, 0, 0, 0);
+                __builtin_nontemporal_store(v4u{value_of(n.x), value_of(n.y), value_of(n.z), value_of(n.w)}, reinterpret_cast<v4u*>(row + b));
             }
-            const uint32_t tail0 = head + 4 * groups;  // cells [0, head) and [tail0, nbins): at most six
-            if (tid < 8) {
-                const uint32_t b = (uint32_t)tid < head ? (uint32_t)tid : tail0 + ((uint32_t)tid - head);
-                if (((uint32_t)tid < head) || b < nbins) {
-                    const uint32_t n = bins[b];
-                    bins[b] = 0;
-                    row[b] = value_of(n);
-                }
+            if (tid < (nbins & 3u)) {  // the last one to three cells
+                const uint32_t b = 4 * groups + tid;
+                const uint32_t n = bins[b];
+                bins[b] = 0;
+                row[b] = value_of(n);
             }
         } else {
             for (uint32_t b = tid; b < nbins; b += kGenThreads) {
