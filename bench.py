@@ -392,10 +392,12 @@ def end_to_end_devices(fasta_path, k, length, n_seqs, n_p, timeout_s=240):
     nothing it does can cost the line measured above.  With one GPU visible there is nothing to compare."""
     from seekr_amd import _lib
     n_dev = _lib.device_count()
-    if n_dev < 2:
+    # test hook (tests/test_gpu_multi_devices.py): a device list with repeats, so that the sub-record's code runs on a one-GPU box
+    forced = os.environ.get("SEEKR_BENCH_E2E_DEVICES") if os.environ.get("SEEKR_TEST_HOOKS") == "1" else None
+    if n_dev < 2 and not forced:
         return {"devices": n_dev, "note": "one GPU visible: SEEKR_DEVICES has nothing to add here"}
     env = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SEEKR_DEVICE")}
-    env.update(SEEKR_DEVICES="all", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.update(SEEKR_DEVICES=forced or "all", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     try:
         res = subprocess.run([sys.executable, "-c", E2E_DEVICES_CHILD, ROOT, fasta_path, str(k), str(n_p)], env=env,
                              capture_output=True, text=True, timeout=timeout_s)

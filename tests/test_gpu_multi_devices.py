@@ -128,3 +128,20 @@ def test_rccl_that_cannot_be_set_up_falls_back_to_peer_copies(baseline, tmp_path
         info = json.load(fh)
     assert info["transport"] == "peer" and info["group_size"] == 2 and info["group_broken"] is False
     same_outputs(run_worker(tmp_path / "small_ref", scale="small"), got)
+
+
+def test_bench_reports_the_host_to_host_figures_with_seekr_devices(tmp_path):
+    """bench.py's `e2e.seekr_devices_all`: the FASTA -> host counts and host -> host pearson() figures
+    again with every visible GPU behind the API, from a child process.  On a one-GPU box the sub-record's code path runs
+    through a test hook that names GPU 0 twice (peer copies)."""
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, SEEKR_TEST_HOOKS="1", SEEKR_BENCH_E2E_DEVICES="0,0", SEEKR_TRANSPORT="peer")
+    env.pop("SEEKR_DEVICES", None)
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rows", "6000", "--length", "600", "--steps", "2", "--warmup", "1",
+                          "--no-f16f8-arm"], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    dev = out["e2e"]["seekr_devices_all"]
+    assert dev.get("devices") == 2 and "error" not in dev, dev
+    assert dev["host_to_host_pearson_mpairs_per_s"] > 0 and dev["fasta_to_host_counts_mbases_per_s"] > 0 and dev["first_call_s"] > 0
+    assert "target_200k" not in out  # only the default workload carries it
