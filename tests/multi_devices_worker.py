@@ -121,7 +121,9 @@ def main():
     cli(cs.console_pearson, path("cli_counts.npy"), path("cli_counts.npy"), "-o", path("cli_r.npy"), "-bi", "-bo")
     cli(cs.console_kmer_counts, path("s2.fa"), "-o", path("cli_counts2.npy"), "-k", 4, "-b", "-rl", "-uc", "-us", "-l", "Log2.none")
     cli(cs.console_pearson, path("cli_counts.npy"), path("cli_counts2.npy"), "-o", path("cli_r_from_npy.csv"), "-bi")
+    cli(cs.console_pearson, path("cli_counts.csv"), path("cli_counts.csv"), "-o", path("cli_r64.npy"), "-bo")  # float64, straight to the file
     pearson_to_file(cb.counts, cb.counts[:777], path("big_r_cross_file"))  # np.save appends .npy
+    pearson_to_file(cb.counts[:900].astype(np.float64), cb.counts[:333], path("mixed_r_file.npy"), row_standardize=False)
     # ---- an exception raised for one range: once, itself; the next call works
     bad = list(s1[:60])
     bad[41] = "ACG"  # k = 4: W = 0 (kmer_counts.py:144)

@@ -73,6 +73,11 @@ def test_the_baseline_is_what_the_reference_does(baseline):
     assert np.array_equal(a["big_r"], a["big_r"].T) and np.abs(np.diag(a["big_r"]) - 1).max() < 1e-6
     r_file = np.load(os.path.join(baseline, "big_r_cross_file.npy"))
     assert r_file.shape == (6000, 777) and r_file.dtype == np.float32
+    r64 = np.load(os.path.join(baseline, "cli_r64.npy"))
+    assert r64.dtype == np.float64 and r64.shape == (111, 111) and np.array_equal(r64, r64.T) and np.allclose(np.diag(r64), 1.0, atol=1e-12)
+    mixed = np.load(os.path.join(baseline, "mixed_r_file.npy"))
+    assert mixed.dtype == np.float64 and mixed.shape == (900, 333)
+    assert np.allclose(mixed, a["big_counts"][:900].astype(np.float64) @ a["big_counts"][:333].astype(np.float64).T / 4096, rtol=1e-12, atol=1e-12)
     assert np.allclose(r_file, a["big_r"][:, :777], rtol=1e-5, atol=2e-6)  # a cross comparison: same values, its own bits
 
 
