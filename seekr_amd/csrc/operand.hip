@@ -500,6 +500,11 @@ __global__ __launch_bounds__(THREADS) void operand_fill_block_kernel(FillArgs a)
         } else
         for (int64_t g = tid; g < groups; g += THREADS) {
             const int64_t c0 = g * 8;
+            // `groups` covers the operand's row PADDED to whole 32-column tiles: a width that is a multiple of 8 but not of
+            // 32 (10^4, 22^3, 14^4 ... columns) has up to three groups past the end of the row.  They hold nothing: until
+            // round 5 the vector path below read them anyway — the next row's first cells —, added them to the row sum and
+            // wrote them "back" through y (found by widening the odd-width test: r 5 bars off at 8 200 columns).
+            if (vec && c0 >= K) continue;
             if (vec) {
                 float4 u = *reinterpret_cast<const float4*>(xr + c0), w = *reinterpret_cast<const float4*>(xr + c0 + 4);
                 u.x = fill_tail(a, u.x, c0, any_nan);

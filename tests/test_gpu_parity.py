@@ -1144,6 +1144,42 @@ def test_g7_alphabets_other_than_four_letters(golden_dir, tmp_path):
 
 
 
+@pytest.mark.parametrize("alphabet,k", [("ACDEFGHIKL", 4), ("ACDEFGHIKLMNPQRSTVWYBZ", 3), ("ACGTNRYKMSWBDH", 4)])
+def test_alphabets_whose_width_is_a_multiple_of_8_but_not_of_32(alphabet, k):
+    """10^4 = 10 000, 22^3 = 10 648 and 14^4 = 38 416 columns: rows that the operand fill's one-workgroup-per-row kernel
+    reads sixteen bytes at a time and that end inside a 32-column tile.  Until round 5 the vector path also read the tile's
+    padding — the next row's first cells — into the row's mean and standard deviation (r about 5 bars off, and the
+    normalised counts of the next row overwritten when they were kept in place); no test had such a width.  Counts
+    bit-exact (raw) / within the bar (normalised) against the oracle (kmer_counts.py:120-151, 217-246), r within the bar of
+    the reference AND of float64 (pearson.py:35-41)."""
+    from seekr_amd.kmer_counts import BasicCounter
+    from seekr_amd.pearson import pearson
+    rng = np.random.default_rng(len(alphabet))
+    letters = np.array(list(alphabet))
+    seqs = ["".join(rng.choice(letters, size=int(n))) for n in rng.integers(4000, 12000, 90)]
+    seqs[7] = seqs[6][3:] + seqs[6][:3]  # a near-copy: r close to 1
+    want_raw = orc.raw_counts(seqs, k, alphabet)
+    for kw in (dict(mean=False, std=False, log2="Log2.none"), dict(mean=True, std=True, log2="Log2.post")):
+        c = BasicCounter(k=k, alphabet=alphabet, silent=True, **kw)
+        c.seqs = list(seqs)
+        with contextlib.redirect_stdout(io.StringIO()):
+            c.get_counts()
+        with np.errstate(all="ignore"):
+            want = orc.normalize(want_raw, mean=kw["mean"], std=kw["std"], log2=kw["log2"])[0]
+        if not kw["mean"]:
+            assert_bits(c.counts, want, "raw")
+        else:
+            assert not np.isnan(want).any() and not np.isnan(c.counts).any()
+            np.testing.assert_allclose(c.counts, want, rtol=1e-5, atol=2e-6)
+        x = c.counts
+        got = pearson(x, x).astype(np.float64)
+        with np.errstate(all="ignore"):
+            ref, truth = orc.pearson(x, x).astype(np.float64), orc.pearson_f64_truth(x, x)
+        assert (np.abs(got - ref) <= 2e-6 + 1e-5 * np.abs(ref)).all(), float((np.abs(got - ref) / (2e-6 + 1e-5 * np.abs(ref))).max())
+        assert (np.abs(got - truth) <= 2e-6 + 1e-5 * np.abs(truth)).all()
+        assert np.array_equal(got, got.T)
+
+
 def test_four_wave_geometry_gives_the_same_bits():
     """The 4-wave / 128 x 128 wave-tile arm of the split contraction (libseekr_hip_diag.so only: measured
     13 % slower and not shipped) adds the same products to every accumulator in the same order as the 8-wave kernel: r

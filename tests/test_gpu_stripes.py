@@ -103,16 +103,20 @@ def test_float64_stripes(L, ctx, cols, n, stripe):
     assert same_bits(got, want)
 
 
-@pytest.mark.parametrize("cols", [15625, 8197, 9999, 16383, 12346])
+@pytest.mark.parametrize("cols", [15625, 8197, 9999, 16383, 12346, 16807, 19683, 8200, 10000, 10648, 38416, 40004, 46656])
 def test_rows_of_odd_width_through_the_register_row_kernel(L, ctx, cols):
     """Round 5: widths of 8 193 .. 16 384 columns that are not a multiple of 8 (5^6 = 15 625, 7^5 = 16 807 is beyond) take
     operand_fill_rowreg_kernel — the row in the registers of a sixteen-wave workgroup, rows on 4-byte boundaries read in
     16-byte pieces.  The normalised counts it writes back are the elementwise reference values bit for bit, r is inside
     the bar of the reference (strict) and of float64, the flags behave (a mostly-constant set is 'coherent'), and the
-    pipeline form (float32 mean / std, Log2.post) agrees with the separate elementwise pass (skr_apply)."""
+    pipeline form (float32 mean / std, Log2.post) agrees with the separate elementwise pass (skr_apply).  The widths
+    above 16 384 (7^5, 3^9: the block kernel with the row staged through the LDS in 16-byte pieces; 6^6 and 40 004: rows too
+    wide for the LDS, sixteen waves a row) and the multiples of 8 that are not multiples of 32 (8 200, 10^4, 22^3, 14^4: the
+    block kernel's vector path, whose padding groups read past the row until round 5 — r was 5 bars off) run the same
+    checks on the neighbouring kernels."""
     from oracle import seekr_oracle as orc
     rng = np.random.default_rng(cols)
-    n = 70
+    n = 70 if cols < 20000 else 40
     x = (rng.poisson(0.4, size=(n, cols)) * np.float32(0.5013)).astype(np.float32)
     x[3] = x[2] * np.float32(2.0) + np.float32(0.25)       # r = 1 off the diagonal
     x[5, 7:] = x[4, :-7]                                  # a shifted near-copy
