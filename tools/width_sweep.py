@@ -1,0 +1,173 @@
+"""Every kernel behind normalisation and Pearson, at MANY widths (round 5, after the block fill was found reading a row's
+tile padding at 8 200 columns — a width no test, golden set or fuzzer had).  The kernels choose their code path by the
+width of a row: multiples of 4 / 8 / 16 / 32, rows that fit a wave / the registers of a workgroup / the LDS / none of
+them, whole strips of 16 columns or a ragged last one.  This walks the widths instead of the paths:
+
+  every width 1 .. 130, the neighbours (-9 .. +9) of every power of two and of the kernels' own thresholds up to 70 000,
+  multiples of 8 that are not multiples of 32 across the whole range, and seeded random widths;
+
+and at each one checks, against the oracle (numpy float32 restatement of seekr/kmer_counts.py:201-209 and
+seekr/pearson.py:35-41):
+
+  normalize   column mean, column std and the normalised matrix of `skr_normalize` (Log2.none) BIT-EXACT; Log2.post within
+              1e-5 relative + 2e-6 absolute;
+  fused       `skr_operand_fill` with centre / scale / Log2.post writing the normalised counts back == `skr_apply`, bit
+              for bit, and the column of the row after the last one untouched (guard rows around the matrix);
+  pearson     r of the default precision and of fp32 by tests/parity_rule.py (strict against the reference, float64 as the
+              yardstick where the reference itself is a range), self and cross comparison.
+
+    python tools/width_sweep.py [--quick] [--widths 8200,10000] [--seed 1]
+
+Exit code 1 and the failing widths on stderr if any check fails.  Needs a real MI355X.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+THRESHOLDS = (16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 12288, 16384, 32768, 38400, 49152, 65536)
+
+
+def widths(quick, seed):
+    w = set(range(1, 131))
+    for t in THRESHOLDS:
+        for d in range(-9, 10):
+            w.add(t + d)
+    rng = np.random.default_rng(seed)
+    w.update(int(v) * 8 for v in rng.integers(17, 8750, 40 if quick else 160))          # multiples of 8
+    w.update(int(v) * 8 + 4 for v in rng.integers(17, 8750, 10 if quick else 40))       # multiples of 4 only
+    w.update(int(v) for v in rng.integers(131, 70000, 30 if quick else 150))             # anything
+    w.update((8200, 10000, 10648, 15625, 16807, 19683, 20736, 38416, 40004, 46656, 50625, 59049, 69999))
+    out = sorted(v for v in w if v >= 1)
+    if quick:  # thin the neighbourhoods: every third neighbour of the thresholds above 256
+        out = [v for v in out if v <= 300 or v % 3 != 1 or v % 8 == 0]
+    return out
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def rows_for(rng, n, cols):
+    x = (rng.poisson(0.7, size=(n, cols)) * np.float32(0.5013)).astype(np.float32)
+    x += (rng.integers(0, 3, size=(n, 1)) * np.float32(0.125)).astype(np.float32)
+    if cols >= 2:
+        x[np.arange(n), rng.integers(0, cols, n)] += np.float32(2.5)  # no constant rows
+        x[0::2, 0] += np.float32(1.0)  # no zero-variance first column
+    if n >= 4 and cols >= 8:
+        x[3] = x[2] * np.float32(2.0) + np.float32(0.25)  # r = 1 off the diagonal
+    return x
+
+
+def check_width(L, ctx, orc, parity_rule, pearson, cols, seed):
+    problems = []
+    rng = np.random.default_rng([seed, cols])
+    n = 33 if cols > 20000 else 61
+    x = rows_for(rng, n, cols)
+    # normalize --------------------------------------------------------------------------------------------------------
+    with np.errstate(all="ignore"):
+        z_ref, mean_ref, std_ref = orc.normalize(x, log2="Log2.none")
+        post_ref = orc.normalize(x, log2="Log2.post")[0]
+    clean = not np.isnan(z_ref).any()
+    dev = ctx.from_numpy(x)
+    mean_out, std_out, has_nan = L.normalize(ctx, dev, "Log2.none", 1, None, 1, None)
+    if has_nan == clean:
+        problems.append("normalize: has_nan %s, oracle clean %s" % (has_nan, clean))
+    if not np.array_equal(bits(mean_out.vector()), bits(mean_ref)):
+        problems.append("column mean differs")
+    if not np.array_equal(bits(std_out.vector()), bits(std_ref)):
+        problems.append("column std differs")
+    got = dev.to_numpy()
+    if not (np.array_equal(bits(got), bits(z_ref)) or np.all((bits(got) == bits(z_ref)) | (np.isnan(got) & np.isnan(z_ref)))):
+        problems.append("normalised matrix differs in %d cells" % int((bits(got) != bits(z_ref)).sum()))
+    dev = ctx.from_numpy(x)
+    L.normalize(ctx, dev, "Log2.post", 1, None, 1, None)
+    got = dev.to_numpy()
+    if clean and not np.allclose(got, post_ref, rtol=1e-5, atol=2e-6):
+        problems.append("Log2.post beyond the bar: %.3g" % float(np.nanmax(np.abs(got - post_ref))))
+    if not clean:
+        return problems  # a zero-variance column: everything after is NaN in the reference too
+    # fused fill -------------------------------------------------------------------------------------------------------
+    dmean, dstd = ctx.from_numpy(mean_ref), ctx.from_numpy(std_ref)
+    shift = float(np.abs(L.min_nan(ctx, ctx.from_numpy(x), dmean, dstd)[0]))
+    want_y, _ = L.apply(ctx, ctx.from_numpy(x), center=dmean, scale=dstd, post=True, shift=shift)
+    want_y = want_y.to_numpy()
+    guard = np.float32(-77.0)
+    framed = np.full((n + 2, cols), guard, dtype=np.float32)  # a row in front and one behind the matrix that nobody may touch
+    framed[1:-1] = x
+    for prec in ("f16x3", "fp32"):
+        whole = ctx.from_numpy(framed)
+        inner = whole.view(1, n)
+        op, nan2 = L.operand_fill(ctx, inner, precision=L.PRECISIONS[prec], center=dmean, scale=dstd, post=True, shift=shift,
+                                  y=inner, want_nan=True)
+        back = whole.to_numpy()
+        if nan2:
+            problems.append("%s fused: NaN reported" % prec)
+        if not np.array_equal(bits(back[1:-1]), bits(want_y)):
+            problems.append("%s fused counts differ from skr_apply in %d cells" % (prec, int((bits(back[1:-1]) != bits(want_y)).sum())))
+        if not ((back[0] == guard).all() and (back[-1] == guard).all()):
+            problems.append("%s fused fill wrote outside its rows" % prec)
+        r = ctx.zeros(n, n)
+        L.pearson_gemm_op(ctx, op, op, r, symmetric=True)
+        with np.errstate(all="ignore"):
+            ref, truth = orc.pearson(want_y, want_y).astype(np.float64), orc.pearson_f64_truth(want_y, want_y)
+        ok = np.isfinite(ref) & np.isfinite(truth)
+        v = parity_rule.judge(r.to_numpy(), ref, truth, ok, want_y, want_y)
+        if v["failures"]:
+            problems.append("%s fused r: %s" % (prec, v["failures"][0]))
+    # pearson() on the raw rows, self and cross ----------------------------------------------------------------------------
+    y = rows_for(rng, 19, cols)
+    for prec in ("f16x3", "fp32"):
+        os.environ["SEEKR_PRECISION"] = prec
+        try:
+            for name, a, b in (("self", x, x), ("cross", x, y)):
+                with np.errstate(all="ignore"):
+                    ref, truth = orc.pearson(a, b).astype(np.float64), orc.pearson_f64_truth(a, b)
+                    got = pearson(a, b).astype(np.float64)
+                ok = np.isfinite(ref) & np.isfinite(truth)
+                if not np.array_equal(np.isnan(got), np.isnan(ref)):
+                    problems.append("%s %s: NaN pattern differs" % (prec, name))
+                v = parity_rule.judge(got, ref, truth, ok, a, b)
+                if v["failures"]:
+                    problems.append("%s %s r: %s" % (prec, name, v["failures"][0]))
+        finally:
+            os.environ.pop("SEEKR_PRECISION", None)
+    return problems
+
+
+def sweep(ws, seed=1, verbose=True):
+    from oracle import seekr_oracle as orc
+    from seekr_amd import _lib as L
+    from seekr_amd.pearson import pearson
+    import parity_rule
+    ctx = L.default_context()
+    bad = {}
+    for i, cols in enumerate(ws):
+        p = check_width(L, ctx, orc, parity_rule, pearson, cols, seed)
+        if p:
+            bad[cols] = p
+            print("width %6d  FAIL  %s" % (cols, "; ".join(p)), file=sys.stderr, flush=True)
+        elif verbose and i % 50 == 0:
+            print("width %6d  ok  (%d of %d)" % (cols, i + 1, len(ws)), flush=True)
+    return bad
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--widths", default=None)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    ws = [int(w) for w in args.widths.split(",")] if args.widths else widths(args.quick, args.seed)
+    bad = sweep(ws, args.seed)
+    print("%d widths (%d .. %d), %d failing%s" % (len(ws), ws[0], ws[-1], len(bad), ": " + ",".join(map(str, sorted(bad))) if bad else ""))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
