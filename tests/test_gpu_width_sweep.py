@@ -20,3 +20,9 @@ def test_every_kernel_behind_normalisation_and_pearson_across_widths():
     assert len(ws) > 300 and {8200, 10000, 15625, 38416, 65536} <= set(ws)
     bad = width_sweep.sweep(ws, seed=1, verbose=False)
     assert not bad, bad
+
+
+def test_row_counts_around_the_tile_heights():
+    import width_sweep
+    bad = width_sweep.rows_sweep(seed=1, verbose=False)
+    assert not bad, bad

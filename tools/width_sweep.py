@@ -42,11 +42,10 @@ def widths(quick, seed):
     w.update(int(v) * 8 for v in rng.integers(17, 8750, 40 if quick else 160))          # multiples of 8
     w.update(int(v) * 8 + 4 for v in rng.integers(17, 8750, 10 if quick else 40))       # multiples of 4 only
     w.update(int(v) for v in rng.integers(131, 70000, 30 if quick else 150))             # anything
-    w.update((8200, 10000, 10648, 15625, 16807, 19683, 20736, 38416, 40004, 46656, 50625, 59049, 69999))
-    out = sorted(v for v in w if v >= 1)
+    named = {8200, 10000, 10648, 15625, 16807, 19683, 20736, 38416, 40004, 46656, 50625, 59049, 69999}  # alphabet^k widths
     if quick:  # thin the neighbourhoods: every third neighbour of the thresholds above 256
-        out = [v for v in out if v <= 300 or v % 3 != 1 or v % 8 == 0]
-    return out
+        w = {v for v in w if v <= 300 or v % 3 != 1 or v % 8 == 0}
+    return sorted(v for v in w | named if v >= 1)
 
 
 def bits(a):
@@ -157,6 +156,59 @@ def sweep(ws, seed=1, verbose=True):
     return bad
 
 
+ROW_COUNTS = (1, 2, 3, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 383, 384, 385, 511, 512, 513,
+              767, 768, 769, 1023, 1024, 1025, 1279, 1281)
+
+
+def rows_sweep(seed=1, verbose=True):
+    """The other axis: row counts around the contraction's tile heights (16 / 32 / 64 / 128 / 256 rows) for the self
+    comparison (the symmetric kernel: blocks on the diagonal, mirrored ones), a cross comparison with different row counts
+    on the two sides, and row stripes of the self comparison (bit-identical to the one-block call), at four widths."""
+    from oracle import seekr_oracle as orc
+    from seekr_amd import _lib as L
+    from seekr_amd.pearson import pearson
+    import parity_rule
+    ctx = L.default_context()
+    bad = {}
+    for cols in (24, 1000, 4096, 8200):
+        for n in ROW_COUNTS:
+            rng = np.random.default_rng([seed, cols, n])
+            x = rows_for(rng, n, cols)
+            m = ROW_COUNTS[(ROW_COUNTS.index(n) * 7 + 3) % len(ROW_COUNTS)]
+            y = rows_for(rng, m, cols)
+            problems = []
+            for name, a, b in (("self", x, x), ("cross", x, y)):
+                with np.errstate(all="ignore"):
+                    ref, truth = orc.pearson(a, b).astype(np.float64), orc.pearson_f64_truth(a, b)
+                    got = pearson(a, b)
+                if not np.array_equal(np.isnan(got), np.isnan(ref)):
+                    problems.append("%s: NaN pattern differs" % name)
+                ok = np.isfinite(ref) & np.isfinite(truth)
+                v = parity_rule.judge(got.astype(np.float64), ref, truth, ok, a, b)
+                if v["failures"]:
+                    problems.append("%s r: %s" % (name, v["failures"][0]))
+                if name == "self":
+                    if not np.array_equal(bits(got), bits(got.T.copy())):
+                        problems.append("self comparison not symmetric")
+                    if n >= 3:  # three ragged stripes carry the one-block bits
+                        op, _ = L.operand_fill(ctx, ctx.from_numpy(x))
+                        whole = ctx.zeros(n, n)
+                        L.pearson_gemm_op(ctx, op, op, whole, symmetric=True)
+                        want = whole.to_numpy()
+                        cut = sorted({0, n // 3, n // 3 + (n + 1) // 2, n})
+                        for s0, s1 in zip(cut[:-1], cut[1:]):
+                            buf = ctx.zeros(s1 - s0, n)
+                            L.pearson_gemm_op_rows(ctx, op.view(s0, s1 - s0), op, s0, buf)
+                            if not np.array_equal(bits(buf.to_numpy()), bits(want[s0:s1])):
+                                problems.append("stripe [%d, %d) differs from the one-block call" % (s0, s1))
+            if problems:
+                bad[(cols, n)] = problems
+                print("cols %5d rows %5d x %5d  FAIL  %s" % (cols, n, m, "; ".join(problems)), file=sys.stderr, flush=True)
+        if verbose:
+            print("cols %5d: %d row counts" % (cols, len(ROW_COUNTS)), flush=True)
+    return bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
@@ -166,7 +218,9 @@ def main():
     ws = [int(w) for w in args.widths.split(",")] if args.widths else widths(args.quick, args.seed)
     bad = sweep(ws, args.seed)
     print("%d widths (%d .. %d), %d failing%s" % (len(ws), ws[0], ws[-1], len(bad), ": " + ",".join(map(str, sorted(bad))) if bad else ""))
-    sys.exit(1 if bad else 0)
+    bad_rows = {} if args.widths else rows_sweep(args.seed)
+    print("%d row counts x 4 widths, %d failing" % (len(ROW_COUNTS), len(bad_rows)))
+    sys.exit(1 if bad or bad_rows else 0)
 
 
 if __name__ == "__main__":
