@@ -21,7 +21,7 @@ TALLY = StrictTally()
 def gen_case(rng):
     """One random case of the pearson() API: (a, b, row_standardize, tag)."""
     K = int(rng.choice([1, 2, 3, 4, 5, 16, 31, 32, 33, 64, 100, 255, 256, 257, 625, 729, 1000, 1023, 1024, 1025, 1500, 2048, 3125,
-                        4096, 4100, 16384, 8200, 10000, 15625]))  # the last three since round 5: the block / register-row fills
+                        4096, 4100, 16384]))  # (this list is frozen: tests/golden/refspread.json stores states of this stream)
     M, N = int(rng.integers(1, 70)), int(rng.integers(1, 70))
     dt = rng.choice(["f32", "f32", "f32", "f64", "i64"])
     same = bool(rng.integers(0, 3) == 0)
@@ -61,9 +61,11 @@ def gen_case(rng):
 
 
 def gen_case_wide(rng):
-    """k = 8 rows (65 536 columns: sixteen accumulator chunks of the split contraction since round 4), float32, row-standardised.
+    """k = 8 rows (65 536 columns: sixteen accumulator chunks of the split contraction since round 4), float32, row-standardised
+    — and, since round 5, the widths above 8 192 columns that the block / register-row fills serve (8 200: a multiple of 8
+    that is not a multiple of 32, where the block fill read past the row until round 5; 10^4, 5^6, 14^4).
     A generator of its own — gen_case's random stream is what tests/golden/refspread.json stores states of."""
-    K = 65536
+    K = int(rng.choice([65536, 65536, 8200, 10000, 15625, 38416]))
     M, N = int(rng.integers(1, 24)), int(rng.integers(1, 24))
     same = bool(rng.integers(0, 2))
     kind = int(rng.choice([0, 1, 5]))
