@@ -14,7 +14,8 @@ seekr/pearson.py:35-41):
   fused       `skr_operand_fill` with centre / scale / Log2.post writing the normalised counts back == `skr_apply`, bit
               for bit, and the column of the row after the last one untouched (guard rows around the matrix);
   pearson     r of the default precision and of fp32 by tests/parity_rule.py (strict against the reference, float64 as the
-              yardstick where the reference itself is a range), self and cross comparison.
+              yardstick where the reference itself is a range), self and cross comparison; float64 rows (1e-11 from
+              numpy's float64) and `row_standardize=False`.
 
     python tools/width_sweep.py [--quick] [--widths 8200,10000] [--seed 1]
 
@@ -136,6 +137,20 @@ def check_width(L, ctx, orc, parity_rule, pearson, cols, seed):
                     problems.append("%s %s r: %s" % (prec, name, v["failures"][0]))
         finally:
             os.environ.pop("SEEKR_PRECISION", None)
+    # the other kernels behind the same call: float64 rows (the float64 contraction) and rows taken as they are
+    a64, b64 = x[:23].astype(np.float64), y.astype(np.float64)
+    with np.errstate(all="ignore"):
+        for name, a, b in (("self", a64, a64), ("cross", a64, b64)):
+            got, truth = pearson(a, b), orc.pearson_f64_truth(a, b)
+            if got.dtype != np.float64 or not np.allclose(got, truth, rtol=1e-11, atol=1e-12, equal_nan=True):
+                problems.append("float64 %s: %.3g from numpy's float64" % (name, float(np.nanmax(np.abs(got - truth)))))
+        a, b = x[:23], y
+        got = pearson(a, b, row_standardize=False).astype(np.float64)
+        ref, truth = orc.pearson(a, b, False).astype(np.float64), orc.pearson_f64_truth(a, b, False)
+    unit = float(max(np.abs(truth).max(), 1.0))
+    v = parity_rule.judge(got, ref, truth, np.isfinite(ref) & np.isfinite(truth), a, b, row_standardize=False, unit=unit)
+    if v["failures"]:
+        problems.append("rows as they are: %s" % (v["failures"][0],))
     return problems
 
 
