@@ -742,61 +742,115 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
     // "prefetch" of the next row was waited for on the spot (the fixed ~5 us per row this kernel had).  The address is
     // clamped into the vector (the ragged last piece reads the vector's LAST four cells, pieces past the end likewise) and
     // the lanes are rotated into place; cells at or past K come back as anything — every user masks them with c + j < K.
+    // The lanes are NOT rotated into place here but where the cells are used (rot4): a select right behind the load is a
+    // wait for it — vmcnt(0), hipcc even made branches of the rotation — and the mixed wave sat out its own prefetch of the
+    // next row on the spot while fifteen waves waited for it at the next barrier (2.75 -> 2.2 ms per 50 000 rows of 5^6).
     auto load4 = [&](const float* base, int c) -> f4u {
         const int cc = c + 3 < K ? c : K - 4;
-        const f4u q = *reinterpret_cast<const f4u*>(base + cc);
-        const int sh = c - cc;  // 0: a whole piece; 1 .. 3: the ragged one
-        f4u r;
-        r[0] = sh == 0 ? q[0] : (sh == 1 ? q[1] : (sh == 2 ? q[2] : q[3]));
-        r[1] = sh == 0 ? q[1] : (sh == 1 ? q[2] : q[3]);
-        r[2] = sh == 0 ? q[2] : q[3];
-        r[3] = q[3];
-        return r;
+        return *reinterpret_cast<const f4u*>(base + cc);
     };
-    f4u nx[VPT];
-    auto fetch = [&](int64_t row, f4u (&dst)[VPT]) {
+    // cell j of the piece at c is element min(j + sh, 3) of what load4 brought, sh = c - min(c, K - 4): two select stages
+    auto shift_of = [&](int c) { return c + 3 < K ? 0 : c - (K - 4); };
+    auto rot4 = [&](auto (&q)[4], int sh) {  // in place
+        const bool b0 = sh & 1, b1 = sh & 2;
+        const auto a0 = b0 ? q[1] : q[0], a1 = b0 ? q[2] : q[1], a2 = b0 ? q[3] : q[2];
+        q[0] = b1 ? a2 : a0, q[1] = b1 ? q[3] : a1, q[2] = b1 ? q[3] : a2;
+    };
+    // The body of a row, compiled twice (round 5, after the ISA showed ~130 instructions per CELL, most of them the exec-mask
+    // bookkeeping of `c + j < K` — sixteen 64-bit lane masks a thread, spilled to VGPR lanes and re-read through
+    // v_readlane — and the lane rotation of the clamped loads).  Which cells of a wave's pieces exist is a property of the
+    // WAVE: with K = 15 625 the pieces of waves 0 .. 12 are whole in every lane, waves 14 and 15 have three whole pieces
+    // and nothing behind them, and only wave 13 holds the ragged piece and the operand's zero padding.  So a wave whose
+    // first NP pieces are whole in all 64 lanes and whose others lie past the padded row runs the UNMASKED body over NP
+    // pieces (MASKED = false: no comparison with K anywhere but the one neighbour test at the end of a piece); the one or
+    // two waves around the end of the row keep the masked body (NP = VPT).  All variants meet at the same barriers.
+    auto run = [&](auto np_, auto masked_) {
+    constexpr int NP = decltype(np_)::value;
+    constexpr bool MASKED = decltype(masked_)::value;
+    // only the LAST of the NP pieces can be ragged / padding / void in some lane: the others are whole in the entire wave
+    auto M = [&](int u) { return MASKED && u == NP - 1; };
+    f4u nx[NP];
+    // (unmasked: every address is a wave-uniform base — row, piece u — plus ONE 32-bit byte offset per thread, the
+    // "saddr + voffset" form of global_load / global_store: no 64-bit address arithmetic and no address registers per piece)
+    const uint32_t tb = (uint32_t)tid * 16u;
+    // (pointer arithmetic, not an integer round trip: through uintptr_t the pointer loses its address space and the loads
+    // become FLAT ones — counted in lgkmcnt too, i.e. waited for at every LDS-only barrier below)
+    auto at = [&](auto* ubase, uint32_t bytes) {
+        typedef std::remove_pointer_t<decltype(ubase)> E;
+        return reinterpret_cast<E*>(reinterpret_cast<char*>(const_cast<std::remove_const_t<E>*>(ubase)) + bytes);
+    };
+    auto piece = [&](const float* base, int u) -> f4u {
+        if (M(u)) return load4(base, 4 * (tid + THREADS * u));
+        return *reinterpret_cast<const f4u*>(at(base + 4 * THREADS * u, tb));
+    };
+    auto fetch = [&](int64_t row) {
         const float* src = a.x + (size_t)row * K;
 #pragma unroll
-        for (int u = 0; u < VPT; u++) dst[u] = load4(src, 4 * (tid + THREADS * u));
+        for (int u = 0; u < NP; u++) nx[u] = piece(src, u);
     };
-    if (PREFETCH && (int64_t)blockIdx.x < a.rows) fetch(blockIdx.x, nx);
+    // centre and reciprocal scale of piece u: the same for every row.  Piece 0's stay in registers for the whole launch, piece
+    // u + 1's are requested while piece u is worked on — loaded at the head of each piece (as until round 5) the L2 latency
+    // of three dependent-free loads stood in front of every piece: four exposed round trips a row.
+    typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+    struct Cs { f4u m; d2u e0, e1; };
+    auto cs_load = [&](int u) -> Cs {
+        Cs o;
+        const int c = 4 * (tid + THREADS * u);
+        o.m = piece(reinterpret_cast<const float*>(a.center), u);
+        const int cc = !M(u) || c + 3 < K ? c : K - 4;  // the same clamping as load4
+        const double* rc = M(u) ? a.scale_recip + cc : at(a.scale_recip + 4 * THREADS * u, 2u * tb);
+        o.e0 = *reinterpret_cast<const d2u*>(rc), o.e1 = *reinterpret_cast<const d2u*>(rc + 2);
+        return o;
+    };
+    Cs cs0 = {};
+    if (MODE >= 1) cs0 = cs_load(0);
+    if (PREFETCH && (int64_t)blockIdx.x < a.rows) fetch(blockIdx.x);
     for (int64_t r = blockIdx.x; r < a.rows; r += gridDim.x) {
-        float v[VPT][4];
-        if (!PREFETCH) fetch(r, nx);
+        float v[NP][4];
+        if (!PREFETCH) fetch(r);
+        Cs cs = cs0;
+        // (opaque per row: hoisted out of the row loop, the sixteen sign masks `dir` expands to cost sixteen registers)
+        uint32_t dir_r = dir;
+        asm volatile("" : "+v"(dir_r));
 #pragma unroll
-        for (int u = 0; u < VPT; u++)
+        for (int u = 0; u < NP; u++) {
+            const int c = 4 * (tid + THREADS * u);
+            float q[4] = {nx[u][0], nx[u][1], nx[u][2], nx[u][3]};
+            if (M(u)) rot4(q, shift_of(c));
 #pragma unroll
-            for (int j = 0; j < 4; j++) v[u][j] = 4 * (tid + THREADS * u) + j < K ? nx[u][j] : 0.f;
+            for (int j = 0; j < 4; j++) v[u][j] = !M(u) || c + j < K ? q[j] : 0.f;
+        }
         // ---- the elementwise tail of the normalisation (kmer_counts.py:169,175,208-209) and the optional write-back
         float s = 0.f, vmin = INFINITY, vmax = -INFINITY;
 #pragma unroll
-        for (int u = 0; u < VPT; u++) {
+        for (int u = 0; u < NP; u++) {
             const int c = 4 * (tid + THREADS * u);
+            Cs cs_next = {};
+            if (MODE >= 1 && u + 1 < NP) {
+                cs_next = cs_load(u + 1);
+                __builtin_amdgcn_sched_barrier(0);  // requested BEFORE this piece's arithmetic, not wherever the scheduler sinks them
+            }
             if (MODE >= 1) {
                 // x / scale as float(double(x) * (1 / double(scale))): three instructions instead of an IEEE division, the same
                 // bits (the register kernel's div_by_recip; the reciprocals are made once per launch: recip64_kernel)
-                const f4u m = load4(reinterpret_cast<const float*>(a.center), c);
-                // the reciprocals (float64): the same clamping, two 16-byte loads, rotated by the same shift
-                const int cc = c + 3 < K ? c : K - 4, sh = c - cc;
-                typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
-                const d2u e0 = *reinterpret_cast<const d2u*>(a.scale_recip + cc), e1 = *reinterpret_cast<const d2u*>(a.scale_recip + cc + 2);
-                double d[4];
-                d[0] = sh == 0 ? e0[0] : (sh == 1 ? e0[1] : (sh == 2 ? e1[0] : e1[1]));
-                d[1] = sh == 0 ? e0[1] : (sh == 1 ? e1[0] : e1[1]);
-                d[2] = sh == 0 ? e1[0] : e1[1];
-                d[3] = e1[1];
+                // centre and reciprocals of the mixed piece: clamped like the cells, rotated by the same shift, here
+                float m[4] = {cs.m[0], cs.m[1], cs.m[2], cs.m[3]};
+                double d[4] = {cs.e0[0], cs.e0[1], cs.e1[0], cs.e1[1]};
+                if (M(u)) rot4(m, shift_of(c)), rot4(d, shift_of(c));
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (c + j < K) {
-                        float t = div_by_recip(__fsub_rn(v[u][j], m[j]), d[j]);
-                        if (t != t) any_nan = true;
-                        if (MODE == 2) t = skr_log2_of_sum1(__fadd_rn(t, a.shift));
-                        v[u][j] = t;
-                    }
+                for (int j = 0; j < 4; j++) {
+                    // (no branch around a cell: the mixed piece computes every lane and SELECTS — a cell past the row is 0
+                    // before and after; as `if (c + j < K) { ... }` each cell was an exec-mask region of its own)
+                    const bool ok = !M(u) || c + j < K;
+                    float t = div_by_recip(__fsub_rn(v[u][j], m[j]), d[j]);
+                    any_nan |= ok && t != t;
+                    if (MODE == 2) t = skr_log2_of_sum1(__fadd_rn(t, a.shift));
+                    v[u][j] = ok ? t : 0.f;
+                }
             }
-            if (HASY && c < K) {
-                float* yr = a.y + (size_t)r * K + c;
-                if (c + 3 < K) {
+            if (HASY && (!M(u) || c < K)) {
+                float* yr = at(a.y + (size_t)r * K + 4 * THREADS * u, tb);
+                if (!M(u) || c + 3 < K) {
                     *reinterpret_cast<f4u*>(yr) = f4u{v[u][0], v[u][1], v[u][2], v[u][3]};
                 } else {
 #pragma unroll
@@ -805,19 +859,20 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (c + j < K) {
-                    s += v[u][j];
-                    vmin = fminf(vmin, v[u][j]);
-                    vmax = fmaxf(vmax, v[u][j]);
-                }
+            for (int j = 0; j < 4; j++) {
+                const bool ok = !M(u) || c + j < K;
+                s += v[u][j];  // (a cell past the row holds 0)
+                vmin = fminf(vmin, ok ? v[u][j] : INFINITY);
+                vmax = fmaxf(vmax, ok ? v[u][j] : -INFINITY);
+            }
             if (sizeof(T) != 4 && lane == 0) edge[u][wave] = v[u][0];  // the first cell of this wave's piece: the wave before needs it
             __builtin_amdgcn_sched_barrier(0);
+            cs = cs_next;
         }
         // The next row's pieces, requested HERE: behind this row's centre / scale loads (vmcnt counts in order — a wait for
         // those would otherwise sit out the prefetch too) and in front of everything that only computes and stores.  The last
         // iteration re-reads its own row: an unconditional load (load4).
-        if (PREFETCH) fetch(r + gridDim.x < a.rows ? r + gridDim.x : r, nx);
+        if (PREFETCH) fetch(r + gridDim.x < a.rows ? r + gridDim.x : r);
         // ---- row statistics in the order pearson.py:35-38 computes them; minimum and maximum ride on the first barrier
         // the row sum, minimum and maximum ride on ONE barrier
         float nmin = -vmin;
@@ -829,42 +884,42 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
         if (sizeof(T) != 4) {
             // how much of the row one value holds: its minimum, or — neighbouring cells equal — any value (block kernel)
 #pragma unroll
-            for (int u = 0; u < VPT; u++) {
+            for (int u = 0; u < NP; u++) {
                 const int c = 4 * (tid + THREADS * u);
                 // the cell after this piece: the next lane's first one; lane 63: the next wave's (the last wave: piece u + 1 of wave 0)
                 float nxt = __shfl_down(v[u][0], 1, 64);
                 if (lane == 63) nxt = wave + 1 < WAVES ? edge[u][wave + 1] : (u + 1 < VPT ? edge[u + 1 < VPT ? u + 1 : u][0] : 0.f);
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (c + j < K) {
-                        same += (float)(v[u][j] == vmin);
-                        const float after = j < 3 ? v[u][j + 1] : nxt;
-                        if (c + j + 1 < K) adj += (float)(v[u][j] == after);
-                    }
+                for (int j = 0; j < 4; j++) {
+                    const bool ok = !M(u) || c + j < K;
+                    same += (float)(ok && v[u][j] == vmin);
+                    const float after = j < 3 ? v[u][j + 1] : nxt;
+                    // (the cell after a whole piece is the one comparison with K the unmasked body keeps: the row may end there)
+                    const bool ok_after = (!M(u) && j < 3) || c + j + 1 < K;
+                    adj += (float)(ok_after && v[u][j] == after);
+                }
             }
         }
         if (a.row_standardize) {
             mean = s / kf;
             s = 0.f;
 #pragma unroll
-            for (int u = 0; u < VPT; u++) {
+            for (int u = 0; u < NP; u++) {
                 const int c = 4 * (tid + THREADS * u);
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (c + j < K) s += v[u][j] - mean;
+                for (int j = 0; j < 4; j++) s += !M(u) || c + j < K ? v[u][j] - mean : 0.f;
             }
             reduce3(s, same, adj, kSum, kSum, kSum);
             const float m2 = s / kf;
             s = 0.f;
 #pragma unroll
-            for (int u = 0; u < VPT; u++) {
+            for (int u = 0; u < NP; u++) {
                 const int c = 4 * (tid + THREADS * u);
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (c + j < K) {
-                        const float dd = (v[u][j] - mean) - m2;
-                        s += dd * dd;
-                    }
+                for (int j = 0; j < 4; j++) {
+                    const float dd = !M(u) || c + j < K ? (v[u][j] - mean) - m2 : 0.f;
+                    s += dd * dd;
+                }
             }
             float z2 = 0.f, z3 = 0.f;
             reduce3(s, z2, z3, kSum, kSum, kSum);
@@ -886,14 +941,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
         // ---- standardise, split, store (operand rows are zero-padded to whole 32-column tiles)
         float sq = 0.f, m3 = 0.f, m4 = 0.f;
 #pragma unroll
-        for (int u = 0; u < VPT; u++) {
+        for (int u = 0; u < NP; u++) {
             const int i = tid + THREADS * u, k0 = 4 * i;
-            if (i >= n4p) continue;
+            if (M(u) && i >= n4p) continue;
             float z[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                float t = k0 + j < K ? v[u][j] : 0.f;
-                if (a.row_standardize && k0 + j < K) t = div_by_recip(__fsub_rn(t, mean), rsd);
+                float t = v[u][j];  // (0 past the row)
+                if (a.row_standardize) t = !M(u) || k0 + j < K ? div_by_recip(__fsub_rn(t, mean), rsd) : 0.f;
                 z[j] = t;
                 sq = __fmaf_rn(t, t, sq);
                 if (sizeof(T) != 4) {
@@ -903,18 +958,21 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
                 }
             }
             if (sizeof(T) == 4) {
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + (size_t)r * Kp + k0) = make_float4(z[0], z[1], z[2], z[3]);
+                float* dst = at(reinterpret_cast<float*>(a.out) + (size_t)r * Kp + 4 * THREADS * u, tb);
+                *reinterpret_cast<float4*>(dst) = make_float4(z[0], z[1], z[2], z[3]);
             } else {
                 vec4h<T> hi, lo;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const float zs = z[j] * a.out_scale;
                     if (fabsf(zs) > 65504.f) overflow = true;
-                    const T hh = split_hi_flip<T>(zs, ((dir >> (u * 4 + j)) & 1u) << 31);
+                    const T hh = split_hi_flip<T>(zs, (dir_r << (31 - (u * 4 + j))) & 0x80000000u);
                     hi[j] = hh;
                     lo[j] = (T)(zs - (float)hh);
                 }
-                T* dst = reinterpret_cast<T*>(a.out) + ((size_t)r * a.kt + (k0 >> 5)) * 64 + (k0 & 31);
+                // piece i = tid + THREADS u sits in tile i / 8, columns 4 (i % 8): (tid / 8) tiles + THREADS / 8 tiles a piece
+                T* dst = at(reinterpret_cast<T*>(a.out) + ((size_t)r * a.kt + (THREADS / 8) * u) * 64,
+                            (uint32_t)(((tid >> 3) * 64 + 4 * (tid & 7)) * sizeof(T)));
                 *reinterpret_cast<vec4h<T>*>(dst) = hi;
                 *reinterpret_cast<vec4h<T>*>(dst + 32) = lo;
             }
@@ -925,6 +983,25 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
         if (sizeof(T) != 4 && a.row_standardize && row_on_two_levels(sq / kf, m3 / kf, m4 / kf)) coherent = true;
         if (sizeof(T) != 4 && row_needs_fp32(zmax2, kf)) outlier = true;
     }
+    };
+    // which body this wave runs: pieces [0, whole) are whole in every lane of the wave; piece `whole` is either entirely past
+    // the padded row (then so are the ones behind it) or MIXED — the ragged piece, the operand's zero padding, lanes past it
+    int whole = 0;
+#pragma unroll
+    for (int u = 0; u < VPT; u++) {
+        const int last = wave * 64 + 63 + THREADS * u;
+        if (4 * last + 3 < K && whole == u) whole = u + 1;
+    }
+    whole = __builtin_amdgcn_readfirstlane(whole);
+    const bool mixed = whole < VPT && wave * 64 + THREADS * whole < n4p;
+    // (the launch condition — more than 2 x 4 096 columns — makes the first two pieces of every wave whole)
+    static_assert(VPT == 4, "bodies for 2, 3 and 4 pieces");
+    if (whole == 4) run(std::integral_constant<int, 4>(), std::false_type());
+    else if (whole == 3 && !mixed) run(std::integral_constant<int, 3>(), std::false_type());
+    else if (whole == 3) run(std::integral_constant<int, 4>(), std::true_type());
+    else if (whole == 2 && !mixed) run(std::integral_constant<int, 2>(), std::false_type());
+    else if (whole == 2) run(std::integral_constant<int, 3>(), std::true_type());
+    else __builtin_trap();
     if (any_nan) atomicOr(&a.flags[1], 1u);
     if (overflow) atomicOr(&a.flags[3], 1u);
     if (outlier) atomicOr(&a.flags[4], 1u);
@@ -1338,9 +1415,10 @@ int launch_fill(skr_ctx* ctx, const skr_operand* op, const FillArgs& a_in) {
 #undef LAUNCH_REG
 #undef LAUNCH_REG2
         SKR_HIP(hipGetLastError());
-    } else if (reg_mode >= 0 && op->kind != 3 && (a.cols & 7) != 0 && a.cols > 8192 && a.cols <= 16384) {
-        // round 5: odd widths of 8 193 .. 16 384 columns (5^6, 7^5 ...) — the row in the registers of a sixteen-wave
-        // workgroup (operand_fill_rowreg_kernel); widths below stay with the wave-per-row kernel and its numpy-ordered
+    } else if (reg_mode >= 0 && op->kind != 3 && a.cols > 8192 && a.cols <= 16384) {
+        // round 5: ANY width of 8 193 .. 16 384 columns but 4^7 (5^6, 10^4, 22^3 ...) — the row in the registers of a
+        // sixteen-wave workgroup (operand_fill_rowreg_kernel; multiples of 8 too: the block kernel below takes 3.1 ms where
+        // this one takes 1.8 on 50 000 x 15 632); widths below stay with the wave-per-row kernel and its numpy-ordered
         // sums, everything else with the block kernel (a 65 536-cell row in registers, 64 per thread, spills: measured)
         FillArgs a = a_in;
         if (reg_mode >= 1) {  // float64 reciprocals of the scale vector (as for the register kernels above)
