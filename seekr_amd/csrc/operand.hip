@@ -81,6 +81,14 @@ __device__ __forceinline__ float row16_all(float v) {  // every lane: the reduct
     v = dpp_step_c<IS_MAX, 0x140>(v);  // row_mirror
     return v;
 }
+template <bool IS_MAX, int N>
+__device__ __forceinline__ float rowN_all(float v) {  // every lane: the reduction over its 16 (or 8) neighbouring lanes
+    v = dpp_step_c<IS_MAX, 0xB1>(v);
+    v = dpp_step_c<IS_MAX, 0x4E>(v);
+    v = dpp_step_c<IS_MAX, 0x141>(v);
+    if (N == 16) v = dpp_step_c<IS_MAX, 0x140>(v);
+    return v;
+}
 template <bool IS_MAX>
 __device__ __forceinline__ float wave64_all(float v) {  // every lane: the reduction over the wave
     v = row16_all<IS_MAX>(v);
@@ -690,11 +698,11 @@ using vec4h = T __attribute__((ext_vector_type(4)));
 // The arithmetic per cell is the block kernel's; the row SUMS are taken in another order (16 waves, pieces lane after
 // lane), so mean and std of a row — and with them the last bits of r — are those of this kernel wherever it serves.
 template <typename T, int VPT, int MODE, bool HASY, int THREADS>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) void operand_fill_rowreg_kernel(FillArgs a) {
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == 512 ? 2 : 4))) void operand_fill_rowreg_kernel(FillArgs a) {
     constexpr int WAVES = THREADS / 64;
     // 1 024 threads: one workgroup per CU (128 registers a thread), the next row prefetched; 512 threads: two workgroups per
     // CU, each on its own row and in its own phase — no prefetch needed, the other workgroup fills the waits
-    constexpr bool PREFETCH = THREADS == 1024;
+    constexpr bool PREFETCH = THREADS == 1024 && VPT <= 4;  // (a 65 536-cell row, 64 cells a thread: no room for a second one)
     typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
     __shared__ float red[2][3][WAVES];
     __shared__ float edge[VPT][WAVES];
@@ -720,23 +728,23 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         // every row of 16 lanes folds the 16 partials by itself — one LDS read and four DPP steps per quantity (reading all
         // 48 partials into registers, on top of this row and the next, is what made the kernel spill)
-        static_assert(WAVES == 16, "a row of 16 lanes folds the 16 partials");
-        p0 = row16_all<M0>(slot[0][lane & 15]);
-        p1 = row16_all<M1>(slot[1][lane & 15]);
-        p2 = row16_all<M2>(slot[2][lane & 15]);
+        static_assert(WAVES == 16 || WAVES == 8, "a row of 16 lanes (or half of one) folds the partials");
+        p0 = rowN_all<M0, WAVES>(slot[0][lane & (WAVES - 1)]);
+        p1 = rowN_all<M1, WAVES>(slot[1][lane & (WAVES - 1)]);
+        p2 = rowN_all<M2, WAVES>(slot[2][lane & (WAVES - 1)]);
     };
     const std::true_type kMax;
     const std::false_type kSum;
     // rounding direction of the hi half of each of this thread's VPT * 4 cells, one bit per cell (a hash of the COLUMN: the
     // same for every row)
-    uint32_t dir = 0;
+    constexpr int DIRW = (VPT * 4 + 31) / 32;
+    uint32_t dir[DIRW] = {};
     if (sizeof(T) == 2) {
 #pragma unroll
         for (int u = 0; u < VPT; u++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) dir |= (split_flip(4 * (tid + THREADS * u) + j) >> 31) << (u * 4 + j);
+            for (int j = 0; j < 4; j++) dir[(u * 4 + j) >> 5] |= (split_flip(4 * (tid + THREADS * u) + j) >> 31) << ((u * 4 + j) & 31);
     }
-    static_assert(VPT * 4 <= 32, "one bit per cell in a 32-bit word");
     // Cells c .. c + 3 of a K-cell float vector WITHOUT a branch: hipcc answers a load inside a branch with s_waitcnt
     // vmcnt(0) right behind it — the four pieces of a row came in one after the other, each at full latency, and the
     // "prefetch" of the next row was waited for on the spot (the fixed ~5 us per row this kernel had).  The address is
@@ -783,6 +791,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
         if (M(u)) return load4(base, 4 * (tid + THREADS * u));
         return *reinterpret_cast<const f4u*>(at(base + 4 * THREADS * u, tb));
     };
+    uint64_t nan_lanes = 0;
+    auto unordered = [&](float x, float y) -> uint64_t {  // lanes in which x or y is NaN
+        uint64_t lanes;
+        asm volatile("v_cmp_u_f32_e64 %0, %1, %2" : "=s"(lanes) : "v"(x), "v"(y));
+        return lanes;
+    };
     auto fetch = [&](int64_t row) {
         const float* src = a.x + (size_t)row * K;
 #pragma unroll
@@ -793,25 +807,36 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
     // of three dependent-free loads stood in front of every piece: four exposed round trips a row.
     typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
     struct Cs { f4u m; d2u e0, e1; };
+    // (the two vectors through pointers that are made opaque once per row: the loads are loop-invariant, and hoisted out of
+    // the row loop by the compiler — all of them, twelve registers a piece — they are what made the 32-piece body spill)
+    const float* center_p = reinterpret_cast<const float*>(a.center);
+    const double* recip_p = a.scale_recip;
     auto cs_load = [&](int u) -> Cs {
         Cs o;
         const int c = 4 * (tid + THREADS * u);
-        o.m = piece(reinterpret_cast<const float*>(a.center), u);
+        o.m = piece(center_p, u);
         const int cc = !M(u) || c + 3 < K ? c : K - 4;  // the same clamping as load4
-        const double* rc = M(u) ? a.scale_recip + cc : at(a.scale_recip + 4 * THREADS * u, 2u * tb);
+        const double* rc = M(u) ? recip_p + cc : at(recip_p + 4 * THREADS * u, 2u * tb);
         o.e0 = *reinterpret_cast<const d2u*>(rc), o.e1 = *reinterpret_cast<const d2u*>(rc + 2);
         return o;
     };
+    constexpr bool RESIDENT0 = VPT <= 4;  // (64 cells a thread leave no twelve registers for it: piece 0's are loaded per row)
     Cs cs0 = {};
-    if (MODE >= 1) cs0 = cs_load(0);
+    if (MODE >= 1 && RESIDENT0) cs0 = cs_load(0);
     if (PREFETCH && (int64_t)blockIdx.x < a.rows) fetch(blockIdx.x);
     for (int64_t r = blockIdx.x; r < a.rows; r += gridDim.x) {
         float v[NP][4];
         if (!PREFETCH) fetch(r);
         Cs cs = cs0;
+        asm volatile("" : "+s"(center_p), "+s"(recip_p));
+        if (MODE >= 1 && !RESIDENT0) cs = cs_load(0);
         // (opaque per row: hoisted out of the row loop, the sixteen sign masks `dir` expands to cost sixteen registers)
-        uint32_t dir_r = dir;
-        asm volatile("" : "+v"(dir_r));
+        uint32_t dir_r[DIRW];
+#pragma unroll
+        for (int w = 0; w < DIRW; w++) {
+            dir_r[w] = dir[w];
+            asm volatile("" : "+v"(dir_r[w]));
+        }
 #pragma unroll
         for (int u = 0; u < NP; u++) {
             const int c = 4 * (tid + THREADS * u);
@@ -837,15 +862,20 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
                 float m[4] = {cs.m[0], cs.m[1], cs.m[2], cs.m[3]};
                 double d[4] = {cs.e0[0], cs.e0[1], cs.e1[0], cs.e1[1]};
                 if (M(u)) rot4(m, shift_of(c)), rot4(d, shift_of(c));
+                float t[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) t[j] = div_by_recip(__fsub_rn(v[u][j], m[j]), d[j]);
+                // NaN among the quotients, tested HERE (volatile): left to the compiler, every `t != t` of a row was deferred to
+                // the end of the row and the sixty-four quotients of a 4^8 row kept alive (spilled) next to their logarithms
+                if (!M(u)) nan_lanes |= unordered(t[0], t[1]) | unordered(t[2], t[3]);
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     // (no branch around a cell: the mixed piece computes every lane and SELECTS — a cell past the row is 0
                     // before and after; as `if (c + j < K) { ... }` each cell was an exec-mask region of its own)
                     const bool ok = !M(u) || c + j < K;
-                    float t = div_by_recip(__fsub_rn(v[u][j], m[j]), d[j]);
-                    any_nan |= ok && t != t;
-                    if (MODE == 2) t = skr_log2_of_sum1(__fadd_rn(t, a.shift));
-                    v[u][j] = ok ? t : 0.f;
+                    if (M(u)) any_nan |= ok && t[j] != t[j];
+                    if (MODE == 2) t[j] = skr_log2_of_sum1(__fadd_rn(t[j], a.shift));
+                    v[u][j] = ok ? t[j] : 0.f;
                 }
             }
             if (HASY && (!M(u) || c < K)) {
@@ -966,7 +996,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
                 for (int j = 0; j < 4; j++) {
                     const float zs = z[j] * a.out_scale;
                     if (fabsf(zs) > 65504.f) overflow = true;
-                    const T hh = split_hi_flip<T>(zs, (dir_r << (31 - (u * 4 + j))) & 0x80000000u);
+                    const T hh = split_hi_flip<T>(zs, (dir_r[(u * 4 + j) >> 5] << (31 - ((u * 4 + j) & 31))) & 0x80000000u);
                     hi[j] = hh;
                     lo[j] = (T)(zs - (float)hh);
                 }
@@ -983,6 +1013,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
         if (sizeof(T) != 4 && a.row_standardize && row_on_two_levels(sq / kf, m3 / kf, m4 / kf)) coherent = true;
         if (sizeof(T) != 4 && row_needs_fp32(zmax2, kf)) outlier = true;
     }
+    if (nan_lanes) any_nan = true;
     };
     // which body this wave runs: pieces [0, whole) are whole in every lane of the wave; piece `whole` is either entirely past
     // the padded row (then so are the ones behind it) or MIXED — the ragged piece, the operand's zero padding, lanes past it
@@ -995,10 +1026,13 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4))) vo
     whole = __builtin_amdgcn_readfirstlane(whole);
     const bool mixed = whole < VPT && wave * 64 + THREADS * whole < n4p;
     // (the launch condition — more than 2 x 4 096 columns — makes the first two pieces of every wave whole)
-    static_assert(VPT == 4, "bodies for 2, 3 and 4 pieces");
-    if (whole == 4) run(std::integral_constant<int, 4>(), std::false_type());
+    static_assert(VPT == 4 || VPT == 16, "bodies for 2, 3 and 4 pieces, or for exactly 16 whole ones (4^8 columns)");
+    if (VPT == 16) {
+        if (whole == VPT && !mixed) run(std::integral_constant<int, VPT>(), std::false_type());
+        else __builtin_trap();
+    } else if (whole == 4) run(std::integral_constant<int, 4>(), std::false_type());
     else if (whole == 3 && !mixed) run(std::integral_constant<int, 3>(), std::false_type());
-    else if (whole == 3) run(std::integral_constant<int, 4>(), std::true_type());
+    else if (whole == 3) run(std::integral_constant<int, VPT == 4 ? 4 : 1>(), std::true_type());
     else if (whole == 2 && !mixed) run(std::integral_constant<int, 2>(), std::false_type());
     else if (whole == 2) run(std::integral_constant<int, 3>(), std::true_type());
     else __builtin_trap();
@@ -1449,6 +1483,35 @@ int launch_fill(skr_ctx* ctx, const skr_operand* op, const FillArgs& a_in) {
         else if (op->kind == 1) LAUNCH_ROWREG(__bf16);
         else LAUNCH_ROWREG(_Float16);
 #undef LAUNCH_ROWREG
+        SKR_HIP(hipGetLastError());
+    } else if (reg_mode >= 0 && op->kind != 3 && a.cols == 65536 && !getenv("SEEKR_DBG_NO_ROWREG16")) {
+        FillArgs a = a_in;
+        if (reg_mode >= 1) {
+            if (ctx->d_recip_len < (size_t)a.cols) {
+                if (ctx->d_recip) SKR_HIP(hipFree(ctx->d_recip));
+                ctx->d_recip = nullptr;
+                ctx->d_recip_len = 0;
+                SKR_HIP(hipMalloc((void**)&ctx->d_recip, (size_t)a.cols * sizeof(double)));
+                ctx->d_recip_len = (size_t)a.cols;
+            }
+            hipLaunchKernelGGL(recip64_kernel, dim3((unsigned)((a.cols + 255) / 256)), dim3(256), 0, ctx->stream,
+                               reinterpret_cast<const float*>(a.scale), ctx->d_recip, a.cols);
+            a.scale_recip = ctx->d_recip;
+        }
+        SkrProfScope prof(ctx, "operand_fill");
+        const unsigned rgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(a.rows, (int64_t)ctx->num_cu));
+#define LAUNCH_ROWREG16(T)                                                                                                  \
+    do {                                                                                                                    \
+        if (reg_mode == 0) hipLaunchKernelGGL((operand_fill_rowreg_kernel<T, 16, 0, false, 1024>), dim3(rgrid), dim3(1024), 0, ctx->stream, a);      \
+        else if (reg_mode == 1 && a.y) hipLaunchKernelGGL((operand_fill_rowreg_kernel<T, 16, 1, true, 1024>), dim3(rgrid), dim3(1024), 0, ctx->stream, a); \
+        else if (reg_mode == 1) hipLaunchKernelGGL((operand_fill_rowreg_kernel<T, 16, 1, false, 1024>), dim3(rgrid), dim3(1024), 0, ctx->stream, a); \
+        else if (a.y) hipLaunchKernelGGL((operand_fill_rowreg_kernel<T, 16, 2, true, 1024>), dim3(rgrid), dim3(1024), 0, ctx->stream, a);             \
+        else hipLaunchKernelGGL((operand_fill_rowreg_kernel<T, 16, 2, false, 1024>), dim3(rgrid), dim3(1024), 0, ctx->stream, a);                    \
+    } while (0)
+        if (op->kind == 0) LAUNCH_ROWREG16(float);
+        else if (op->kind == 1) LAUNCH_ROWREG16(__bf16);
+        else LAUNCH_ROWREG16(_Float16);
+#undef LAUNCH_ROWREG16
         SKR_HIP(hipGetLastError());
     } else if (row_floats * 4 >= 32 * 1024) {  // k >= 7: one workgroup per row
         SkrProfScope prof(ctx, "operand_fill");
