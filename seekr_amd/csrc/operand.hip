@@ -1484,7 +1484,12 @@ int launch_fill(skr_ctx* ctx, const skr_operand* op, const FillArgs& a_in) {
         else LAUNCH_ROWREG(_Float16);
 #undef LAUNCH_ROWREG
         SKR_HIP(hipGetLastError());
-    } else if (reg_mode >= 0 && op->kind != 3 && a.cols == 65536 && !getenv("SEEKR_DBG_NO_ROWREG16")) {
+    } else if (reg_mode >= 0 && op->kind != 3 && a.cols == 65536) {
+        // round 5: 4^8 columns — the same kernel with sixteen pieces (64 cells) a thread and no second row in flight: ONE read
+        // of the 256 KB row instead of the block kernel's four (its passes re-read the row through an L2 that 256 rows in
+        // flight overflow), 8.84 -> 3.79 ms per 20 000 rows in the pipeline form, 9.3 -> 2.3 bare.  Every piece of every
+        // wave is whole at this width; other widths above 16 384 would need the mixed-piece bodies for up to sixteen
+        // pieces and stay with the block kernel.
         FillArgs a = a_in;
         if (reg_mode >= 1) {
             if (ctx->d_recip_len < (size_t)a.cols) {
