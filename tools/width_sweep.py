@@ -44,6 +44,8 @@ def widths(quick, seed):
     w.update(int(v) * 8 + 4 for v in rng.integers(17, 8750, 10 if quick else 40))       # multiples of 4 only
     w.update(int(v) for v in rng.integers(131, 70000, 30 if quick else 150))             # anything
     named = {8200, 10000, 10648, 15625, 16807, 19683, 20736, 38416, 40004, 46656, 50625, 59049, 69999}  # alphabet^k widths
+    if not quick:
+        named |= {78125, 100000, 117649, 160000, 262144}  # 5^7, 10^5, 7^6, 20^4, 4^9: beyond the split-fp16 kernel's widths
     if quick:  # thin the neighbourhoods: every third neighbour of the thresholds above 256
         w = {v for v in w if v <= 300 or v % 3 != 1 or v % 8 == 0}
     return sorted(v for v in w | named if v >= 1)
