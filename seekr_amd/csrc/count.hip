@@ -722,7 +722,8 @@ __global__ __launch_bounds__(kThreads) void convert_generic_kernel(const uint32_
 // (memset of a uint32 histogram in HBM + L2 atomics + a conversion pass: >= 3 x the row bytes, plus the upload inside the
 // call) the device traffic is the row write alone: 1 + 4 A^k / L bytes per base (SURVEY 8d's ASCII figure).
 constexpr int kGenChunk = 4096;
-constexpr int64_t kGenLdsBins = 16384;
+constexpr int64_t kGenLdsBins = 36864;  // 144 KiB of bins + 8.6 KiB of tables and codes: ONE workgroup per CU above 19 K bins (round 5: was
+                                        // 16 384 — 7^5, 3^9, 12^4, 8^5 columns went through the histogram in HBM at 0.04 of the peak)
 
 constexpr int kGenThreads = 1024;  // two workgroups of 16 waves per CU at 62.5 KiB of bins: the flush is a latency-bound loop of
                                    // dword stores, so what counts is how many of them are in flight (256 threads: 1.32 ms for
@@ -731,7 +732,10 @@ constexpr int kGenThreads = 1024;  // two workgroups of 16 waves per CU at 62.5 
 // 0.76 ms — the sub-dword LDS reads and writes of the flush cost more than the halved footprint buys;
 // profiles/r5_generic_width_arms.log.  Not kept.)
 template <typename OutT, bool LOG2>
-__global__ __launch_bounds__(kGenThreads) void count_generic_lds_kernel(const unsigned char* __restrict__ bases,
+// (at most 72 SGPRs: with the 86 the compiler would take, the CU holds ONE sixteen-wave workgroup of this kernel instead of two —
+// hipOccupancyMaxActiveBlocksPerMultiprocessor says two either way; measured with per-workgroup start times: the second 256
+// workgroups started when the first 256 had ended.  The surplus goes to VGPR lanes, 18 of them.)
+__global__ __launch_bounds__(kGenThreads) __attribute__((amdgpu_num_vgpr(56), amdgpu_num_sgpr(72))) void count_generic_lds_kernel(const unsigned char* __restrict__ bases,
                                                                   const int64_t* __restrict__ offsets, int64_t n_seqs, int k,
                                                                   int alen, uint32_t nbins, GenericLut lut,
                                                                   OutT* __restrict__ out) {
@@ -745,30 +749,63 @@ __global__ __launch_bounds__(kGenThreads) void count_generic_lds_kernel(const un
     for (uint32_t b = tid; b < words_pad; b += kGenThreads) glds[b] = 0;
     if (tid < 256) lutb[tid] = lut.code[tid];
     __syncthreads();
-    // Round 5: the characters of the NEXT sequence's first chunk are requested before this sequence's flush (offsets -> bases:
-    // two dependent global loads that used to stand in front of every sequence, ~3 of the 7.7 us a 2 kb sequence took) and
-    // sit in kGenPre registers per thread until the next turn of the loop translates them.
+    // Round 5: the characters of the NEXT sequence's first chunk are requested at the TOP of this sequence's turn (its
+    // offsets were read one turn earlier still), translated into a SECOND code buffer after this sequence's histogram and
+    // found there, ready, by the next turn: no load stands in front of a sequence, the translate phase and its barrier are
+    // gone, and — the point — nothing at the top of a turn depends on vmcnt any more.  The first form (characters requested
+    // before the flush, consumed at the top of the next turn) made every wave wait there for vmcnt(0): the loads are older
+    // than the flush's stores, but the number of stores a wave issues in a loop is not known to the compiler, so "the loads
+    // have landed" became "everything has landed" and each turn sat out the write latency of its own row.  All barriers of
+    // the loop wait for the LDS only (every hazard in it is an LDS one).
     constexpr int kGenPre = (kGenChunk + 64 + kGenThreads - 1) / kGenThreads;
-    unsigned char pre[kGenPre];
-    int64_t pre_off = 0, pre_len = 0;
-    auto prefetch = [&](int64_t sn) {
-        if (sn >= n_seqs) return;
-        pre_off = offsets[sn];
-        pre_len = offsets[sn + 1] - pre_off;
-        const int64_t n_first = std::min<int64_t>(pre_len, kGenChunk + k - 1);
-#pragma unroll
-        for (int j = 0; j < kGenPre; j++) {
-            const int64_t i = tid + (int64_t)kGenThreads * j;
-            pre[j] = i < n_first && i < kGenChunk + 64 ? bases[pre_off + i] : 0;
+    int8_t* codes_next = codes + kGenChunk + 64;
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    const int64_t stride = gridDim.x;
+    // characters in flight: `pre` for the next sequence (requested one turn ago), `pre2` for the one after it (requested at the
+    // top of this turn).  The requests are UNCONDITIONAL loads of exactly kGenPre bytes a thread (addresses clamped into the
+    // buffer): the wait in front of the translation can then be "all but the kGenPre youngest" — with loads inside
+    // `i < n ? ... : 0` branches the compiler cannot count them and waits for everything, i.e. for the request it has just made.
+    unsigned char pre[kGenPre], pre2[kGenPre];
+    const int64_t last_byte = std::max<int64_t>(offsets[n_seqs] - 1, 0);
+    auto read_offsets = [&](int64_t sn, int64_t& off, int64_t& len) {
+        off = 0, len = 0;
+        if (sn < n_seqs) {
+            off = offsets[sn];
+            len = offsets[sn + 1] - off;
         }
     };
-    prefetch(blockIdx.x);
-    for (int64_t s = blockIdx.x; s < n_seqs; s += gridDim.x) {
-        const unsigned char* seq = bases + pre_off;
-        const int64_t len = pre_len;
-        unsigned char mine[kGenPre];
+    // (32-bit lane arithmetic throughout the loop: the kernel is bound by VALU issue — a wave64 instruction takes four cycles —
+    // and 64-bit compares / adds per character and per window were a third of what a turn issued)
+    auto request = [&](unsigned char (&dst)[kGenPre], int64_t off) {  // the first chunk's characters of the sequence at `off`
+        const unsigned char* base = bases + off;  // wave-uniform
+        const uint32_t lim = (uint32_t)std::min<int64_t>(last_byte - std::min<int64_t>(off, last_byte), kGenChunk + 64);
 #pragma unroll
-        for (int j = 0; j < kGenPre; j++) mine[j] = pre[j];
+        for (int j = 0; j < kGenPre; j++) dst[j] = base[std::min<uint32_t>((uint32_t)tid + (uint32_t)kGenThreads * j, lim)];
+    };
+    auto translate = [&](int8_t* dst, const unsigned char (&src)[kGenPre], int64_t len) {
+        const uint32_t n_first = (uint32_t)std::min<int64_t>(std::min<int64_t>(len, kGenChunk + k - 1), kGenChunk + 64);
+#pragma unroll
+        for (int j = 0; j < kGenPre; j++) {
+            const uint32_t i = (uint32_t)tid + (uint32_t)kGenThreads * j;
+            if (i < n_first) dst[i] = lutb[src[j]];
+        }
+    };
+    int64_t cur_off, cur_len, nxt_off, nxt_len, nn_off, nn_len;
+    read_offsets(blockIdx.x, cur_off, cur_len);
+    read_offsets(blockIdx.x + stride, nxt_off, nxt_len);
+    read_offsets(blockIdx.x + 2 * stride, nn_off, nn_len);
+    request(pre, cur_off);
+    translate(codes, pre, cur_len);
+    request(pre, nxt_off);
+    lds_barrier();
+    // one sequence; `use` holds the NEXT sequence's characters (requested a turn ago), `req` takes those of the one after it —
+    // the two register sets swap roles from turn to turn (a copy would be a wait for the request just made)
+    auto turn = [&](int64_t s, unsigned char (&use)[kGenPre], unsigned char (&req)[kGenPre], int8_t* codes, int8_t* codes_next) {
+        const unsigned char* seq = bases + cur_off;
+        const int64_t len = cur_len;
+        request(req, nn_off);  // the sequence after next: a whole turn to land
+        int64_t n3_off, n3_len;
+        read_offsets(s + 3 * stride, n3_off, n3_len);
         const int64_t W = len - k + 1;  // windows, counting every character (kmer_counts.py:143-144)
         const double inc = W > 0 ? 1000.0 / (double)W : 0.0;
         if (!std::is_same<OutT, uint32_t>::value && sizeof(OutT) == 4 && tid < kTabSize) {
@@ -776,34 +813,36 @@ __global__ __launch_bounds__(kGenThreads) void count_generic_lds_kernel(const un
             if (LOG2) t = skr_log2_cr(t + 1.0f);
             tab[tid] = t;
         }
-        __syncthreads();  // the table is read by every wave's flush — also for a sequence without a single window (W <= 0:
-                          // no chunk, hence no other barrier in between; found by the differential fuzzer)
         for (int64_t c0 = 0; c0 < W; c0 += kGenChunk) {
-            const int64_t n_char = std::min<int64_t>(std::min<int64_t>(len - c0, kGenChunk + k - 1), kGenChunk + 64);
-            if (c0 == 0) {
-#pragma unroll
-                for (int j = 0; j < kGenPre; j++) {
-                    const int64_t i = tid + (int64_t)kGenThreads * j;
-                    if (i < n_char) codes[i] = lutb[mine[j]];
-                }
-            } else {
-                for (int64_t i = tid; i < n_char; i += kGenThreads) codes[i] = lutb[seq[c0 + i]];
+            if (c0 > 0) {  // later chunks of a long sequence: translated here, into the buffer the first chunk came in
+                const uint32_t n_char = (uint32_t)std::min<int64_t>(std::min<int64_t>(len - c0, kGenChunk + k - 1), kGenChunk + 64);
+                const unsigned char* chunk = seq + c0;  // wave-uniform
+                for (uint32_t i = tid; i < n_char; i += kGenThreads) codes[i] = lutb[chunk[i]];
+                lds_barrier();
             }
-            __syncthreads();
-            const int64_t n_win = std::min<int64_t>(W - c0, kGenChunk);
-            for (int64_t w = tid; w < n_win; w += kGenThreads) {
+            const uint32_t n_win = (uint32_t)std::min<int64_t>(W - c0, kGenChunk);
+            for (uint32_t w = tid; w < n_win; w += kGenThreads) {
+                // (idx < nbins <= 36 864 and alen <= 127: a 24-bit multiply-add, full rate, instead of v_mad_u64_u32; two
+                // letters per turn of the loop: two LDS reads in flight instead of one read -> wait -> multiply)
                 uint32_t idx = 0;
-                int bad = 0;
-                for (int p = 0; p < k; p++) {
+                int bad = 0, p = 0;
+                for (; p + 2 <= k; p += 2) {
+                    const int c = codes[w + p], d = codes[w + p + 1];
+                    bad |= c | d;  // the sign bit survives: any letter outside the alphabet
+                    idx = __umul24(__umul24(idx, (uint32_t)alen) + (uint32_t)(c & 127), (uint32_t)alen) + (uint32_t)(d & 127);
+                }
+                if (p < k) {
                     const int c = codes[w + p];
-                    bad |= c;  // the sign bit survives: any letter outside the alphabet
-                    idx = idx * (uint32_t)alen + (uint32_t)(c & 127);
+                    bad |= c;
+                    idx = __umul24(idx, (uint32_t)alen) + (uint32_t)(c & 127);
                 }
                 if (bad >= 0) (void)__hip_atomic_fetch_add(&bins[idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            __syncthreads();
+            lds_barrier();  // the bins are complete (and `codes` may be overwritten by the next chunk); the table is visible
         }
-        prefetch(s + gridDim.x);  // in flight during the flush below
+        translate(codes_next, use, nxt_len);  // BEFORE the flush issues its stores: the turn's one wait for vmcnt (all but `req`)
+        if (W <= 0) lds_barrier();  // a sequence without a single window: the table still has to reach every wave's flush
+                                    // (no chunk, hence no other barrier in between; found by the differential fuzzer)
         OutT* row = out + (size_t)s * nbins;
         auto value_of = [&](uint32_t n) -> OutT {
             if (std::is_same<OutT, uint32_t>::value) return (OutT)n;
@@ -843,7 +882,12 @@ __global__ __launch_bounds__(kGenThreads) void count_generic_lds_kernel(const un
                 __builtin_nontemporal_store(value_of(n), row + b);
             }
         }
-        __syncthreads();  // zeroed bins and the table are settled before the next sequence
+        lds_barrier();  // zeroed bins, the table and the next sequence's codes are settled before the next turn
+        cur_off = nxt_off, cur_len = nxt_len, nxt_off = nn_off, nxt_len = nn_len, nn_off = n3_off, nn_len = n3_len;
+    };
+    for (int64_t s = blockIdx.x; s < n_seqs; s += 2 * stride) {
+        turn(s, pre, pre2, codes, codes_next);  // (the code buffers swap roles with the register sets: fixed LDS addresses in
+        if (s + stride < n_seqs) turn(s + stride, pre2, pre, codes_next, codes);  // each body, not a pointer that is exchanged)
     }
 }
 
@@ -926,9 +970,17 @@ extern "C" int skr_count_generic_dev(skr_ctx* ctx, const skr_aseqs* a, const cha
     SKR_TRY(skr_activate(ctx));
     if (nbins <= kGenLdsBins && k <= 64 && !ctx->knobs.count_generic_global) {
         // the histogram fits the LDS: one pass, the row write is the only traffic (kernel comment above)
-        const size_t lds = (size_t)((nbins + 3) & ~(int64_t)3) * 4 + kTabSize * 4 + 256 + kGenChunk + 64;
+        const size_t lds = (size_t)((nbins + 3) & ~(int64_t)3) * 4 + kTabSize * 4 + 256 + 2 * (kGenChunk + 64);
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / kGenThreads, ((size_t)160 * 1024) / lds));
-        const unsigned grid = (unsigned)std::min<int64_t>(n, (int64_t)ctx->num_cu * per_cu);
+        // Two workgroups per CU overlap one's flush with the other's histogram — except when the rows are long and the
+        // sequences short (the flush is nearly all of a turn): measured at 50 000 x 2 kb, 14 641 / 15 625 bins: 0.735 / 0.770 ms
+        // with two workgroups per CU against 0.563 / 0.594 with one; 10 000 bins and fewer, or 20 kb sequences: two win
+        // (0.378 against 0.479 ms at 10 000 bins).  (tools/count_generic_bench.py)
+        double mean_len = 0.0;
+        for (int64_t L : a->h_len) mean_len += (double)L;
+        mean_len /= (double)n;
+        const int want_per_cu = (nbins >= 12288 && 2.0 * mean_len < (double)nbins) ? 1 : per_cu;
+        const unsigned grid = (unsigned)std::min<int64_t>(n, (int64_t)ctx->num_cu * want_per_cu);
         SkrProfScope prof(ctx, "count_generic");
 #define SKR_GEN_LAUNCH(T, LG)                                                                                              \
     do {                                                                                                                   \

@@ -30,7 +30,7 @@ def test_row_counts_around_the_tile_heights():
 
 def test_sequence_lengths_through_every_counter():
     """tools/length_sweep.py: every length 0 .. 300, the neighbours of the counters' chunk and tile boundaries, random
-    lengths up to 100 000 — 23 (alphabet, k) pairs from 1 to 262 144 columns, integer counts and per-kb float32 rows
+    lengths up to 100 000 — 27 (alphabet, k) pairs from 1 to 262 144 columns, integer counts and per-kb float32 rows
     bit-exact against the C oracle (kmer_counts.py:140-151)."""
     import length_sweep
     bad = length_sweep.sweep(quick=False, seed=1, verbose=False)

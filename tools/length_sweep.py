@@ -24,7 +24,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 CASES = [("AGTC", k) for k in range(1, 10)] + [("ACGTN", k) for k in (1, 2, 3, 5, 6, 7)] + [("AT", 3), ("AT", 12), ("AT", 15),
-         ("ARNDCQEGHILKMFPSTWYV", 2), ("ARNDCQEGHILKMFPSTWYV", 3), ("ACDEFGHIKL", 4), ("AGTA", 4), ("T", 3)]
+         ("ARNDCQEGHILKMFPSTWYV", 2), ("ARNDCQEGHILKMFPSTWYV", 3), ("ACDEFGHIKL", 4), ("AGTA", 4), ("T", 3),
+         ("ACDEFGH", 5), ("ACG", 9), ("ACGTRYNK", 5), ("ACDEFG", 6)]  # 16 807 / 19 683 / 32 768 bins: the LDS above 16 384; 46 656: HBM
 
 
 def lengths_for(k, quick, rng):
