@@ -26,6 +26,7 @@ struct SkrKnobs {
     int count_wps = 0;           // SEEKR_COUNT_WPS: waves per sequence (0 = by k)
     int64_t split_max_cols = 262144;    // SEEKR_SPLIT_MAX_COLS: widest row the split-fp16 contraction takes (k = 9; 16384 = rounds 1-3: k >= 8 on the fp32 kernel)
     bool count_generic_global = false;  // SEEKR_COUNT_GENERIC_GLOBAL=1: any-alphabet counting on the round-1 path (histogram in HBM)
+    int count_generic_wgs = 0;          // SEEKR_COUNT_GENERIC_WGS=1|2: workgroups per CU of the any-alphabet LDS counter (0: chosen from the shape)
     bool count_k8_global = false;  // SEEKR_COUNT_K8_GLOBAL=1: k = 8 on the round-1 path (histogram in the output row, L2 atomics)
     int count_occ = 0;           // SEEKR_COUNT_OCC: cap on one-wave workgroups per CU of the non-persistent launch (0 = what the LDS allows)
     bool chain_host_wait = false;  // SEEKR_CHAIN_HOST_WAIT=1 (only under SEEKR_TEST_HOOKS=1): the column-sum chain waits for its

@@ -57,6 +57,7 @@ extern "C" int skr_ctx_reload_knobs(skr_ctx* c) {
     kn.count_wps = env_int("SEEKR_COUNT_WPS", 0);
     kn.split_max_cols = env_int("SEEKR_SPLIT_MAX_COLS", 262144);
     kn.count_generic_global = env_int("SEEKR_COUNT_GENERIC_GLOBAL", 0) != 0;
+    kn.count_generic_wgs = env_int("SEEKR_COUNT_GENERIC_WGS", 0);
     kn.count_k8_global = env_int("SEEKR_COUNT_K8_GLOBAL", 0) != 0;
     kn.count_occ = std::max(0, env_int("SEEKR_COUNT_OCC", 0));
     kn.chain_host_wait = env_int("SEEKR_TEST_HOOKS", 0) == 1 && env_int("SEEKR_CHAIN_HOST_WAIT", 0) != 0;

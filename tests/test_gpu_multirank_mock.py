@@ -260,7 +260,9 @@ def test_bench_rank_gives_up_when_a_peer_never_arrives(mock_lib):
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--rows", "4000",
                           "--length", "400", "--launch-timeout", "6"], env=env, capture_output=True, text=True, timeout=120)
     assert res.returncode == 3, (res.returncode, res.stderr[-1500:])
-    assert "no progress for 6 s, last stage:" in res.stderr and time.time() - t0 < 60
+    import re
+    said = re.search(r"no progress for (\d+) s, last stage:", res.stderr)  # (the watchdog looks once a second: 6 s, or 7 on a busy box)
+    assert said and 6 <= int(said.group(1)) <= 9 and time.time() - t0 < 60, res.stderr[-500:]
     assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
 
 
