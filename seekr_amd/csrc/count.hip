@@ -738,7 +738,10 @@ template <typename OutT, bool LOG2>
 __global__ __launch_bounds__(kGenThreads) __attribute__((amdgpu_num_vgpr(56), amdgpu_num_sgpr(72))) void count_generic_lds_kernel(const unsigned char* __restrict__ bases,
                                                                   const int64_t* __restrict__ offsets, int64_t n_seqs, int k,
                                                                   int alen, uint32_t nbins, GenericLut lut,
-                                                                  OutT* __restrict__ out, int fast_tab) {
+                                                                  OutT* __restrict__ out, int fast_tab, uint32_t row_bins,
+                                                                  uint32_t bin_lo) {
+    // `nbins` bins of the row live in the LDS: bins [bin_lo, bin_lo + nbins) of a row of `row_bins` cells.  A row wider than the
+    // LDS (5^7, 6^6 ... columns) is counted in several launches, each over ALL windows and one range of bins.
     extern __shared__ __attribute__((aligned(16))) uint32_t glds[];
     const uint32_t words_pad = (nbins + 3u) & ~3u;
     uint32_t* bins = glds;                                                 // [nbins]
@@ -822,7 +825,7 @@ __global__ __launch_bounds__(kGenThreads) __attribute__((amdgpu_num_vgpr(56), am
             }
             const uint32_t n_win = (uint32_t)std::min<int64_t>(W - c0, kGenChunk);
             for (uint32_t w = tid; w < n_win; w += kGenThreads) {
-                // (idx < nbins <= 36 864 and alen <= 127: a 24-bit multiply-add, full rate, instead of v_mad_u64_u32; two
+                // (idx < row_bins <= 2^24 and alen <= 127: a 24-bit multiply-add, full rate, instead of v_mad_u64_u32; two
                 // letters per turn of the loop: two LDS reads in flight instead of one read -> wait -> multiply)
                 uint32_t idx = 0;
                 int bad = 0, p = 0;
@@ -836,14 +839,15 @@ __global__ __launch_bounds__(kGenThreads) __attribute__((amdgpu_num_vgpr(56), am
                     bad |= c;
                     idx = __umul24(idx, (uint32_t)alen) + (uint32_t)(c & 127);
                 }
-                if (bad >= 0) (void)__hip_atomic_fetch_add(&bins[idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                idx -= bin_lo;  // (wraps for a bin below the range)
+                if (bad >= 0 && idx < nbins) (void)__hip_atomic_fetch_add(&bins[idx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             lds_barrier();  // the bins are complete (and `codes` may be overwritten by the next chunk); the table is visible
         }
         translate(codes_next, use, nxt_len);  // BEFORE the flush issues its stores: the turn's one wait for vmcnt (all but `req`)
         if (W <= 0) lds_barrier();  // a sequence without a single window: the table still has to reach every wave's flush
                                     // (no chunk, hence no other barrier in between; found by the differential fuzzer)
-        OutT* row = out + (size_t)s * nbins;
+        OutT* row = out + (size_t)s * row_bins + bin_lo;
         auto value_of = [&](uint32_t n) -> OutT {
             if (std::is_same<OutT, uint32_t>::value) return (OutT)n;
             if (sizeof(OutT) == 8) return (OutT)per_kb_value_f64(n, inc);
@@ -978,9 +982,12 @@ extern "C" int skr_count_generic_dev(skr_ctx* ctx, const skr_aseqs* a, const cha
     // a repeated letter keeps its LAST position, as the reference's dict {kmer: index} does (:122)
     for (int c = 0; c < alen; c++) lut.code[(unsigned char)alphabet[c]] = (int8_t)c;
     SKR_TRY(skr_activate(ctx));
-    if (nbins <= kGenLdsBins && k <= 64 && !ctx->knobs.count_generic_global) {
-        // the histogram fits the LDS: one pass, the row write is the only traffic (kernel comment above)
-        const size_t lds = (size_t)((nbins + 3) & ~(int64_t)3) * 4 + kTabSize * 4 + 256 + 2 * (kGenChunk + 64);
+    if (nbins <= ((int64_t)1 << 24) && k <= 64 && !ctx->knobs.count_generic_global) {
+        // the histogram — or, for rows wider than the LDS (round 5: 5^7, 6^6, 20^4 ... columns, until then counted with L2
+        // atomics into a histogram in HBM at 0.04 of the peak), one RANGE of its bins per launch — lives in the LDS: the row
+        // write is the only traffic that matters, the characters (a few kB a sequence) are simply read once per range
+        const int64_t range = std::min<int64_t>(nbins, kGenLdsBins);
+        const size_t lds = (size_t)((range + 3) & ~(int64_t)3) * 4 + kTabSize * 4 + 256 + 2 * (kGenChunk + 64);
         const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / kGenThreads, ((size_t)160 * 1024) / lds));
         // Two workgroups per CU overlap one's flush with the other's histogram — except when the rows are long and the
         // sequences short (the flush is nearly all of a turn): measured at 50 000 x 2 kb, 14 641 / 15 625 bins: 0.735 / 0.770 ms
@@ -989,7 +996,7 @@ extern "C" int skr_count_generic_dev(skr_ctx* ctx, const skr_aseqs* a, const cha
         double mean_len = 0.0;
         for (int64_t L : a->h_len) mean_len += (double)L;
         mean_len /= (double)n;
-        int want_per_cu = (nbins >= 12288 && 2.0 * mean_len < (double)nbins) ? 1 : per_cu;
+        int want_per_cu = (range >= 12288 && 2.0 * mean_len < (double)range) ? 1 : per_cu;
         if (ctx->knobs.count_generic_wgs >= 1) want_per_cu = std::min(per_cu, ctx->knobs.count_generic_wgs);  // A/B knob
         const unsigned grid = (unsigned)std::min<int64_t>(n, (int64_t)ctx->num_cu * want_per_cu);
         SkrProfScope prof(ctx, "count_generic");
@@ -997,8 +1004,10 @@ extern "C" int skr_count_generic_dev(skr_ctx* ctx, const skr_aseqs* a, const cha
     do {                                                                                                                   \
         auto kern = count_generic_lds_kernel<T, LG>;                                                                       \
         SKR_TRY(skr_kernel_lds(ctx, reinterpret_cast<const void*>(kern), lds));                                            \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kGenThreads), lds, ctx->stream, a->d_bases, a->d_off, n, k, alen, (uint32_t)nbins, \
-                           lut, (T*)out->data, want_per_cu > 1 ? 1 : 0);                                                   \
+        for (int64_t lo = 0; lo < nbins; lo += range)                                                                      \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kGenThreads), lds, ctx->stream, a->d_bases, a->d_off, n, k, alen,       \
+                               (uint32_t)std::min<int64_t>(range, nbins - lo), lut, (T*)out->data, want_per_cu > 1 ? 1 : 0,   \
+                               (uint32_t)nbins, (uint32_t)lo);                                                               \
     } while (0)
         if (out->dtype == SKR_U32) SKR_GEN_LAUNCH(uint32_t, false);
         else if (out->dtype == SKR_F64) SKR_GEN_LAUNCH(double, false);

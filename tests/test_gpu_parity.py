@@ -1301,9 +1301,9 @@ def _with_knobs(ctx, env, fn):
 
 
 @pytest.mark.parametrize("alphabet,k", [("ACGTN", 6), ("ACGTN", 2), ("ARNDCQEGHILKMFPSTWYV", 3), ("AT", 7), ("AGTA", 5), ("T", 4),
-                                        ("ACGTRYN", 4), ("ACDEFGH", 5), ("ACGTRYNK", 5)])
+                                        ("ACGTRYN", 4), ("ACDEFGH", 5), ("ACGTRYNK", 5), ("ACGTN", 7), ("ACDEFG", 6)])
 def test_any_alphabet_counts_in_the_lds(alphabet, k, L, ctx):
-    """Round 4: up to 16 384 columns (round 5: 36 864) the any-alphabet counter keeps its histogram in the LDS (count_generic_lds_kernel) and
+    """Round 4: up to 16 384 columns (round 5: 36 864, and wider rows one range of 36 864 bins per launch) the any-alphabet counter keeps its histogram in the LDS (count_generic_lds_kernel) and
     counts from sequences RESIDENT on the device (skr_aseqs).  Integer counts, float32 / float64 per-kb values and the
     Log2.pre form bit-exact against the oracle (kmer_counts.py:120-122,140-151) — sequences longer than one LDS chunk
     (4 096 characters), shorter than k, empty, with letters outside the alphabet, lower case — and identical to the

@@ -9,7 +9,8 @@ from seekr_amd import _lib  # noqa: E402
 
 ctx = _lib.default_context()
 cases = [("ACGTN", 6, 50000, 2000), ("ACGTN", 5, 50000, 2000), ("ARNDCQEGHILKMFPSTWYV", 3, 50000, 2000), ("ACGTN", 6, 5000, 20000),
-         ("ACDEFGHIKL", 4, 50000, 2000), ("ACDEFGHIKLM", 4, 50000, 2000), ("ACGTN", 6, 50000, 500), ("ACDEFGH", 5, 30000, 5000)]
+         ("ACDEFGHIKL", 4, 50000, 2000), ("ACDEFGHIKLM", 4, 50000, 2000), ("ACGTN", 6, 50000, 500), ("ACDEFGH", 5, 30000, 5000),
+         ("ACGTN", 7, 20000, 2000), ("ACDEFG", 6, 30000, 2000)]  # 78 125 / 46 656 bins: three / two bin ranges a row
 if len(sys.argv) > 1:  # only the cases named by index (PMC runs: tools/pmc_count_generic.sh)
     cases = [cases[int(a)] for a in sys.argv[1:]]
 rng = np.random.default_rng(0)
