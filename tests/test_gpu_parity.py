@@ -1180,6 +1180,38 @@ def test_alphabets_whose_width_is_a_multiple_of_8_but_not_of_32(alphabet, k):
         assert np.array_equal(got, got.T)
 
 
+
+def test_g9_wide_rows_of_other_alphabets_against_the_reference(golden_dir):
+    """G9 (tests/golden/make_golden_g9.py): the REFERENCE's output for 10 letters at k = 4 (10 000 columns: the width class
+    whose fill was wrong until round 5), ACGTN at k = 6 (15 625) and 7 letters at k = 5 (16 807: the LDS histogram above
+    16 384 bins, the block fill) — raw counts bit-exact, the mean-centred Log2.post matrix on 64 seeded cells and in its
+    sum, r of both matrices within the north_star's bar of the reference's own `pearson` (kmer_counts.py:140-151,201-209;
+    pearson.py:32-44)."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import make_golden_g9 as mk
+    from seekr_amd.kmer_counts import BasicCounter
+    from seekr_amd.pearson import pearson
+    g9 = np.load(os.path.join(golden_dir, "g9_wide_alphabets.npz"))
+    for name, alphabet, k in mk.CASES:
+        seqs = mk.sequences(name, alphabet)
+        for tag, kw in (("raw", dict(mean=False, std=False, log2="Log2.none")), ("post", dict(mean=True, std=False, log2="Log2.post"))):
+            c = BasicCounter(k=k, alphabet=alphabet, silent=True, **kw)
+            c.seqs = list(seqs)
+            with contextlib.redirect_stdout(io.StringIO()):
+                c.get_counts()
+            if tag == "raw":
+                assert np.array_equal(c.counts.view(np.uint32), g9[name + "_raw"].view(np.uint32)), name
+            else:
+                rows, cols = mk.sampled_cells(name, c.counts.shape)
+                np.testing.assert_allclose(c.counts[rows, cols], g9[name + "_post_cells"], rtol=1e-5, atol=2e-6)
+                want_sum = float(g9[name + "_post_sum"])
+                assert abs(c.counts.astype(np.float64).sum() - want_sum) <= 1e-5 * abs(want_sum)
+            want = g9["%s_r_%s" % (name, tag)].astype(np.float64)
+            got = pearson(c.counts, c.counts).astype(np.float64)
+            assert got.shape == want.shape
+            assert (np.abs(got - want) <= 2e-6 + 1e-5 * np.abs(want)).all(), (name, tag, float(np.abs(got - want).max()))
+
 def test_four_wave_geometry_gives_the_same_bits():
     """The 4-wave / 128 x 128 wave-tile arm of the split contraction (libseekr_hip_diag.so only: measured
     13 % slower and not shipped) adds the same products to every accumulator in the same order as the 8-wave kernel: r

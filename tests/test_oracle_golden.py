@@ -291,6 +291,28 @@ def test_g7_alphabets_other_than_four_letters(golden_dir):
         np.testing.assert_array_equal(post, g7[name + "_post"])
 
 
+def test_g9_wide_rows_of_other_alphabets(golden_dir):
+    """G9 (make_golden_g9.py): 10 letters at k = 4 (10 000 columns), ACGTN at k = 6 (15 625), 7 letters at k = 5 (16 807) through
+    the REFERENCE — the oracle's raw counts bit-exact, its mean-centred Log2.post matrix on 64 seeded cells and in its sum,
+    its Pearson of both within the north_star's bar of the reference's."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import make_golden_g9 as mk
+    g9 = np.load(os.path.join(golden_dir, "g9_wide_alphabets.npz"))
+    for name, alphabet, k in mk.CASES:
+        seqs = mk.sequences(name, alphabet)
+        raw = orc.raw_counts(seqs, k, alphabet)
+        assert np.array_equal(raw.view(np.uint32), g9[name + "_raw"].view(np.uint32)), name
+        post = orc.normalize(raw, mean=True, std=False, log2="Log2.post")[0]
+        rows, cols = mk.sampled_cells(name, post.shape)
+        np.testing.assert_allclose(post[rows, cols], g9[name + "_post_cells"], rtol=1e-6, atol=1e-7)
+        assert abs(post.astype(np.float64).sum() - float(g9[name + "_post_sum"])) <= 1e-6 * abs(float(g9[name + "_post_sum"]))
+        for tag, m in (("raw", raw), ("post", post)):
+            want = g9["%s_r_%s" % (name, tag)].astype(np.float64)
+            got = orc.pearson(m, m).astype(np.float64)
+            assert (np.abs(got - want) <= 2e-6 + 1e-5 * np.abs(want)).all(), (name, tag)
+
+
 def test_g8_file_whose_first_line_is_not_a_header(golden_dir, tmp_path):
     """fasta_reader.py:47-63 keeps entries in encounter order and :70-78 slice them as they stand: the oracle and the
     package's Reader must return the reference's (odd-looking) lists for such a file."""
