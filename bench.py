@@ -382,6 +382,7 @@ for _ in range(3):
     t0 = time.perf_counter(); pearson(head, head); ts.append(time.perf_counter() - t0)
 out["host_to_host_pearson_s"] = round(float(np.median(ts)), 4)
 out["host_to_host_pearson_rows"] = int(n_p)
+out.update(multi.group_info())  # the transport that carried the data and the ranks its all-reduce counted
 print(json.dumps(out), flush=True)
 '''
 

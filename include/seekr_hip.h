@@ -39,7 +39,10 @@ enum {
     SKR_ERR_COMM = -6,        /* RCCL failure / communicator not initialised                      */
     SKR_ERR_IO = -7,          /* file could not be read or written                                */
     SKR_ERR_FASTA_BLANK = -8, /* blank line in FASTA (fasta_reader.py:53 IndexError)              */
-    SKR_ERR_FASTA_HEADER = -9 /* header without sequence (fasta_reader.py:58 AssertionError)      */
+    SKR_ERR_FASTA_HEADER = -9,/* header without sequence (fasta_reader.py:58 AssertionError)      */
+    SKR_ERR_FASTA_TEXT = -10  /* the file holds a byte >= 0x80: the reference decodes it in text mode
+                               * (fasta_reader.py:44) before strip / upper / len; the byte parser
+                               * declines it and the caller reads it through a text-mode reader    */
 };
 
 /* element types of a skr_mat */
@@ -122,7 +125,10 @@ int skr_seqs_pack(skr_ctx* ctx, const char* bases, const int64_t* offsets, int64
 /* The reader's half of skr_seqs_from_fasta as a step of its own: the file parsed into host memory once (same semantics,
  * same errors), then packed onto one GPU or, range by range, onto several — each GPU packs and uploads the sequences it
  * will count (skr_fasta_pack only reads the parsed file: the ranges may be packed from several host threads at once).
- * lengths: int64 [n]; headers as skr_seqs_headers.                                                                   */
+ * lengths: int64 [n]; headers as skr_seqs_headers.
+ * A file with any byte >= 0x80 returns SKR_ERR_FASTA_TEXT before any other check: the reference's text-mode open
+ * (fasta_reader.py:44) decodes first, so its strip / upper / len see characters, not bytes; the caller hands such a file
+ * to a text-mode reader (the package: seekr_amd.fasta_reader.Reader) and packs the strings with skr_seqs_pack.      */
 typedef struct skr_fasta skr_fasta;
 int skr_fasta_open(const char* path, skr_fasta** out);
 int skr_fasta_free(skr_fasta* fa);

@@ -166,9 +166,40 @@ class SeekrHipError(RuntimeError):
     """A HIP / RCCL runtime failure inside libseekr_hip."""
 
 
+class FastaNeedsText(Exception):
+    """The native FASTA parser declined the file (SKR_ERR_FASTA_TEXT: a byte >= 0x80).  The reference opens the file in
+    text mode (fasta_reader.py:44), so characters — not bytes — are stripped, upper-cased and counted in len(seq); the
+    caller reads such a file with `seekr_amd.fasta_reader.Reader` and packs the strings."""
+
+
+IPC_VAR = "HSA_ENABLE_IPC_MODE_LEGACY"
+_ipc_env_at_load = "(library not loaded)"  # what IPC_VAR held when the HIP runtime came into the process
+
+
+def names_several_devices(spec=None):
+    """Does SEEKR_DEVICES (or `spec`) ask for more than one GPU?  Answered from the text alone — no HIP call."""
+    spec = (os.environ.get("SEEKR_DEVICES", "") if spec is None else spec).strip().lower()
+    return spec == "all" or len([t for t in spec.split(",") if t.strip()]) > 1
+
+
+def prepare_runtime_env():
+    """What must stand in the environment BEFORE the first HIP call of the process.  RCCL's peer-to-peer set-up between the
+    GPU threads of SEEKR_DEVICES needs dmabuf IPC (HSA_ENABLE_IPC_MODE_LEGACY=0: the driver of these nodes supports no
+    other), and the HIP / HSA runtime reads its environment once, when it starts — so the variable is set here, at
+    `import seekr_amd` and again right before libseekr_hip.so is loaded, whenever SEEKR_DEVICES names several devices.
+    A value the user exported is left alone.  Nothing to do once the library is in the process."""
+    if _lib is None and names_several_devices():
+        os.environ.setdefault(IPC_VAR, "0")
+
+
+def ipc_env_at_load():
+    """The value of HSA_ENABLE_IPC_MODE_LEGACY the HIP runtime started with (None = unset)."""
+    return _ipc_env_at_load
+
+
 def lib():
     """Load libseekr_hip.so once; raise ImportError (never fall back) when it is absent."""
-    global _lib
+    global _lib, _ipc_env_at_load
     if _lib is not None:
         return _lib
     with _lock:
@@ -178,6 +209,8 @@ def lib():
             raise ImportError(
                 "seekr_amd: {} is missing — build it with `python -m seekr_amd.build` "
                 "(hipcc, gfx950). There is no CPU fallback.".format(LIB_PATH))
+        prepare_runtime_env()
+        _ipc_env_at_load = os.environ.get(IPC_VAR)
         handle = C.CDLL(LIB_PATH)
         sigs = dict(SIGNATURES, **DIAG_SIGNATURES) if LIB_PATH == DIAG_LIB_PATH else SIGNATURES
         for name, (res, args) in sigs.items():
@@ -200,6 +233,7 @@ _EXC = {
     -7: OSError,
     -8: IndexError,
     -9: AssertionError,
+    -10: FastaNeedsText,
 }
 
 
@@ -539,6 +573,36 @@ class FastaFile:
             pass
 
 
+class _OtherTable(dict):
+    """str.translate table: letters of the alphabet keep a byte of their own, every other character shares one."""
+
+    def __init__(self, mapping, other):
+        super().__init__(mapping)
+        self.other = other
+
+    def __missing__(self, key):
+        return self.other
+
+
+def encode_text(seqs, alphabet):
+    """Sequences and alphabet as bytes for the kernels, one CHARACTER -> one byte (the reference indexes `str`:
+    kmer_counts.py:143-149), so len(seq) and every window position are kept.  Latin-1 text is taken as it stands.  With
+    a character above U+00FF anywhere (a text-mode read of a UTF-8 file can produce one) each distinct letter of the
+    alphabet gets a byte of its own and everything else one byte that no letter uses — what a window needs to be counted
+    or skipped exactly as the dict look-up of the reference does."""
+    joined = "".join(seqs)
+    try:
+        return joined.encode("latin-1"), alphabet.encode("latin-1")
+    except UnicodeEncodeError:
+        pass
+    letters = list(dict.fromkeys(alphabet))
+    if len(letters) > 255:
+        raise NotImplementedError("an alphabet of more than 255 distinct characters is not supported")
+    code = {ord(ch): chr(1 + i) for i, ch in enumerate(letters)}
+    table = _OtherTable(code, chr(0))
+    return joined.translate(table).encode("latin-1"), alphabet.translate(table).encode("latin-1")
+
+
 class PackedSeqs:
     """Sequences packed 2 bits/base in HBM (skr_seqs)."""
 
@@ -554,7 +618,7 @@ class PackedSeqs:
         if len(alphabet) != 4:
             raise NotImplementedError(
                 "the MI355X counting path packs 2 bits per base and needs a 4-letter alphabet (got {!r})".format(alphabet))
-        return alphabet.encode("latin-1")
+        return alphabet if isinstance(alphabet, bytes) else alphabet.encode("latin-1")
 
     @classmethod
     def from_strings(cls, ctx, seqs, alphabet="AGTC"):
@@ -562,8 +626,8 @@ class PackedSeqs:
         lengths = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
         offsets = np.zeros(len(seqs) + 1, dtype=np.int64)
         np.cumsum(lengths, out=offsets[1:])
-        blob = "".join(seqs).encode("latin-1", "replace")  # 1 char -> 1 byte; non-latin-1 -> '?'
-        return cls.from_buffer(ctx, blob, offsets, alphabet)
+        blob, alpha = encode_text(seqs, alphabet)  # 1 char -> 1 byte
+        return cls.from_buffer(ctx, blob, offsets, alpha)
 
     @classmethod
     def from_buffer(cls, ctx, blob, offsets, alphabet="AGTC"):
@@ -631,8 +695,7 @@ def count_generic(ctx, seqs, alphabet, k, dtype=np.float32, log2_pre=False):
     lengths = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=len(seqs))
     offsets = np.zeros(len(seqs) + 1, dtype=np.int64)
     np.cumsum(lengths, out=offsets[1:])
-    blob = "".join(seqs).encode("latin-1", "replace")
-    alpha = alphabet.encode("latin-1", "replace")
+    blob, alpha = encode_text(seqs, alphabet)
     out = ctx.empty(len(seqs), len(alpha) ** k, dtype)
     check(lib().skr_count_generic(ctx._h, C.cast(C.c_char_p(blob), _p), offsets.ctypes.data_as(_p), len(seqs), alpha,
                                   len(alpha), int(k), 1 if log2_pre else 0, out._h))

@@ -780,8 +780,11 @@ __global__ __launch_bounds__(kGenThreads) __attribute__((amdgpu_num_vgpr(56), am
     // (32-bit lane arithmetic throughout the loop: the kernel is bound by VALU issue — a wave64 instruction takes four cycles —
     // and 64-bit compares / adds per character and per window were a third of what a turn issued)
     auto request = [&](unsigned char (&dst)[kGenPre], int64_t off) {  // the first chunk's characters of the sequence at `off`
-        const unsigned char* base = bases + off;  // wave-uniform
-        const uint32_t lim = (uint32_t)std::min<int64_t>(last_byte - std::min<int64_t>(off, last_byte), kGenChunk + 64);
+        // (a trailing empty sequence has off == total: the address itself is clamped too, or bases[total] — one past the
+        // allocation — would be read and thrown away, a fault when `total` ends on an allocation boundary)
+        const int64_t at = std::min<int64_t>(off, last_byte);
+        const unsigned char* base = bases + at;  // wave-uniform
+        const uint32_t lim = (uint32_t)std::min<int64_t>(last_byte - at, kGenChunk + 64);
 #pragma unroll
         for (int j = 0; j < kGenPre; j++) dst[j] = base[std::min<uint32_t>((uint32_t)tid + (uint32_t)kGenThreads * j, lim)];
     };
@@ -934,7 +937,7 @@ extern "C" int skr_aseqs_create(skr_ctx* ctx, const char* bases, const int64_t* 
         a->h_len[(size_t)i] = offsets[i + 1] - offsets[i];
         rel[(size_t)i + 1] = offsets[i + 1] - offsets[0];
     }
-    hipError_t e = hipMalloc((void**)&a->d_bases, std::max<size_t>(a->total, 1));
+    hipError_t e = hipMalloc((void**)&a->d_bases, a->total + 64);  // slack: the counter's prefetch is clamped, this is the belt
     if (e == hipSuccess) e = hipMalloc((void**)&a->d_off, (size_t)(n + 1) * sizeof(int64_t));
     if (e == hipSuccess && a->total) e = hipMemcpyAsync(a->d_bases, bases + offsets[0], a->total, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(a->d_off, rel.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
@@ -976,7 +979,7 @@ extern "C" int skr_count_generic_dev(skr_ctx* ctx, const skr_aseqs* a, const cha
     if (out->dtype != SKR_U32)
         for (int64_t L : a->h_len)
             if (L == k - 1)  // kmer_counts.py:144
-                return skr_set_error(SKR_ERR_ZERODIV, "division by zero (a sequence has length k-1 = %d)", k - 1);
+                return skr_set_error(SKR_ERR_ZERODIV, "division by zero");  // the text Python gives `1000 / 0` (kmer_counts.py:144)
     GenericLut lut;
     memset(lut.code, -1, sizeof(lut.code));
     // a repeated letter keeps its LAST position, as the reference's dict {kmer: index} does (:122)
@@ -1076,7 +1079,7 @@ extern "C" int skr_count_per_kb(skr_ctx* ctx, const skr_seqs* s, int k, int log2
     // len == k-1 is an error in the reference (ZeroDivisionError, kmer_counts.py:144): detect on the host
     for (int64_t L : s->h_len)
         if (L == k - 1)
-            return skr_set_error(SKR_ERR_ZERODIV, "division by zero (a sequence has length k-1 = %d)", k - 1);
+            return skr_set_error(SKR_ERR_ZERODIV, "division by zero");  // the text Python gives `1000 / 0` (kmer_counts.py:144)
     if (out->dtype == SKR_F64) {
         if (k > 7) return skr_set_error(SKR_ERR_UNSUPPORTED, "float64 count output is implemented for k <= 7");
         return launch_count<OUT_F64>(ctx, s, k, out->data, "count_kmers_f64");

@@ -166,6 +166,19 @@ inline bool py_space(unsigned char c) {
     return c == ' ' || (c >= 0x09 && c <= 0x0d) || (c >= 0x1c && c <= 0x1f);
 }
 
+// Any byte >= 0x80 in p[0, n)?  Eight bytes a step (the compiler widens it further): far below the cost of the parse.
+inline bool has_high_byte(const char* p, size_t n) {
+    uint64_t acc = 0;
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32) {
+        uint64_t w[4];
+        memcpy(w, p + i, 32);
+        acc |= (w[0] | w[1]) | (w[2] | w[3]);
+    }
+    for (; i < n; i++) acc |= (uint64_t)(unsigned char)p[i];
+    return (acc & 0x8080808080808080ull) != 0;
+}
+
 // What one thread learns from the lines of data[begin, end) (begin is a line start).
 struct FastaPiece {
     std::string joined;                // sequence characters of the piece, stripped lines back to back
@@ -175,9 +188,14 @@ struct FastaPiece {
     int64_t n_lines = 0;
     int64_t blank_line = -1;           // first line that is empty after strip()
     bool first_is_header = false;
+    bool high_byte = false;            // a byte >= 0x80: the piece was not parsed (see skr_fasta_open)
 };
 
 void parse_piece(const char* data, size_t begin, size_t end, FastaPiece* out) {
+    if (has_high_byte(data + begin, end - begin)) {
+        out->high_byte = true;
+        return;
+    }
     out->joined.reserve(end - begin);
     size_t pos = begin;
     while (pos < end) {
@@ -285,6 +303,15 @@ extern "C" int skr_fasta_open(const char* path, skr_fasta** out) {
         parse_piece(data, cut[0], cut[1], &pieces[0]);
         for (auto& t : th) t.join();
     }
+    // The reference opens the file in text mode (fasta_reader.py:44): bytes are decoded before strip() / upper() / len()
+    // see them, so a multi-byte character counts once in len(seq) (kmer_counts.py:143-144), Unicode white space (NBSP,
+    // NEL, U+2028 ...) is stripped, upper() may change the length, and an undecodable byte raises.  None of that is a
+    // byte-level rule; a file with any byte >= 0x80 is declined here and read by the text-mode Reader of the package.
+    for (int i = 0; i < n_pieces; i++)
+        if (pieces[i].high_byte) {
+            if (data) munmap((void*)data, fsize);
+            return skr_set_error(SKR_ERR_FASTA_TEXT, "'%s' holds bytes >= 0x80: it is read in text mode, as the reference does", path);
+        }
     // ---- stitch
     int rc = SKR_OK;
     int64_t err_line = INT64_MAX;  // line of the first error in file order

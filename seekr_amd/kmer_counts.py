@@ -79,6 +79,12 @@ class BasicCounter:
                         self._fasta = _lib.FastaFile(infasta)  # the reader's errors surface here, as in the reference
                     else:
                         self._packed = _lib.default_context().pack_fasta(infasta, alphabet)
+                except _lib.FastaNeedsText:
+                    # a byte >= 0x80 somewhere in the file: the reference decodes the text before strip() / upper() /
+                    # len() (fasta_reader.py:44, kmer_counts.py:143-144), so NBSP at a line end is stripped, 'ß' becomes
+                    # 'SS', a two-byte letter is one position of W = len(seq) - k + 1, an undecodable byte raises
+                    # UnicodeDecodeError.  The text-mode Reader does all of that by construction.
+                    self._seqs = Reader(infasta).get_seqs()
                 except ValueError as e:
                     # a file whose first line is not a header: the native reader refuses it, the reference slices its
                     # entry list anyway (Reader.get_seqs then returns what stands at the odd positions).  Same result

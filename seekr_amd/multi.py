@@ -2,7 +2,8 @@
 
     SEEKR_DEVICES=all  (or 0,1,2,3)   seekr_kmer_counts transcripts.fa -o counts.npy -b -rl
                                       seekr_pearson counts.npy counts.npy -o r.npy -bi -bo
-    >>> os.environ["SEEKR_DEVICES"] = "all"; BasicCounter("transcripts.fa").get_counts(); pearson(c, c)
+    >>> os.environ["SEEKR_DEVICES"] = "all"          # BEFORE `import seekr_amd` (see _lib.prepare_runtime_env), or exported
+    >>> BasicCounter("transcripts.fa").get_counts(); pearson(c, c)
 
 Unset (or naming one device) everything runs as before on one GPU.  With several devices ONE host process drives them
 all, one Python thread per GPU (every call into libseekr_hip releases the interpreter lock): the rows — transcripts — are
@@ -264,6 +265,17 @@ def _hip_backend(group, rank):
             raise _lib.SeekrHipError("GPU {} (rank {} of {}): the {} ring self-test delivered {} instead of {}".format(
                 group.devices[rank], rank, size, group.transport, got[0, 0], want))
         comm.barrier()  # (peer transport: `send` is read by the neighbour's copy until here)
+        # how many ranks the transport itself saw: a one-element all-reduce on the devices over RCCL (what "did RCCL carry
+        # data between N GPUs" is answered from: group_info()), the host gather for peer copies
+        if group.transport == "rccl":
+            seen = int(round(_lib.comm_allreduce(ctx, [1.0], "sum")[0]))
+        else:
+            seen = len(group.gather(rank, 1))
+        if seen != size:
+            raise _lib.SeekrHipError("GPU {} (rank {} of {}): the {} all-reduce counted {} ranks".format(
+                group.devices[rank], rank, size, group.transport, seen))
+        if rank == 0:
+            group.n_ranks_seen = seen
     st.phase(ring)
     return st
 
@@ -281,6 +293,7 @@ class DeviceGroup:
         self.acks = {(a, b): queue.Queue() for a in range(self.size) for b in range(self.size) if a != b}  # (sender, receiver)
         self.mail_timeout = 120.0
         self.broken = False
+        self.n_ranks_seen = None  # set by the set-up's all-reduce (_hip_backend)
         self._backend = backend or _hip_backend
         self._barrier = threading.Barrier(self.size)
         self._slots = [None] * self.size
@@ -377,6 +390,30 @@ def requested_transport():
     return t
 
 
+def group_info():
+    """What is actually behind SEEKR_DEVICES in this process, for records (bench.py's e2e.seekr_devices_all, the tests'
+    info.json): the transport that carries device data — 'rccl' or 'peer', never the one merely asked for — the number of
+    ranks its set-up all-reduce counted, and the IPC mode the HIP runtime started with."""
+    g = _group
+    if g is None:
+        return {"group_size": 0, "transport": None, "n_ranks_seen": None, "ipc_env_at_load": _lib.ipc_env_at_load()}
+    return {"group_size": g.size, "transport": g.transport, "n_ranks_seen": g.n_ranks_seen,
+            "n_ranks_seen_by": "RCCL all-reduce on the devices" if g.transport == "rccl" else "host gather (peer copies: no RCCL)",
+            "transport_asked": requested_transport(), "ipc_env_at_load": _lib.ipc_env_at_load()}
+
+
+def late_ipc_note():
+    """Why RCCL may have failed through no fault of its own: HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC, which RCCL's
+    peer-to-peer set-up needs on these nodes) was not in the environment when the HIP runtime started — SEEKR_DEVICES was set
+    inside the process, after seekr_amd had been used.  The package sets the variable itself only when it sees SEEKR_DEVICES
+    before its first HIP call (seekr_amd._lib.prepare_runtime_env).  '' when the runtime did start with it."""
+    if _lib.ipc_env_at_load() == "0":
+        return ""
+    return ("{0} was {1!r}, not '0', when the HIP runtime started: SEEKR_DEVICES was first seen after seekr_amd's first HIP "
+            "call, too late to set it — export SEEKR_DEVICES (or {0}=0) before the process starts, or set os.environ"
+            "['SEEKR_DEVICES'] before importing seekr_amd".format(_lib.IPC_VAR, _lib.ipc_env_at_load()))
+
+
 def group_for(devices):
     """The process-wide DeviceGroup for this device list (created on first use, replaced when the list, the transport
     asked for changes or the group broke)."""
@@ -387,16 +424,18 @@ def group_for(devices):
             _group.close()
             _group = None
         if _group is None:
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's peer-to-peer set-up needs it here
             if want in ("auto", "rccl"):
                 try:
                     _group = DeviceGroup(devices, uid=_lib.comm_unique_id(), transport="rccl")
                 except Exception as e:  # noqa: BLE001
+                    late = late_ipc_note()
                     if want == "rccl":
+                        if late:
+                            raise type(e)("{} [{}]".format(e, late)) from e
                         raise
                     import sys
-                    print("seekr_amd: RCCL could not be set up between the GPUs of SEEKR_DEVICES ({}: {}); using peer copies "
-                          "(SEEKR_TRANSPORT=peer)".format(type(e).__name__, e), file=sys.stderr)
+                    print("seekr_amd: RCCL could not be set up between the GPUs of SEEKR_DEVICES ({}: {}){}; using peer copies "
+                          "(SEEKR_TRANSPORT=peer)".format(type(e).__name__, e, " — " + late if late else ""), file=sys.stderr)
             if _group is None:
                 _group = DeviceGroup(devices, transport="peer")
         return _group

@@ -1,7 +1,10 @@
 """Differential fuzzing of the native FASTA reader / packer (skr_seqs_from_fasta) against the oracle's
 restatement of fasta_reader.py:41-63: random files with CRLF, trailing blanks, lower case, N runs,
 odd characters, missing final newline, blank lines and headers without sequence (which must raise the
-reference's exceptions)."""
+reference's exceptions).  One file in three is not ASCII: 2 % of its header and sequence characters are code points
+above U+007F (Unicode white space that strip() removes, letters whose upper() is longer or lands in ASCII, astral
+characters, a BOM) — such a file must take the text-mode reader (fasta_reader.py:44 decodes before strip / upper / len)
+— and one file in 200 holds a byte that is not UTF-8 at all (UnicodeDecodeError, like the reference)."""
 import io
 import os
 import sys
@@ -16,12 +19,38 @@ from oracle import seekr_oracle as orc  # noqa: E402
 from seekr_amd.kmer_counts import BasicCounter  # noqa: E402
 
 
+WIDE = ["\u00a0", "\u0085", "\u2028", "\u2029", "\u3000", "\ufeff", "\u00e9", "\u00df", "\u0131", "\ufb01", "\u0149",
+        "\u03a9", "\u00ff", "\U0001d400", "\U0001f9ec", "\u1680", "\u200b"]
+
+
+def sprinkle(rng, text, share=0.02):
+    """`share` of the characters of `text` replaced by code points above U+007F."""
+    if not text:
+        return text
+    chars = list(text)
+    for at in np.nonzero(rng.random(len(chars)) < share)[0]:
+        chars[at] = WIDE[int(rng.integers(0, len(WIDE)))]
+    return "".join(chars)
+
+
 def random_fasta(rng):
+    """The file as BYTES (UTF-8 unless an undecodable byte was planted)."""
+    wide = rng.integers(0, 3) == 0
+    text = random_text(rng, wide)
+    data = text.encode("utf-8")
+    if rng.integers(0, 200) == 0 and data:
+        at = int(rng.integers(0, len(data)))
+        data = data[:at] + bytes([int(rng.choice([0xff, 0xc3, 0x80, 0xe2]))]) + data[at:]
+    return data
+
+
+def random_text(rng, wide):
     n = int(rng.integers(1, 12))
     eol = "\r\n" if rng.integers(0, 4) == 0 else "\n"
     lines = []
     for i in range(n):
-        lines.append(">seq%d %s" % (i, "".join(rng.choice(list("abc |,;\t"), int(rng.integers(0, 6))))))
+        head = ">seq%d %s" % (i, "".join(rng.choice(list("abc |,;\t"), int(rng.integers(0, 6)))))
+        lines.append(head[0] + sprinkle(rng, head[1:], 0.05) if wide else head)
         if rng.integers(0, 25) == 0:
             continue  # header without sequence -> AssertionError (unless last: silently dropped? the oracle decides)
         L = int(rng.choice([0, 1, 2, 3, 5, 17, 64, 65, 300, 2050])) if rng.integers(0, 3) == 0 else int(rng.integers(1, 400))
@@ -31,7 +60,10 @@ def random_fasta(rng):
         for c in chunks:
             if c == "" and rng.integers(0, 2):
                 continue
-            lines.append(c + (" " * int(rng.integers(0, 3)) if rng.integers(0, 6) == 0 else ""))
+            if wide:
+                c = sprinkle(rng, c)
+            blank = "\u00a0" if wide and rng.integers(0, 3) == 0 else " "
+            lines.append(c + (blank * int(rng.integers(0, 3)) if rng.integers(0, 6) == 0 else ""))
         if rng.integers(0, 40) == 0:
             lines.append("")  # blank line -> IndexError
     text = eol.join(lines)
@@ -47,7 +79,7 @@ def fuzz(seed, budget_s=30.0, max_cases=10 ** 9):
     t0, n_cases = time.time(), 0
     while time.time() - t0 < budget_s and n_cases < max_cases:
         text = random_fasta(rng)
-        with open(path, "w", newline="") as fh:
+        with open(path, "wb") as fh:
             fh.write(text)
         k = int(rng.integers(1, 4))
         # the reader parses big files in pieces on several threads and stitches them; force that on small files
@@ -79,7 +111,7 @@ def fuzz(seed, budget_s=30.0, max_cases=10 ** 9):
         except AssertionError:
             out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
             os.makedirs(out, exist_ok=True)
-            with open(os.path.join(out, "fuzz_fasta_fail_%d_%d.fa" % (seed, n_cases)), "w", newline="") as fh:
+            with open(os.path.join(out, "fuzz_fasta_fail_%d_%d.fa" % (seed, n_cases)), "wb") as fh:
                 fh.write(text)
             print("piece bytes", piece, repr(text[:400]))
             raise

@@ -143,15 +143,35 @@ def main():
         out["blank_text"] = np.array(str(e))
     c = counter(s1[:60], k=4)
     save("after_error", c.counts)
+    # ---- golden set G10: files with bytes >= 0x80 (read in text mode, fasta_reader.py:44): counts or the reference's exception
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "g10_non_ascii.json")) as fh:
+        g10 = json.load(fh)["cases"]
+    for case in g10:
+        with open(path("g10.fa"), "wb") as fh:
+            fh.write(bytes.fromhex(case["hex"]))
+        try:
+            c = BasicCounter(path("g10.fa"), k=2, mean=False, std=False, log2="Log2.none", silent=True)
+            c.get_counts()
+            save("g10_" + case["name"], c.counts)
+            out["g10_seqs_" + case["name"]] = np.array("\n".join(c.seqs))
+        except Exception as e:  # noqa: BLE001 - compared with the reference's own
+            out["g10_" + case["name"]] = np.array(type(e).__name__ + ": " + str(e))
+    with open(path("g10.fa"), "wb") as fh:
+        fh.write(bytes.fromhex([c for c in g10 if c["name"] == "mixed_records"][0]["hex"]))
+    c = BasicCounter(path("g10.fa"), k=2, silent=True)
+    c.get_counts()
+    save("g10_mixed_normalised", c.counts), save("g10_mixed_mean", c.mean)
+    os.remove(path("g10.fa"))
     out["stdout"] = np.array(log.getvalue())
     np.savez(path("results.npz"), **out)
     # what actually ran (not compared between settings): the device list, the live group's size, the stripe height
-    import json
     from seekr_amd import multi
     with open(path("info.json"), "w") as fh:
         json.dump({"devices": multi.requested_devices(), "group_size": multi._group.size if multi._group else 0,
                    "group_broken": bool(multi._group.broken) if multi._group else None,
                    "transport": multi._group.transport if multi._group else None,
+                   "n_ranks_seen": multi.group_info()["n_ranks_seen"], "ipc_env_at_load": multi.group_info()["ipc_env_at_load"],
                    "threads": sorted(t.name for t in multi._group._threads) if multi._group else [],
                    "stripe_rows": multi.forced_stripe_rows()}, fh)
     for name in ("example.fa", "s1.fa", "s2.fa", "big.fa", "blank.fa"):

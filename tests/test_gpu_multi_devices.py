@@ -81,6 +81,29 @@ def test_the_baseline_is_what_the_reference_does(baseline):
     assert np.allclose(r_file, a["big_r"][:, :777], rtol=1e-5, atol=2e-6)  # a cross comparison: same values, its own bits
 
 
+def test_g10_files_that_are_not_ascii(baseline, golden_dir):
+    """Golden set G10 through BasicCounter(infasta): the native parser declines a file with a byte >= 0x80 and the text-mode
+    Reader gives what the reference's text-mode open gives — the reference's sequences, raw k = 2 counts bit for bit, and its
+    exceptions (UnicodeDecodeError included) with their text.  The same cases run under every SEEKR_DEVICES setting of this
+    file (same_outputs compares them byte for byte with this run)."""
+    import locale
+    with open(os.path.join(golden_dir, "g10_non_ascii.json")) as fh:
+        g = json.load(fh)
+    if locale.getpreferredencoding(False).lower().replace("-", "") != g["text_encoding"].lower().replace("-", ""):
+        pytest.skip("text-mode open() decodes with another codec here")
+    a = np.load(os.path.join(baseline, "results.npz"))
+    n_counts = 0
+    for case in g["cases"]:
+        got = a["g10_" + case["name"]]
+        if "exception" in case:
+            assert str(got) == case["exception"] + ": " + case["message"], case["name"]
+            continue
+        assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), np.array(case["raw_k2_bits"], dtype=np.uint32)), case["name"]
+        assert str(a["g10_seqs_" + case["name"]]).split("\n") == case["seqs"], case["name"]
+        n_counts += 1
+    assert n_counts >= 13
+
+
 @pytest.mark.parametrize("stripe", [300, 1])
 def test_one_gpu_with_r_in_stripes(baseline, tmp_path, stripe):
     """pearson() by row stripes on ONE GPU (what a result larger than the HBM gets), stripe height forced: same bytes.
@@ -103,6 +126,9 @@ def test_ranks_on_one_gpu_behind_the_api(baseline, mock_lib, tmp_path, size, str
     # the run really was `size` GPU threads that lived through every call (the ZeroDivisionError included)
     assert info["devices"] == [0] * size and info["group_size"] == size and info["group_broken"] is False
     assert len(info["threads"]) == size and info["stripe_rows"] == stripe
+    # the transport recorded is the one that carried the data, and its set-up all-reduce (ncclAllReduce on the devices) counted
+    # every rank; SEEKR_DEVICES stood in the environment at import, so the runtime started with dmabuf IPC
+    assert info["transport"] == "rccl" and info["n_ranks_seen"] == size and info["ipc_env_at_load"] == "0", info
     with open(os.path.join(baseline, "info.json")) as fh:
         assert json.load(fh)["group_size"] == 0
     same_outputs(baseline, got)
@@ -121,6 +147,7 @@ def test_gpu_threads_over_peer_copies(baseline, tmp_path, size, stripe):
     with open(os.path.join(got, "info.json")) as fh:
         info = json.load(fh)
     assert info["group_size"] == size and info["group_broken"] is False and info["transport"] == "peer"
+    assert info["n_ranks_seen"] == size
     same_outputs(baseline, got)
 
 
@@ -148,5 +175,6 @@ def test_bench_reports_the_host_to_host_figures_with_seekr_devices(tmp_path):
     out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
     dev = out["e2e"]["seekr_devices_all"]
     assert dev.get("devices") == 2 and "error" not in dev, dev
+    assert dev["transport"] == "peer" and dev["n_ranks_seen"] == 2 and dev["group_size"] == 2, dev  # what was used, not what was asked
     assert dev["host_to_host_pearson_mpairs_per_s"] > 0 and dev["fasta_to_host_counts_mbases_per_s"] > 0 and dev["first_call_s"] > 0
     assert "target_200k" not in out  # only the default workload carries it

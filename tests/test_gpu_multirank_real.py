@@ -99,18 +99,33 @@ def test_bench_starts_two_real_ranks(extra):
 
 
 @needs2
-@pytest.mark.parametrize("devices,stripe", [("all", None), ("0,1", 256)])
-def test_seekr_devices_behind_the_api_on_real_gpus(devices, stripe, tmp_path):
+@pytest.mark.parametrize("devices,stripe,transport", [("all", None, None), ("0,1", 256, None), ("all", None, "peer"), ("0,1", 256, "rccl")])
+def test_seekr_devices_behind_the_api_on_real_gpus(devices, stripe, transport, tmp_path):
     """SEEKR_DEVICES over the REAL librccl — one host thread per GPU, ncclCommInitRank per thread — through BasicCounter,
     pearson() and the three commands: every output byte-identical to the run with SEEKR_DEVICES unset (the comparison of
-    tests/test_gpu_multi_devices.py, which has only mock ranks on one GPU to offer on the pool's boxes)."""
+    tests/test_gpu_multi_devices.py, which has only mock ranks on one GPU to offer on the pool's boxes).  With
+    SEEKR_TRANSPORT unset the data MUST have travelled over RCCL (the 'auto' arm falls back to peer
+    copies with one stderr line, which this test would otherwise never notice): the transport recorded is the one used,
+    its set-up all-reduce counted every rank, and HSA_ENABLE_IPC_MODE_LEGACY=0 stood in the environment when the HIP
+    runtime started although this test removes it from the child's (the package sets it at import).  The
+    SEEKR_TRANSPORT=peer twin runs the same comparison over peer copies."""
     from test_gpu_multi_devices import run_worker, same_outputs
     baseline = run_worker(tmp_path / "one_gpu")
     env = {"SEEKR_DEVICES": devices}
     if stripe:
         env["SEEKR_PEARSON_STRIPE_ROWS"] = stripe
-    got = run_worker(tmp_path / "devices", **env)
+    if transport:
+        env["SEEKR_TRANSPORT"] = transport
+    saved = os.environ.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)  # the child's environment is copied from this one
+    try:
+        got = run_worker(tmp_path / "devices", **env)
+    finally:
+        if saved is not None:
+            os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = saved
     with open(os.path.join(got, "info.json")) as fh:
         info = json.load(fh)
-    assert info["group_size"] == (_gpus() if devices == "all" else 2) and info["group_broken"] is False
+    size = _gpus() if devices == "all" else 2
+    assert info["group_size"] == size and info["group_broken"] is False
+    assert info["transport"] == (transport or "rccl"), info
+    assert info["n_ranks_seen"] == size and info["ipc_env_at_load"] == "0", info
     same_outputs(baseline, got)

@@ -329,6 +329,74 @@ def test_g8_file_whose_first_line_is_not_a_header(golden_dir, tmp_path):
     assert np.array_equal(raw.view(np.uint32), np.array(g["raw_k2_bits"], dtype=np.uint32))
 
 
+def g10_cases(golden_dir):
+    """The non-ASCII FASTA files of tests/golden/g10_non_ascii.json (made by the reference under UTF-8 text decoding)."""
+    import json
+    import locale
+    g = json.load(open(os.path.join(golden_dir, "g10_non_ascii.json")))
+    if locale.getpreferredencoding(False).lower().replace("-", "") != g["text_encoding"].lower().replace("-", ""):
+        pytest.skip("text-mode open() decodes with {} here, the fixture was made with {}".format(
+            locale.getpreferredencoding(False), g["text_encoding"]))
+    return g["cases"]
+
+
+def test_g10_files_that_are_not_ascii(golden_dir, tmp_path):
+    """fasta_reader.py:44 opens in text mode: strip / upper / len work on decoded characters.  The oracle's reader and
+    the package's Reader return the reference's lists for 19 files with NBSP / NEL / U+2028 / U+3000 at line ends and
+    inside lines, letters whose upper() is longer, astral characters, a BOM, CRLF; the structure-faithful counting loop
+    on those strings gives the reference's raw k = 2 bits; and the files the reference fails on fail the same way."""
+    from seekr_amd.fasta_reader import Reader
+    builtin = {"IndexError": IndexError, "AssertionError": AssertionError, "ZeroDivisionError": ZeroDivisionError,
+               "UnicodeDecodeError": UnicodeDecodeError}
+    n_ok = n_err = 0
+    for case in g10_cases(golden_dir):
+        path = str(tmp_path / (case["name"] + ".fa"))
+        with open(path, "wb") as fh:
+            fh.write(bytes.fromhex(case["hex"]))
+        if "exception" in case:
+            for read in (lambda: orc.raw_counts_py(orc.read_fasta(path)[1], 2), lambda: orc.raw_counts_py(Reader(path).get_seqs(), 2)):
+                with pytest.raises(builtin[case["exception"]]) as err:
+                    read()
+                assert str(err.value) == case["message"], case["name"]
+            n_err += 1
+            continue
+        assert orc.read_fasta(path) == (case["headers"], case["seqs"]), case["name"]
+        assert Reader(path).get_headers() == case["headers"] and Reader(path).get_seqs() == case["seqs"], case["name"]
+        assert [len(s) for s in case["seqs"]] == case["lengths"]
+        raw = orc.raw_counts_py(case["seqs"], 2)
+        assert np.array_equal(raw.view(np.uint32), np.array(case["raw_k2_bits"], dtype=np.uint32)), case["name"]
+        n_ok += 1
+    assert n_ok >= 13 and n_err >= 6
+
+
+def test_g10_native_parser_declines_every_file_with_a_high_byte(golden_dir, tmp_path):
+    """skr_fasta_open (CPU code of the library) answers SKR_ERR_FASTA_TEXT for each G10 file — before any of its other
+    checks — and still parses the ASCII twin of the file; BasicCounter turns the answer into the text-mode Reader."""
+    from seekr_amd import _lib
+    for case in g10_cases(golden_dir):
+        data = bytes.fromhex(case["hex"])
+        path = str(tmp_path / (case["name"] + ".fa"))
+        with open(path, "wb") as fh:
+            fh.write(data)
+        with pytest.raises(_lib.FastaNeedsText):
+            _lib.FastaFile(path)
+    # the high byte far into a file cut into pieces, in the last piece only
+    os.environ["SEEKR_FASTA_PIECE_BYTES"] = "64"
+    try:
+        body = "".join(">s%d\nACGTACGTAC\nGGTTAACC\n" % i for i in range(200))
+        path = str(tmp_path / "late.fa")
+        with open(path, "wb") as fh:
+            fh.write(body.encode() + b">last\nACGT\xc2\xa0\n")
+        with pytest.raises(_lib.FastaNeedsText):
+            _lib.FastaFile(path)
+        with open(path, "wb") as fh:
+            fh.write(body.encode() + b">last\nACGT\x7f\n")
+        fa = _lib.FastaFile(path)
+        assert fa.n == 201 and int(fa.lengths()[-1]) == 5
+    finally:
+        del os.environ["SEEKR_FASTA_PIECE_BYTES"]
+
+
 def test_numpy_adds_a_row_in_the_pairwise_order_the_fill_kernel_reproduces():
     """The order seekr_amd/csrc/operand.hip: np_pairwise_sum reproduces on the device, restated in Python and pinned
     against np.add.reduce itself (float32, every length up to 300 and the widths the product meets): fewer than 8 values
