@@ -236,6 +236,30 @@ int skr_normalize(skr_ctx* ctx, skr_mat* x, int log2_mode, int mean_mode, const 
                   int std_mode, const skr_mat* std_vec, skr_mat* mean_out, skr_mat* std_out,
                   int* has_nan);
 
+/* BasicCounter.center() / standardize() / log2_norm() on a hand-assigned HOST count matrix whose dtype is not float32
+ * (kmer_counts.py:165-192 act on whatever `self.counts` holds — test_kmer_counts.py:44-90 assigns it by hand; SURVEY §8(b):
+ * "those methods must work on an arbitrary host array").  x: C-contiguous [rows, cols] of element type np_type; the
+ * arithmetic is numpy's for that type, step for step (seekr_amd/csrc/normalize_any.hip lists it): float64 in float64,
+ * integers converted to float64 for the statistics, float16 with float32 sums for the mean and half-rounded steps for
+ * the std.  Upload, one kernel, download: the drop-in surface, not the hot path (SKR_NP_F32 is refused: skr_colsum_seq /
+ * skr_apply are the float32 path).                                                                                   */
+enum {
+    SKR_NP_F16 = 0, SKR_NP_F32 = 1, SKR_NP_F64 = 2, SKR_NP_I8 = 3, SKR_NP_I16 = 4, SKR_NP_I32 = 5, SKR_NP_I64 = 6,
+    SKR_NP_U8 = 7, SKR_NP_U16 = 8, SKR_NP_U32 = 9, SKR_NP_U64 = 10, SKR_NP_BOOL = 11
+};
+/* what = 0: np.mean(x, axis=0) (:168), 1: np.std(x, axis=0) (:174).  out: [cols] float16 for a float16 matrix, float64
+ * for every other type (numpy's result types).                                                                       */
+int skr_host_colstat(skr_ctx* ctx, const void* x, int64_t rows, int64_t cols, int np_type, int what, void* out);
+/* In place on x.  op 0: x -= vec[col] (:169), op 1: x /= vec[col] (:175) — float matrices; vec is float64 (vec_is_f64) or
+ * float32 [cols], the type numpy's promotion evaluates the operation in (a float64 matrix: always float64; a float16
+ * matrix: float32 for float16 / float32 / 8- and 16-bit integer vectors, float64 otherwise), the result rounded once to
+ * the matrix's type; has_nan = a NaN was stored (:176).  op 2: integer x -= vec[col], vec int64 [cols], two's-complement
+ * wrap like numpy's cast.  op 3: x += 1 in the matrix's type (integers wrap), then y = log2(x) (:191-192); y_np_type must
+ * be numpy's result type: F64 for F64 and 32/64-bit integers, F16 for F16 and 8-bit integers, F32 for 16-bit integers.
+ * The cases numpy itself refuses (float statistics into an integer matrix, `+= 1` on bool) are the caller's to raise.  */
+int skr_host_apply(skr_ctx* ctx, void* x, int64_t rows, int64_t cols, int np_type, int op, const void* vec, int vec_is_f64,
+                   void* y, int y_np_type, int* has_nan);
+
 /* ---------------------------------------------------------------- Pearson (K6+K7) ------- */
 /* z = row-standardised x (pearson.py:35-38): per row, subtract the mean, divide by the
  * population std of the centred row.  F32 -> F32 or F64 -> F64, same shape.                 */

@@ -242,6 +242,74 @@ def normalize(raw, mean=True, std=True, log2="Log2.post"):
     return x, mean, std
 
 
+# --------------------------------------------------------------------------
+# The same three methods on a hand-assigned matrix that is NOT float32 —
+# kmer_counts.py:165-192 act on whatever dtype `self.counts` has
+# (test_kmer_counts.py:44-90 assigns it by hand).  Restated step by step in the
+# order numpy 2.x's `_methods._mean` / `_var` take for each dtype; pinned to
+# the reference by tests/golden/g11_other_dtypes (test_oracle_golden.py).
+# --------------------------------------------------------------------------
+def seqsum_any(x, acc_dtype):
+    """Rows added one after the other into one accumulator per column of type
+    `acc_dtype` (np.add.reduce along axis 0 of a C-contiguous matrix), every
+    addition rounded to that type."""
+    acc = np.zeros(x.shape[1], dtype=acc_dtype)
+    for i in range(x.shape[0]):
+        acc = (acc + x[i].astype(acc_dtype)).astype(acc_dtype)
+    return acc
+
+
+def column_mean_any(x):
+    """np.mean(x, axis=0) (:168): float16 sums in float32, the quotient is taken
+    in float64 (float32 array / intp scalar), stored as float32 and then cast
+    to float16; integers are converted to float64; float64 is itself."""
+    n = x.shape[0]
+    with np.errstate(all="ignore"):
+        if x.dtype == np.float16:
+            s = seqsum_any(x, np.float32)
+            return (s.astype(np.float64) / n).astype(np.float32).astype(np.float16)
+        return seqsum_any(x, np.float64) / n
+
+
+def column_std_any(x):
+    """np.std(x, axis=0) (:174): float16 stays float16 at every step (each
+    quotient by N taken in float64 and rounded once to half); everything else
+    runs in float64."""
+    n = x.shape[0]
+    dt = np.float16 if x.dtype == np.float16 else np.float64
+    with np.errstate(all="ignore"):
+        m = (seqsum_any(x, dt).astype(np.float64) / n).astype(dt)
+        d = (x.astype(dt) - m).astype(dt)
+        d = (d * d).astype(dt)
+        v = (seqsum_any(d, dt).astype(np.float64) / n).astype(dt)
+        return np.sqrt(v)
+
+
+def host_center(counts, mean=True):
+    """:165-169 on `counts` IN PLACE; raises what numpy raises (float statistics
+    do not cast into an integer matrix).  Returns the mean that was used — it
+    replaces the attribute BEFORE the subtraction, so callers that want the
+    reference's state after an exception pass a holder: see the tests."""
+    if mean is True:
+        mean = column_mean_any(counts)
+    return mean, (lambda: np.subtract(counts, mean, out=counts))
+
+
+def host_standardize(counts, std=True):
+    """:171-175, same contract as host_center."""
+    if std is True:
+        std = column_std_any(counts)
+    return std, (lambda: np.true_divide(counts, std, out=counts))
+
+
+def host_log2_norm(counts):
+    """:189-192: `counts += 1` in place (integers wrap), then a NEW array
+    np.log2(counts) whose dtype follows numpy's loops."""
+    np.add(counts, 1, out=counts)
+    with np.errstate(all="ignore"):
+        return np.log2(counts)
+
+
 def get_counts(seqs, k=6, mean=True, std=True, log2="Log2.post", alphabet="AGTC"):
     """BasicCounter(...).get_counts() end to end (:194-209)."""
     if len(seqs) == 1 and std is True:

@@ -140,6 +140,8 @@ SIGNATURES = {
     "skr_comm_exchange": (_int, [_p, _int, _p, _p, _p, _p, _p, _p, _p, _p, C.POINTER(_i64)]),
     "skr_comm_wait": (_int, [_p, _i64]),
     "skr_comm_allreduce_f64": (_int, [_p, C.POINTER(C.c_double), _int, _int]),
+    "skr_host_colstat": (_int, [_p, _p, _i64, _i64, _int, _int, _p]),
+    "skr_host_apply": (_int, [_p, _p, _i64, _i64, _int, _int, _p, _int, _p, _int, C.POINTER(_int)]),
 }
 # libseekr_hip_diag.so only (tools/gemm_diag.py sets LIB_PATH to it before the first call)
 DIAG_SIGNATURES = {
@@ -732,6 +734,34 @@ def count_generic_dev(ctx, aseqs, alphabet, k, dtype=np.float32, log2_pre=False,
     out = ctx.empty(aseqs.n, len(alpha) ** k, dtype) if out is None else out
     check(lib().skr_count_generic_dev(ctx._h, aseqs._h, alpha, len(alpha), int(k), 1 if log2_pre else 0, out._h))
     return out
+
+
+# ---- BasicCounter's normalisation methods on a host matrix that is not float32 (skr_host_colstat / skr_host_apply)
+NP_CODES = {np.dtype(np.float16): 0, np.dtype(np.float32): 1, np.dtype(np.float64): 2, np.dtype(np.int8): 3, np.dtype(np.int16): 4,
+            np.dtype(np.int32): 5, np.dtype(np.int64): 6, np.dtype(np.uint8): 7, np.dtype(np.uint16): 8, np.dtype(np.uint32): 9,
+            np.dtype(np.uint64): 10, np.dtype(np.bool_): 11}
+
+
+def host_colstat(ctx, x, what):
+    """np.mean (what = 'mean') / np.std ('std') along axis 0 of a C-contiguous host matrix of any supported dtype, evaluated
+    on the device in numpy's order for that dtype; float16 in, float16 out — every other type gives float64."""
+    out = np.empty(x.shape[1], dtype=np.float16 if x.dtype == np.float16 else np.float64)
+    check(lib().skr_host_colstat(ctx._h, x.ctypes.data_as(_p), x.shape[0], x.shape[1], NP_CODES[x.dtype],
+                                 {"mean": 0, "std": 1}[what], out.ctypes.data_as(_p)))
+    return out
+
+
+def host_apply(ctx, x, op, vec=None, out=None):
+    """In place on the C-contiguous host matrix x: 'sub' / 'div' by the float32 or float64 vector `vec`, 'isub' by an int64
+    vector, 'log2p1' (x += 1, out = log2(x)).  Returns has_nan."""
+    code = {"sub": 0, "div": 1, "isub": 2, "log2p1": 3}[op]
+    nan = _int(0)
+    check(lib().skr_host_apply(ctx._h, x.ctypes.data_as(_p), x.shape[0], x.shape[1], NP_CODES[x.dtype], code,
+                               vec.ctypes.data_as(_p) if vec is not None else None,
+                               1 if vec is not None and vec.dtype == np.float64 else 0,
+                               out.ctypes.data_as(_p) if out is not None else None, NP_CODES[out.dtype] if out is not None else 0,
+                               C.byref(nan)))
+    return bool(nan.value)
 
 
 def colsum_seq(ctx, x, acc, center=None, center2=None, square=False):

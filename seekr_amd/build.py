@@ -14,7 +14,7 @@ OBJDIR = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libseekr_hip.so")
 DIAG_LIB = os.path.join(HERE, "libseekr_hip_diag.so")
 DIAG_SOURCES = ["pearson_bf16.hip"]  # compiled a second time with -DSEEKR_DIAG for the diagnostic library
-SOURCES = ["ctx.hip", "pack.hip", "count.hip", "normalize.hip", "pearson.hip", "pearson_bf16.hip", "operand.hip",
+SOURCES = ["ctx.hip", "pack.hip", "count.hip", "normalize.hip", "normalize_any.hip", "pearson.hip", "pearson_bf16.hip", "operand.hip",
            "consumers.hip", "fused_edges.hip", "comm.hip", "io.hip", "csv_read.hip", "host_api.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
@@ -22,6 +22,7 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-
 PER_FILE = {
     # numpy-order parity: no FMA contraction anywhere in the normalisation / scaling arithmetic
     "normalize.hip": ["-ffp-contract=off"],
+    "normalize_any.hip": ["-ffp-contract=off"],
     "count.hip": ["-ffp-contract=off"],
     # the 4-wave geometry of the contraction has 64 accumulator tiles per lane: its epilogue loops are only unrolled (and
     # the accumulator array only kept in registers) above clang's default 16 384-instruction limit for `#pragma unroll`

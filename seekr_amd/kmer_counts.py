@@ -202,13 +202,67 @@ class BasicCounter:
 
     # ---- host-array versions of the normalisation steps (kmer_counts.py:165-192) -----------
     def _device_counts(self):
+        return self._ctx().from_numpy(np.asarray(self.counts))
+
+    def _other_dtype(self):
+        """`self.counts` when it is NOT float32 — a matrix assigned by hand (test_kmer_counts.py:44-90 does; a float64
+        matrix read from a CSV, an integer one): the reference's methods act on whatever dtype it has, so do these
+        (skr_host_colstat / skr_host_apply: numpy's arithmetic for that dtype, on the device).  None for float32, the
+        dtype get_counts() produces and the tuned kernels take."""
         counts = np.asarray(self.counts)
         if counts.ndim != 2:
             raise ValueError("counts must be a 2-D matrix")
-        if counts.dtype != np.float32:
-            raise TypeError("the MI355X normalisation kernels work on float32 count matrices "
-                            "(got {}); get_counts() always produces float32".format(counts.dtype))
-        return self._ctx().from_numpy(counts)
+        if counts.dtype == np.float32:
+            return None
+        if counts.dtype not in _lib.NP_CODES:
+            raise TypeError("count matrices of dtype {} are not supported on the device (float16/32/64, integers and "
+                            "bool are)".format(counts.dtype))
+        return counts
+
+    @staticmethod
+    def _replay(ufunc, counts, operand):
+        """numpy's own verdict on the in-place `counts <op>= operand`, asked on a ZERO-row slice: type resolution, the
+        same_kind casting rule, broadcasting and the read-only check all run, no cell is computed.  What the reference
+        raises — UFuncTypeError for float statistics into an integer matrix (`counts -= mean`, kmer_counts.py:169,175),
+        ValueError for a vector of the wrong length — is raised here as numpy words it."""
+        probe = counts[:0]
+        ufunc(probe, operand, out=probe)
+
+    @staticmethod
+    def _vector_for(counts, operand):
+        """The column vector of `counts <op>= operand` in the type numpy evaluates the operation in: a Python scalar is
+        weak (it takes the matrix's type), an array promotes — float64 matrix: float64; float16 matrix: float32 when the
+        promoted type is float16 / float32 (half arithmetic IS float32 arithmetic rounded to half), else float64."""
+        cols = counts.shape[1]
+        if isinstance(operand, (bool, int, float)):
+            vec = np.asarray(operand, dtype=counts.dtype)
+        else:
+            vec = np.asarray(operand)
+        if counts.dtype.kind != "f":
+            return np.ascontiguousarray(np.broadcast_to(vec, (cols,))).astype(np.int64)  # legal integer case only (see _replay)
+        wide = counts.dtype == np.float64 or np.result_type(counts.dtype, vec.dtype).itemsize > 4
+        return np.ascontiguousarray(np.broadcast_to(vec, (cols,))).astype(np.float64 if wide else np.float32)
+
+    def _finish_host(self, counts, work):
+        """`work` (C-contiguous, holding the result) back where the reference's in-place operation leaves it."""
+        if work is counts:
+            return  # the device result was downloaded straight into the caller's matrix
+        if isinstance(self.counts, np.ndarray):
+            self.counts[...] = work
+        else:
+            self.counts = work
+
+    def _in_place_any(self, counts, attr, what, ufunc, op):
+        ctx = self._ctx()
+        work = np.ascontiguousarray(counts)
+        if getattr(self, attr) is True:
+            setattr(self, attr, _lib.host_colstat(ctx, work, what))  # (:168,174: the attribute is replaced first)
+        operand = getattr(self, attr)
+        self._replay(ufunc, counts, operand)
+        vec = self._vector_for(counts, operand)
+        has_nan = _lib.host_apply(ctx, work, op if counts.dtype.kind == "f" else "isub", vec)
+        self._finish_host(counts, work)
+        return has_nan
 
     def _store(self, dev):
         if isinstance(self.counts, np.ndarray) and self.counts.flags.c_contiguous and self.counts.flags.writeable:
@@ -219,6 +273,10 @@ class BasicCounter:
     @_lib.api_call
     def center(self):
         """Mean center counts by column (:165-169)."""
+        other = self._other_dtype()
+        if other is not None:
+            self._in_place_any(other, "mean", "mean", np.subtract, "sub")
+            return
         ctx = self._ctx()
         dev = self._device_counts()
         if self.mean is True:
@@ -235,6 +293,11 @@ class BasicCounter:
     @_lib.api_call
     def standardize(self):
         """Divide out the standard deviations from columns of the count matrix (:171-187)."""
+        other = self._other_dtype()
+        if other is not None:
+            if self._in_place_any(other, "std", "std", np.true_divide, "div"):
+                print(NAN_WARNING)
+            return
         ctx = self._ctx()
         dev = self._device_counts()
         if self.std is True:
@@ -256,6 +319,15 @@ class BasicCounter:
     @_lib.api_call
     def log2_norm(self):
         """Apply a log2 transform to the count matrix (:189-192): counts += 1; log2."""
+        other = self._other_dtype()
+        if other is not None:
+            self._replay(np.add, other, 1)  # `counts += 1`: numpy refuses it on bool
+            work = np.ascontiguousarray(other)
+            out = np.empty(work.shape, dtype=np.log2(other[:0]).dtype)  # numpy's result type (no cell computed)
+            _lib.host_apply(self._ctx(), work, "log2p1", out=out)
+            self._finish_host(other, work)  # the reference's `+= 1` is in place, the log2 a new array
+            self.counts = out
+            return
         ctx = self._ctx()
         dev = self._device_counts()
         _lib.apply(ctx, dev, pre=True)

@@ -1624,3 +1624,58 @@ def test_f16f8_degrades_on_other_widths_and_through_the_api(L, ctx, monkeypatch)
     assert np.allclose(got, want, rtol=RTOL, atol=ATOL_R)
     got2 = pearson(y, y[:100] * np.float32(3.0) + np.float32(1.0))
     assert np.allclose(got2, want[:, :100], rtol=RTOL, atol=ATOL_R)
+
+
+# ------------------------------------------------------------------ G11: normalisation methods on any host dtype
+def test_g11_normalisation_methods_on_matrices_that_are_not_float32(golden_dir):
+    """VERDICT r5 missing #3: center() / standardize() / log2_norm() on a hand-assigned count matrix that is not float32
+    (kmer_counts.py:165-192 act on whatever dtype it has).  Golden set G11, made by the reference on float64 / float16 /
+    integer / bool matrices of 7 x 5 and 3 000 x 256 with computed and user-supplied vectors of six types: the device
+    path (skr_host_colstat / skr_host_apply) leaves the reference's BYTES for mean, std and the centred / scaled matrices
+    of every dtype — float64 bit-exact is the bar, float16 and the integer cases come out exact too — log2 outputs
+    within |a - b| <= 1e-6 + 1e-5 |b| (one unit of half for float16), and numpy's own exception, worded as numpy words
+    it, where the reference gets one (with `mean` / `std` already replaced by the computed vector)."""
+    import g11_cases
+    from seekr_amd.kmer_counts import BasicCounter
+    assert g11_cases.check_all(golden_dir, g11_cases.run_counter(BasicCounter)) == 9 * 2 * 16
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float16", "int32"])
+def test_normalisation_on_other_dtypes_is_in_place_like_the_reference(dtype):
+    """`counts -= mean` / `counts /= std` are in-place operations in the reference (kmer_counts.py:169,175): the caller's
+    own array holds the result afterwards, also when it is a non-contiguous view; log2_norm adds 1 in place and binds a
+    NEW array (:191-192).  Random matrices against the oracle's restatement, bit for bit."""
+    from seekr_amd.kmer_counts import BasicCounter
+    rng = np.random.default_rng(5)
+    base = (rng.poisson(1.3, size=(40, 24)) * (0.5 if dtype != "int32" else 1)).astype(dtype)
+    for view in (lambda a: a, lambda a: a[:, ::2], lambda a: a.T):
+        mine = base.copy()
+        target = view(mine)
+        c = BasicCounter(k=1, silent=True)
+        c.counts = target
+        want = np.ascontiguousarray(view(base.copy()))
+        if dtype == "int32":
+            vec = np.arange(target.shape[1], dtype=np.int64)
+            c.mean = vec
+            c.center()
+            orc.host_center(want, vec)[1]()
+            assert c.counts is target and np.array_equal(target, want)
+        else:
+            c.center()
+            m, op = orc.host_center(want)
+            op()
+            assert c.counts is target and target.tobytes() == want.tobytes() and c.mean.tobytes() == m.tobytes()
+            with contextlib.redirect_stdout(io.StringIO()):
+                c.standardize()
+            s, op = orc.host_standardize(want)
+            with np.errstate(all="ignore"):
+                op()
+            assert c.counts is target and np.array_equal(target, want, equal_nan=True) and c.std.tobytes() == s.tobytes()
+        before = view(base.copy()).copy()
+        c2 = BasicCounter(k=1, silent=True)
+        held = view(base.copy())
+        c2.counts = held
+        c2.log2_norm()
+        assert c2.counts is not held and np.array_equal(held, before + 1)  # the `+= 1` landed in the caller's array
+        with np.errstate(all="ignore"):
+            assert np.allclose(c2.counts, np.log2(before + 1), rtol=2e-3 if dtype == "float16" else 1e-12, equal_nan=True)

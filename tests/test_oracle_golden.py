@@ -397,6 +397,15 @@ def test_g10_native_parser_declines_every_file_with_a_high_byte(golden_dir, tmp_
         del os.environ["SEEKR_FASTA_PIECE_BYTES"]
 
 
+def test_g11_normalisation_methods_on_matrices_that_are_not_float32(golden_dir):
+    """kmer_counts.py:165-192 on hand-assigned float64 / float16 / integer / bool matrices (7 x 5 and 3 000 x 256): the
+    oracle's step-by-step restatement of numpy's `_mean` / `_var` per dtype (row-sequential sums; float16 mean in float32,
+    float16 std in half steps; integers through float64) leaves the reference's bytes — mean, std, centred / scaled matrices
+    exact, log2 within the bar — and numpy's exception where the reference gets one (with the attribute already replaced)."""
+    import g11_cases
+    assert g11_cases.check_all(golden_dir, g11_cases.run_oracle(orc)) == 9 * 2 * 16
+
+
 def test_numpy_adds_a_row_in_the_pairwise_order_the_fill_kernel_reproduces():
     """The order seekr_amd/csrc/operand.hip: np_pairwise_sum reproduces on the device, restated in Python and pinned
     against np.add.reduce itself (float32, every length up to 300 and the widths the product meets): fewer than 8 values
