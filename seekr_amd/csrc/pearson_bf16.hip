@@ -129,6 +129,11 @@ __device__ __forceinline__ void mfma16x16_pinned(f32x4v& c, vec8<__bf16> a, vec8
 __device__ __forceinline__ void mfma16x16_pinned(f32x4v& c, vec8<_Float16> a, vec8<_Float16> b) {
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
+// lane <- lane ^ 1 (CTRL 0xB1 = quad_perm [1,0,3,2]) / lane ^ 2 (0x4E = [2,3,0,1]) inside each quad of lanes: one DPP move
+template <int CTRL>
+__device__ __forceinline__ float quad_perm(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
 // an MFMA's result may be read by anything but the next MFMA's C operand only 12+ wait states after issue (8-pass XDL)
 __device__ __forceinline__ void mfma_drain() {
     __builtin_amdgcn_sched_barrier(0);
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
     int64_t M, int64_t N, int64_t kt, int64_t ldc, int64_t ldct, float kdiv, int64_t tiles_m, int64_t tiles_n,
     int64_t super_n, uint32_t* __restrict__ queues, int64_t slots_per_queue, int64_t pitch_tiles, int flags,
     unsigned long long* __restrict__ diag, const EdgeSink es) {
-    const int accumulate = flags & 1;  // later k chunks add to what the earlier ones left in C; bit 1: last chunk; bits 8..: tile order shape
+    const int accumulate = flags & 1;  // later k chunks add to what the earlier ones left in C; bit 1: last chunk; bits 2-3: lean epilogue (0 = off, 1-3 = 64 / 128 / 256-byte row runs); bits 8..: tile order shape
     static_assert(WAVES == 8 || (WAVES == 4 && NPROD == 3), "4-wave geometry: three products only");
     static_assert(NPROD != 2 || (std::is_same<T, _Float16>::value && WAVES == 8), "f16f8: fp16 hi lines, 8-wave geometry");
     constexpr int WN = WAVES == 8 ? 4 : 2, MT = 8, NT = WAVES == 8 ? 4 : 8, PP = 32 / WAVES;  // waves as 2 x WN, wave tile 128 x 16 NT
@@ -585,8 +590,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
 #pragma unroll
         for (int e = 0; e < 4; e += 2) {
             const float send = (j & 1) ? v[e] : v[e + 1];
-            // lane ^ 1 / lane ^ 2 inside a quad: one DPP move (quad_perm) instead of the ds_bpermute __shfl_xor compiles to —
-            // 128 LDS operations per wave and tile less in an epilogue that shares the LDS pipe with the next tile's staging
+            // lane ^ 1 / lane ^ 2 inside a quad (ds_bpermute; DPP quad_perm moves were measured 1 % slower in round 5 and reverted)
             const float recv = __shfl_xor(send, 1, 64);
             if (j & 1) v[e] = recv; else v[e + 1] = recv;
         }
@@ -608,6 +612,199 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
                 if (m0 + e < M) dst[e] = v[e];
         }
     };
+    // The LEAN epilogue (round 6): what nearly every tile of a launch is — whole, off the diagonal, one k chunk, the divisor
+    // a power of two, rows of r 16-byte aligned — stored without a test, a 64-bit multiply or a branch per cell.  The
+    // general loop below spends ~130 instructions per accumulator tile on bounds, alignment, the diagonal and the
+    // multiply-or-divide choice (4 200 per wave and tile, two waves per SIMD: the 16 us of a tile's epilogue were issue
+    // slots, not stores); here an accumulator tile is 4 multiplies, the quad transpose and two 16-byte stores whose
+    // addresses are a scalar base per (mt | nt) + one per-lane 32-bit offset + an immediate.  Same values, same cells,
+    // same cells: r is the same bits.  flags bits 2-3 (SEEKR_GEMM_EPILOGUE: 0 = off, 1 / 2 / 3 = the run length
+    // below) select it; every other tile takes the general loop.
+    const bool lean = (flags & 12) && !accumulate && rk != 0.f && row_base + TM <= M && col_base + TN <= N && !(SYM && tm == tn) &&
+                      ldc < (int64_t(1) << 26) && ((reinterpret_cast<uintptr_t>(C) | (uintptr_t)(ldc * 4)) & 15) == 0 &&
+                      (!mirror || (ldct < (int64_t(1) << 26) && ((reinterpret_cast<uintptr_t>(Ct) | (uintptr_t)(ldct * 4)) & 15) == 0));
+    if (DIAG && (diag[1] & 32)) {
+        // diagnostic only (round 6): NO store at all — the timing ceiling of any scheme that hides the epilogue under the
+        // next tile's k loop; the accumulators are still read, r stays unwritten
+        float sink = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) sink += acc[mt][nt][0] + acc[mt][nt][1] + acc[mt][nt][2] + acc[mt][nt][3];
+        if (sink == 123.456f) C[0] = sink;
+    } else if (lean) {
+        // Lane geometry of a 16 x 16 accumulator tile: lane = 16 rho + c holds column c, rows 4 rho .. 4 rho + 3 (c = 4 g + j).
+        // RUN = bytes of one row of r that one store instruction covers: 64 is what the MFMA layout gives after the 4 x 4
+        // transpose inside each quad of lanes (16 rows x 64 B per instruction); with G = RUN / 64 neighbouring accumulator tiles
+        // exchanged between lane groups first an instruction covers 8 rows x 128 B or 4 rows x 256 B.  tools/micro/tile_store
+        // (stores alone, this tile walk, whole chip): 3.7 TB/s with 64-byte runs, 4.6 with 128, 5.3 with 256 — HBM takes
+        // half-line writes badly, and the write stream competes with the k loops' staging loads of every other CU.
+        //   direct tile (rows of r): v_permlane32_swap pairs tile nt with nt + 1 (lane halves), v_permlane16_swap pairs of pairs;
+        //   mirror (columns of the tile become rows): DPP row_ror:8 / row_shr:4 / row_shl:4 pair tile mt with mt + 1, pairs of pairs.
+        // All of it moves finished values between lanes: r is the same bits whatever RUN (tools/epilogue_check.py).
+        // (the lane's geometry is re-derived HERE for every tile: taken from `lane` directly, the dozen values below are loop
+        // invariants of the persistent loop, hoisted above it and kept alive through the k loop — where the kernel has no
+        // register to spare: 256 VGPRs and 600 bytes of scratch instead of 215 and none)
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int c = lane_e & 15, g = c >> 2, j = lane_e & 3, rho = lane_e >> 4;
+        const bool odd = (j & 1) != 0, upper = (j & 2) != 0, c_hi = (c & 8) != 0, c_mid = (c & 4) != 0;
+        char* cw = reinterpret_cast<char*>(C + (size_t)(row_base + wm * 128) * ldc + col_base + wn * WTN);  // wave-uniform
+        const size_t d_step = (size_t)ldc * 64;  // 16 rows down
+        char* tw[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+            tw[nt] = reinterpret_cast<char*>(Ct + (size_t)(col_base + wn * WTN + nt * 16) * ldct + row_base + wm * 128);
+        auto swap32 = [](float& a, float& b) {  // a's lanes 32-63 <-> b's lanes 0-31
+            // (the two results are copied into scalars first: __builtin_bit_cast(float, r[1]) straight from the vector element
+            // reads element 0 with this clang — both outputs of the swap then compile to the first)
+            const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+            const unsigned r0 = r[0], r1 = r[1];
+            a = __builtin_bit_cast(float, r0);
+            b = __builtin_bit_cast(float, r1);
+        };
+        auto swap16 = [](float& a, float& b) {  // a's odd 16-lane rows <-> b's even ones (row 1 <-> row 0, row 3 <-> row 2)
+            const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+            const unsigned r0 = r[0], r1 = r[1];
+            a = __builtin_bit_cast(float, r0);
+            b = __builtin_bit_cast(float, r1);
+        };
+        auto put = [](const float (&v)[4], char* base, uint32_t off) {
+            __builtin_nontemporal_store(f32x4v{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4v*>(base + (size_t)off));
+        };
+        // every accumulator is scaled where it is stored — twice for a tile with a mirror, by the SAME factor under two
+        // names: one name, and the compiler merges the two multiplications into 128 scaled copies that live from the first
+        // pass to the second (256 VGPRs + scratch instead of 215)
+        float rk_m = rk;
+        asm volatile("" : "+v"(rk_m));
+        auto body = [&](auto with_mirror, auto run_c) {
+            constexpr int G = decltype(run_c)::value / 64;  // accumulator tiles per row run
+            // ---- the direct tile
+            const int tile_d = G == 1 ? 0 : (G == 2 ? (rho >> 1) : (((rho & 1) << 1) | (rho >> 1)));  // which tile of its group a lane stores
+            const int row_d = G == 1 ? 4 * rho + j : (G == 2 ? 4 * (rho & 1) + j : j);                 // ... and which of the first rows
+            const uint32_t d_off = (uint32_t)((row_d * ldc + 16 * tile_d + 4 * g) * 4);
+            const size_t d_rows = (size_t)ldc * (16 / G) * 4;  // from one store of a group to the next: 16 / G rows down
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+#pragma unroll
+                for (int nb = 0; nb < NT / G; nb++) {
+                    float t[G][4];
+#pragma unroll
+                    for (int i = 0; i < G; i++) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) t[i][e] = acc[mt][nb * G + i][e] * rk;
+#pragma unroll
+                        for (int e = 0; e < 4; e += 2) {  // 4 x 4 transpose inside the quads: lane j ends up with row 4 rho + j, four columns
+                            const float t0 = quad_perm<0xB1>(t[i][e]), t1 = quad_perm<0xB1>(t[i][e + 1]);
+                            t[i][e + 1] = odd ? t[i][e + 1] : t0;
+                            t[i][e] = odd ? t1 : t[i][e];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 2; e++) {
+                            const float t0 = quad_perm<0x4E>(t[i][e]), t1 = quad_perm<0x4E>(t[i][e + 2]);
+                            t[i][e + 2] = upper ? t[i][e + 2] : t0;
+                            t[i][e] = upper ? t1 : t[i][e];
+                        }
+                    }
+                    char* base = cw + nb * (64 * G);
+                    if constexpr (G == 1) {
+                        put(t[0], base, d_off);
+                    } else if constexpr (G == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) swap32(t[0][e], t[1][e]);  // t[0]: rows 0-7 of both tiles, t[1]: rows 8-15
+                        put(t[0], base, d_off);
+                        put(t[1], base + d_rows, d_off);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            swap32(t[0][e], t[1][e]);
+                            swap32(t[2][e], t[3][e]);
+                            swap16(t[0][e], t[2][e]);  // t[0]: rows 0-3 of the four tiles, t[2]: rows 4-7
+                            swap16(t[1][e], t[3][e]);  // t[1]: rows 8-11, t[3]: rows 12-15
+                        }
+                        put(t[0], base, d_off);
+                        put(t[2], base + d_rows, d_off);
+                        put(t[1], base + 2 * d_rows, d_off);
+                        put(t[3], base + 3 * d_rows, d_off);
+                    }
+                    // one group at a time: left to itself the scheduler interleaves the 32 independent groups of this 3 000-
+                    // instruction block until all 256 registers are in use, and the allocator then spills accumulators
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                cw += d_step;
+            }
+            // ---- the mirror: a lane's four rows are four consecutive cells of row (column index) of Ct
+            if constexpr (decltype(with_mirror)::value) {
+                const int row_m = G == 1 ? c : (G == 2 ? (c & 7) : (c & 3));
+                const int tile_m = G == 1 ? 0 : (G == 2 ? (c >> 3) : ((((c >> 2) & 1) << 1) | (c >> 3)));
+                const uint32_t m_off = (uint32_t)((row_m * ldct + 16 * tile_m + 4 * rho) * 4);
+                const size_t m_rows = (size_t)ldct * (16 / G) * 4;
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+#pragma unroll
+                    for (int mb = 0; mb < MT / G; mb++) {
+                        float u[G][4];
+#pragma unroll
+                        for (int i = 0; i < G; i++)
+#pragma unroll
+                            for (int e = 0; e < 4; e++) u[i][e] = acc[mb * G + i][nt][e] * rk_m;
+                        char* base = tw[nt] + mb * (64 * G);
+                        if constexpr (G == 1) {
+                            put(u[0], base, m_off);
+                        } else {
+                            // columns 0-7 of tile i meet columns 0-7 of tile i + 1 (lane c <-> c ^ 8): a = mirror rows 0-7, b = rows 8-15
+                            auto pair8 = [&](float (&x)[4], float (&y)[4]) {
+#pragma unroll
+                                for (int e = 0; e < 4; e++) {
+                                    const float xr = quad_perm<0x128>(x[e]), yr = quad_perm<0x128>(y[e]);  // row_ror:8
+                                    x[e] = c_hi ? yr : x[e];
+                                    y[e] = c_hi ? y[e] : xr;
+                                }
+                            };
+                            pair8(u[0], u[1]);
+                            if constexpr (G == 2) {
+                                put(u[0], base, m_off);
+                                put(u[1], base + m_rows, m_off);
+                            } else {
+                                pair8(u[2], u[3]);
+                                // ... and the two pairs (lane c <-> c ^ 4): x = mirror rows c & 3 of four tiles, y = rows 4 + (c & 3)
+                                auto pair4 = [&](float (&x)[4], float (&y)[4]) {
+#pragma unroll
+                                    for (int e = 0; e < 4; e++) {
+                                        const float yd = quad_perm<0x114>(y[e]), xu = quad_perm<0x104>(x[e]);  // row_shr:4 (from lane c - 4), row_shl:4 (from c + 4)
+                                        x[e] = c_mid ? yd : x[e];
+                                        y[e] = c_mid ? y[e] : xu;
+                                    }
+                                };
+                                pair4(u[0], u[2]);  // u[0]: mirror rows 0-3, u[2]: rows 4-7
+                                pair4(u[1], u[3]);  // u[1]: rows 8-11, u[3]: rows 12-15
+                                put(u[0], base, m_off);
+                                put(u[2], base + m_rows, m_off);
+                                put(u[1], base + 2 * m_rows, m_off);
+                                put(u[3], base + 3 * m_rows, m_off);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        };
+#ifndef SEEKR_LEAN_RUN
+        const int run = (flags >> 2) & 3;  // 1: 64-byte runs, 2: 128, 3: 256
+        if (mirror) {
+            if (run == 3) body(std::true_type{}, std::integral_constant<int, 256>{});
+            else if (run == 2) body(std::true_type{}, std::integral_constant<int, 128>{});
+            else body(std::true_type{}, std::integral_constant<int, 64>{});
+        } else {
+            if (run == 3) body(std::false_type{}, std::integral_constant<int, 256>{});
+            else if (run == 2) body(std::false_type{}, std::integral_constant<int, 128>{});
+            else body(std::false_type{}, std::integral_constant<int, 64>{});
+        }
+#else
+        if (mirror) body(std::true_type{}, std::integral_constant<int, SEEKR_LEAN_RUN>{});
+        else body(std::false_type{}, std::integral_constant<int, SEEKR_LEAN_RUN>{});
+#endif
+    } else
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
@@ -710,8 +907,9 @@ int launch_chunk(skr_ctx* ctx, const T* Ac, const T* Bc, const SplitOut& o, int6
             // stores, 5 = two product-units per k (one int8 MFMA in place of the two cross products: timing ceiling)
             const int dmode = ctx->diag_mode;
             // 6 (f16f8 operands only) = the X line staged half (timing ceiling of a layout without the hi8 copies)
-            if (dmode >= 2 && dmode <= 6)
-                SKR_HIP(hipMemsetAsync(diag + 1, dmode == 2 ? 1 : (dmode == 3 ? 2 : (dmode == 4 ? 4 : (dmode == 5 ? 8 : 16))), 1, ctx->stream));
+            // 7 = no epilogue stores at all (timing ceiling of hiding the epilogue: round 6)
+            if (dmode >= 2 && dmode <= 7)
+                SKR_HIP(hipMemsetAsync(diag + 1, dmode == 2 ? 1 : (dmode == 3 ? 2 : (dmode == 4 ? 4 : (dmode == 5 ? 8 : (dmode == 6 ? 16 : 32)))), 1, ctx->stream));
             kern = pearson_gemm_split16_kernel<T, NPROD, (MODE == SELF ? SELF : PLAIN), true, true>;
         }
 #endif
@@ -732,13 +930,13 @@ int launch_chunk(skr_ctx* ctx, const T* Ac, const T* Bc, const SplitOut& o, int6
         const int reserve = ctx->knobs.gemm_reserve_cus >= 0 ? ctx->knobs.gemm_reserve_cus : (ctx->nranks > 1 ? 8 : 0);
         const unsigned grid = (unsigned)std::max(8, ctx->num_cu - reserve);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), 2 * kStageBytes, ctx->stream, Ac, Bc, o.C, o.Ct, M, N, ktc, o.ldc, o.ldct, K,
-                           tiles_m, tiles_n, super_n, queues, slots / 8, kt_pitch, accumulate | (ctx->knobs.gemm_subtile << 8), diag, es);
+                           tiles_m, tiles_n, super_n, queues, slots / 8, kt_pitch, accumulate | ((ctx->knobs.gemm_epilogue & 3) << 2) | (ctx->knobs.gemm_subtile << 8), diag, es);
     } else {
         auto kern = pearson_gemm_split16_kernel<T, NPROD, MODE, false>;
         SKR_TRY(skr_kernel_lds(ctx, reinterpret_cast<const void*>(kern), 2 * kStageBytes));
         hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(512), 2 * kStageBytes, ctx->stream, Ac, Bc, o.C, o.Ct, M, N, ktc, o.ldc,
                            o.ldct, K, tiles_m, tiles_n, super_n, (uint32_t*)nullptr, (int64_t)0, kt_pitch,
-                           accumulate | (ctx->knobs.gemm_subtile << 8), (unsigned long long*)nullptr, es);
+                           accumulate | ((ctx->knobs.gemm_epilogue & 3) << 2) | (ctx->knobs.gemm_subtile << 8), (unsigned long long*)nullptr, es);
     }
     SKR_HIP(hipGetLastError());
     return SKR_OK;
@@ -844,9 +1042,9 @@ extern "C" int skr_gemm_diag_read(skr_ctx* ctx, unsigned long long* out, int64_t
     return SKR_OK;
 }
 
-// 0 = production kernels; 1 = stamps only (r stays valid); 2-6 = timing experiments that make r meaningless (above)
+// 0 = production kernels; 1 = stamps only (r stays valid); 2-7 = timing experiments that make r meaningless (above)
 extern "C" int skr_gemm_diag_mode(skr_ctx* ctx, int mode) {
-    SKR_REQUIRE(ctx && mode >= 0 && mode <= 6, "mode 0..6");
+    SKR_REQUIRE(ctx && mode >= 0 && mode <= 7, "mode 0..7");
     ctx->diag_mode = mode;
     return SKR_OK;
 }

@@ -30,6 +30,7 @@ ap.add_argument("--same-tile", action="store_true", help="every stage re-loads k
 ap.add_argument("--two-units", action="store_true", help="TIMING CEILING of a two-product-unit split (VERDICT r3 #5): one v_mfma_i32_16x16x64_i8 in place of the two cross products, same staging and LDS reads; r is garbage.  Printed next to a stamps-only launch of the same process")
 ap.add_argument("--half-x", action="store_true", help="f16f8 operands; TIMING CEILING of an H / X layout whose X line carries lo8 alone (staged half); r is garbage.  Printed next to a stamps-only launch of the f16f8 kernel")
 ap.add_argument("--no-mirror", action="store_true", help="self mode without the mirror stores (timing experiment; the lower triangle stays unwritten)")
+ap.add_argument("--no-stores", action="store_true", help="NO epilogue store at all (round 6): the timing ceiling of hiding the epilogue under the next tile's k loop; r stays unwritten.  Printed next to a stamps-only launch of the same process")
 args = ap.parse_args()
 ctx = _lib.default_context()
 rng = np.random.default_rng(0)
@@ -94,6 +95,11 @@ if args.half_x:
     for rep in range(3):
         a_ms = one_launch(1, "f16f8 as shipped (stamps only)")
         b_ms = one_launch(6, "f16f8 with the X line staged half (timing ceiling)")
+        print("==== launch %.3f -> %.3f ms: %+.1f %%" % (a_ms, b_ms, (b_ms / a_ms - 1) * 100))
+elif args.no_stores:
+    for rep in range(3):
+        a_ms = one_launch(1, "as shipped (stamps only)")
+        b_ms = one_launch(7, "no epilogue stores (timing ceiling)")
         print("==== launch %.3f -> %.3f ms: %+.1f %%" % (a_ms, b_ms, (b_ms / a_ms - 1) * 100))
 elif mode == 5:
     for rep in range(3):  # alternate in one process: stamps only / two product-units
