@@ -107,6 +107,9 @@ int skr_mat_download(const skr_mat* m, void* host, int64_t row0, int64_t nrows);
  * row stripe at a time enqueues the contraction of stripe s + 1, then downloads stripe s: the two overlap.  A mark is
  * used once; mark < 0 = "everything enqueued so far".                                                                */
 int skr_ctx_mark(skr_ctx* ctx, int64_t* mark);
+/* A mark is used up by the one call it is passed to — also when that call refuses its other arguments.  A mark that will
+ * never be passed on is handed back with skr_ctx_mark_release (unknown / used marks are ignored).                        */
+int skr_ctx_mark_release(skr_ctx* ctx, int64_t mark);
 int skr_mat_download_at(const skr_mat* m, void* host, int64_t row0, int64_t nrows, int64_t mark);
 int skr_mat_fill_zero(skr_mat* m);
 /* non-owning view of rows [row0, row0+nrows) of `parent`; free it with skr_mat_free before the parent */

@@ -51,6 +51,7 @@ SIGNATURES = {
     "skr_mat_download": (_int, [_p, _p, _i64, _i64]),
     "skr_mat_fill_zero": (_int, [_p]),
     "skr_ctx_mark": (_int, [_p, C.POINTER(_i64)]),
+    "skr_ctx_mark_release": (_int, [_p, _i64]),
     "skr_mat_download_at": (_int, [_p, _p, _i64, _i64, _i64]),
     "skr_npy_create": (_int, [C.c_char_p, _int, _i64, _i64, C.POINTER(_i64)]),
     "skr_mat_write_rows_at": (_int, [_p, _i64, _i64, C.c_char_p, _i64, _i64]),
@@ -279,6 +280,11 @@ class Context:
         m = _i64(-1)
         check(lib().skr_ctx_mark(self._h, C.byref(m)))
         return m.value
+
+    def mark_release(self, mark):
+        """Hand back a mark that will not be passed to a download after all (skr_ctx_mark_release; always safe)."""
+        if mark is not None and getattr(self, "_h", None) and not _shutdown:
+            lib().skr_ctx_mark_release(self._h, int(mark))
 
     def mem_info(self):
         """(free, total) bytes of device memory."""

@@ -174,6 +174,18 @@ extern "C" int skr_ctx_mark(skr_ctx* ctx, int64_t* mark) {
     return SKR_OK;
 }
 
+// A mark that will not be consumed after all (the consumer's arguments were refused, or the caller gave up before using
+// it): its slot goes back.  Unknown or already used marks are ignored — releasing is always safe.  (slots were
+// recycled by the consumer only, so 4 096 abandoned marks ended skr_ctx_mark for the ctx.)
+extern "C" int skr_ctx_mark_release(skr_ctx* ctx, int64_t mark) {
+    SKR_REQUIRE(ctx, "ctx is NULL");
+    if (mark >= 0 && mark < (int64_t)ctx->marks.size() && ctx->mark_live[mark]) {
+        ctx->mark_live[mark] = 0;
+        ctx->free_marks.push_back((int)mark);
+    }
+    return SKR_OK;
+}
+
 int skr_copy_stream_after(skr_ctx* ctx, int64_t mark, hipStream_t* out) {
     SKR_TRY(skr_activate(ctx));
     if (!ctx->copy_stream) SKR_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
@@ -451,7 +463,10 @@ extern "C" int skr_mat_download(const skr_mat* m, void* host, int64_t row0, int6
 // skr_mat_download beside the compute stream: the copy waits for `mark` (or, mark < 0, for what is enqueued now), the
 // compute stream does not wait for the copy — the caller enqueued the next stripe's contraction before it came here.
 extern "C" int skr_mat_download_at(const skr_mat* m, void* host, int64_t row0, int64_t nrows, int64_t mark) {
-    SKR_TRY(check_rows(m, host, row0, nrows));
+    if (const int rc = check_rows(m, host, row0, nrows)) {
+        if (m && m->ctx) (void)skr_ctx_mark_release(m->ctx, mark);  // a refused call still uses its mark up
+        return rc;
+    }
     hipStream_t cs = nullptr;
     SKR_TRY(skr_copy_stream_after(m->ctx, mark, &cs));
     size_t rb = (size_t)m->cols * m->elem();

@@ -616,9 +616,12 @@ extern "C" int skr_npy_create(const char* path, int dtype, int64_t rows, int64_t
 extern "C" int skr_mat_write_rows_at(const skr_mat* m, int64_t row0, int64_t nrows, const char* path, int64_t file_offset,
                                      int64_t mark) {
     SKR_REQUIRE(m && path, "NULL argument");
-    SKR_REQUIRE(row0 >= 0 && nrows >= 0 && row0 + nrows <= m->rows, "row range [%lld, %lld) outside 0..%lld", (long long)row0,
-                (long long)(row0 + nrows), (long long)m->rows);
-    SKR_REQUIRE(file_offset >= 0, "negative file offset");
+    if (!(row0 >= 0 && nrows >= 0 && row0 + nrows <= m->rows) || file_offset < 0) {
+        (void)skr_ctx_mark_release(m->ctx, mark);  // a refused call still uses its mark up
+        SKR_REQUIRE(file_offset >= 0, "negative file offset");
+        return skr_set_error(SKR_ERR_INVALID, "row range [%lld, %lld) outside 0..%lld", (long long)row0, (long long)(row0 + nrows),
+                             (long long)m->rows);
+    }
     skr_ctx* ctx = m->ctx;
     hipStream_t cs = nullptr;
     SKR_TRY(skr_copy_stream_after(ctx, mark, &cs));

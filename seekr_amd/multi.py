@@ -489,10 +489,14 @@ class ApiHipEngine(HipEngine):
             _lib.row_standardize(self.ctx, x, z)
         return z
 
-    def allgather_matrix(self, comm, z, bounds):
+    def gather_room(self, z, rows):
+        """Where the rows of all GPUs will be gathered (allocated inside a phase: see pearson_job)."""
+        return self.ctx.empty(rows, z.cols, z.dtype)
+
+    def allgather_matrix(self, comm, z, bounds, full=None):
         if comm.size == 1:
             return z
-        full = self.ctx.empty(bounds[-1], z.cols, z.dtype)
+        full = self.ctx.empty(bounds[-1], z.cols, z.dtype) if full is None else full
         comm.wait(comm.allgather_rows(z, full, bounds))
         return full
 
@@ -511,6 +515,9 @@ class ApiHipEngine(HipEngine):
     def mark(self):
         return self.ctx.mark()
 
+    def release_mark(self, mark):
+        self.ctx.mark_release(mark)
+
 
 class HostSink:
     """r lands in the caller's array: every GPU copies its stripes straight into its rows, over its own PCIe link."""
@@ -526,12 +533,25 @@ class NpySink:
     """r lands in a .npy file, stripe by stripe, never whole in host memory (np.save(outfile, dist), pearson.py:43)."""
 
     def __init__(self, path, dtype, rows, cols):
-        self.path = _lib.npy_path(path)
+        # np.save(outfile, dist) touches the file only once dist exists (pearson.py:41-43): the stripes go to a temporary
+        # file beside it, which takes the name when the job is done (commit) and disappears when it fails (discard) — a
+        # failed job neither leaves a full-size, valid-looking file of zeros nor destroys what was there (ADVICE r5)
+        self.final = _lib.npy_path(path)
+        self.path = "{}.part{}.npy".format(self.final[:-4], os.getpid())
         self.row_bytes = int(cols) * np.dtype(dtype).itemsize
         self.offset = _lib.npy_create(self.path, dtype, rows, cols)
 
     def put(self, buf, nrows, row0, mark):
         buf.write_rows_at(mark, self.path, self.offset + row0 * self.row_bytes, 0, nrows)
+
+    def commit(self):
+        os.replace(self.path, self.final)
+
+    def discard(self):
+        try:
+            os.unlink(self.path)
+        except OSError:
+            pass
 
 
 # ------------------------------------------------------------------------------ get_counts -----
@@ -640,48 +660,75 @@ def pearson_job(st, spec):
     lo, hi = b1[g], b1[g + 1]
     same = spec.c2 is None
     n_out, K = b2[-1], spec.c1.shape[1]
+    rows = hi - lo
+    # Everything this GPU must allocate or upload — its rows, the gathered operand, the stripe buffers — happens inside
+    # phases: a failure on ONE GPU (out of memory, say) is agreed on by all before anybody enters a device collective.
+    # Outside a phase the other GPU threads would sit in ncclSend / ncclRecv with no timeout, run() would never return, and
+    # — pearson() holding the API lock — neither would the process.
     if spec.f64:
-        z1 = eng.rows_f64(spec.c1[lo:hi], spec.row_standardize, spec.pad)
-        full = eng.allgather_matrix(comm, z1 if same else eng.rows_f64(spec.c2[b2[g]:b2[g + 1]], spec.row_standardize, spec.pad), b2)
+        def local_f64():
+            a = eng.rows_f64(spec.c1[lo:hi], spec.row_standardize, spec.pad)
+            own = a if same else eng.rows_f64(spec.c2[b2[g]:b2[g + 1]], spec.row_standardize, spec.pad)
+            return a, own, (eng.gather_room(own, n_out) if comm.size > 1 else None)
+        z1, own, room = st.phase(local_f64)
+        full = eng.allgather_matrix(comm, own, b2, room)
     else:
-        x1 = eng.upload(spec.c1[lo:hi])
+        def local_f32():
+            return eng.upload(spec.c1[lo:hi]), (None if same else eng.upload(spec.c2[b2[g]:b2[g + 1]]))
+        x1, x2 = st.phase(local_f32)
         z1 = sharded_normalize_prepare(eng, comm, x1, b1[-1], "Log2.none", False, False, keep_counts=False)[3]
         if same:
             z2 = z1
         else:
-            x2 = eng.upload(spec.c2[b2[g]:b2[g + 1]])
             z2 = sharded_normalize_prepare(eng, comm, x2, n_out, "Log2.none", False, False, keep_counts=False)[3]
             z1, z2 = _match_pair(eng, x1, z1, x2, z2)
-        full = allgather_operand(eng, comm, z2, b2)
-    rows = hi - lo
-    height = stripe_height(rows, n_out, spec.out_dtype.itemsize, eng.free_bytes(), spec.stripe_rows)
-    bufs = [eng.block(height, n_out, spec.out_dtype) for _ in range(2 if rows > height else 1)] if rows else []
-    pending = None
-    for i, s0 in enumerate(range(0, rows, height)):
-        m, buf = min(height, rows - s0), bufs[i % 2]
-        g0 = lo + s0  # global index of the stripe's first row
-        if spec.f64:
-            a = eng.view_matrix(z1, s0, m)
-            if same:  # float64 products round once: any tiling gives the one-block call's bits
-                if g0:
-                    eng.gemm_f64(a, eng.view_matrix(full, 0, g0), buf, K)
-                eng.gemm_f64(a, a, buf, K, col0=g0, symmetric=True)
-                if g0 + m < n_out:
-                    eng.gemm_f64(a, eng.view_matrix(full, g0 + m, n_out - g0 - m), buf, K, col0=g0 + m)
-            else:
-                eng.gemm_f64(a, full, buf, K)
-        elif same:
-            eng.gemm_rows(eng.view(z1, s0, m), full, g0, buf)
-        else:
-            eng.gemm(eng.view(z1, s0, m), full, buf, 0)
-        mark = eng.mark()
-        if pending is not None:  # stripe s - 1 leaves while stripe s is contracted
-            spec.sink.put(*pending)
-        pending = (buf, m, g0, mark)
-    if pending is not None:
-        spec.sink.put(*pending)
+        room = st.phase(lambda: eng.empty_operand(n_out, eng.cols(z2)) if comm.size > 1 else None)
+        full = allgather_operand(eng, comm, z2, b2, room)
+
+    def stripe_buffers():
+        h = stripe_height(rows, n_out, spec.out_dtype.itemsize, eng.free_bytes(), spec.stripe_rows)
+        return h, ([eng.block(h, n_out, spec.out_dtype) for _ in range(2 if rows > h else 1)] if rows else [])
+    height, bufs = st.phase(stripe_buffers)
+    _stripe_loop(eng, spec, z1, full, bufs, rows, height, lo, n_out, K, same)
     st.comm.barrier()  # the operand shards stay alive until every GPU has pulled them (peer transport)
     return None
+
+
+def _stripe_loop(eng, spec, z1, full, bufs, rows, height, lo, n_out, K, same):
+    """Stripe s of this GPU's rows is contracted while stripe s - 1 leaves through the sink, behind its mark.  A mark whose
+    stripe never reaches the sink (an exception on the way) is handed back: marks are single-use slots of the ctx."""
+    pending = None
+    try:
+        for i, s0 in enumerate(range(0, rows, height)):
+            m, buf = min(height, rows - s0), bufs[i % 2]
+            g0 = lo + s0  # global index of the stripe's first row
+            if spec.f64:
+                a = eng.view_matrix(z1, s0, m)
+                if same:  # float64 products round once: any tiling gives the one-block call's bits
+                    if g0:
+                        eng.gemm_f64(a, eng.view_matrix(full, 0, g0), buf, K)
+                    eng.gemm_f64(a, a, buf, K, col0=g0, symmetric=True)
+                    if g0 + m < n_out:
+                        eng.gemm_f64(a, eng.view_matrix(full, g0 + m, n_out - g0 - m), buf, K, col0=g0 + m)
+                else:
+                    eng.gemm_f64(a, full, buf, K)
+            elif same:
+                eng.gemm_rows(eng.view(z1, s0, m), full, g0, buf)
+            else:
+                eng.gemm(eng.view(z1, s0, m), full, buf, 0)
+            mark = eng.mark()
+            if pending is not None:  # stripe s - 1 leaves while stripe s is contracted
+                leaving, pending = pending, (buf, m, g0, mark)
+                spec.sink.put(*leaving)
+            else:
+                pending = (buf, m, g0, mark)
+        if pending is not None:
+            leaving, pending = pending, None
+            spec.sink.put(*leaving)
+    except BaseException:
+        if pending is not None:
+            eng.release_mark(pending[3])
+        raise
 
 
 class _Solo:
@@ -693,6 +740,9 @@ class _Solo:
 
     def engine(self, precision=_lib.PREC_F16X3, row_standardize=True):
         return ApiHipEngine(self.ctx, precision, row_standardize=row_standardize)
+
+    def phase(self, fn):
+        return fn()  # nobody to agree with
 
 
 def forced_stripe_rows():
@@ -720,9 +770,16 @@ def run_pearson(c1, c2, w1, w2, row_standardize, precision, devices, out=None, o
         sink = HostSink(out)
     spec = PearsonSpec(c1, c2, shard_bounds(m_rows, size), shard_bounds(n_rows, size), f64, pad, precision, row_standardize,
                        sink, forced_stripe_rows(), out_dtype)
-    if m_rows and n_rows:
-        if devices:
-            group_for(devices).run(pearson_job, spec)
-        else:
-            pearson_job(_Solo(_lib.default_context()), spec)
+    try:
+        if m_rows and n_rows:
+            if devices:
+                group_for(devices).run(pearson_job, spec)
+            else:
+                pearson_job(_Solo(_lib.default_context()), spec)
+    except BaseException:
+        if isinstance(sink, NpySink):
+            sink.discard()
+        raise
+    if isinstance(sink, NpySink):
+        sink.commit()
     return out

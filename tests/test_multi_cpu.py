@@ -5,6 +5,7 @@ engine and RCCL (tests/test_gpu_multi_devices.py); what is checked HERE is that 
 reorders a row, that statistics chained across the ranges are bit-identical to the oracle's single pass, and that an
 exception raised for one range reaches the caller once, as itself, with every thread back in its loop
 (reference: kmer_counts.py:194-209, pearson.py:32-44)."""
+import os
 import queue
 import threading
 
@@ -80,10 +81,13 @@ class ApiNumpyEngine(NumpyEngine):
             z = self.row_standardize(rows) if row_standardize and len(rows) else rows
         return np.asarray(z, dtype=np.float64)
 
-    def allgather_matrix(self, comm, z, bounds):
+    def gather_room(self, z, rows):
+        return np.zeros((rows, z.shape[1]), z.dtype)
+
+    def allgather_matrix(self, comm, z, bounds, full=None):
         if comm.size == 1:
             return z
-        full = np.zeros((bounds[-1], z.shape[1]), z.dtype)
+        full = np.zeros((bounds[-1], z.shape[1]), z.dtype) if full is None else full
         comm.wait(comm.allgather_rows(z, full, bounds))
         return full
 
@@ -106,6 +110,9 @@ class ApiNumpyEngine(NumpyEngine):
 
     def mark(self):
         return -1
+
+    def release_mark(self, mark):
+        pass
 
 
 class ArraySink:
@@ -280,6 +287,51 @@ def test_pearson_job_places_every_stripe(size, m, n, stripe, f64):
         assert max(k for _, k in rows) <= stripe
 
 
+@pytest.mark.parametrize("where", ["upload", "gather_room", "block"])
+@pytest.mark.parametrize("f64", [False, True])
+def test_pearson_job_one_gpu_out_of_memory_is_agreed_on_before_any_collective(where, f64):
+    """a failure of ONE GPU's local work in pearson_job — its upload, the room for the gathered rows, its stripe
+    buffers — must reach the caller as itself, once, with every thread back in its loop; outside a phase the other threads
+    would be left inside a device collective that has no timeout (over RCCL: a hang with the API lock held)."""
+    if where == "upload" and f64:
+        where = "rows_f64"
+    if where == "gather_room" and not f64:
+        where = "empty_operand"
+    rng = np.random.default_rng(3)
+    c1 = rng.standard_normal((29, 32)).astype(np.float64 if f64 else np.float32)
+    failing = {"on": True}
+
+    class Flaky(ApiNumpyEngine):
+        rank = None
+
+        def __getattribute__(self, name):
+            fn = object.__getattribute__(self, name)
+            if name == where and object.__getattribute__(self, "rank") == 2 and failing["on"]:
+                def boom(*a, **kw):
+                    raise MemoryError("GPU 2 is out of memory in %s" % name)
+                return boom
+            return fn
+
+    class FlakyRank(multi.Rank):
+        def engine(self, precision=0, row_standardize=True):
+            e = Flaky(row_standardize)
+            e.rank = self.rank
+            return e
+
+    pipes = {(a, b): queue.Queue() for a in range(4) for b in range(4) if a != b}
+    group = multi.DeviceGroup(list(range(4)), backend=lambda grp, rank: FlakyRank(grp, rank, None, QueueComm(grp, rank, pipes)))
+    out = np.full((29, 29), np.nan, c1.dtype)
+    spec = multi.PearsonSpec(c1, None, shard_bounds(29, 4), shard_bounds(29, 4), f64, False, 0, True, ArraySink(out), 4, out.dtype)
+    with pytest.raises(MemoryError, match="GPU 2 is out of memory"):
+        group.run(multi.pearson_job, spec)
+    assert not group.broken
+    failing["on"] = False
+    group.run(multi.pearson_job, spec)  # the same group, the same job: every thread was back in its loop
+    group.close()
+    with np.errstate(all="ignore"):
+        assert np.allclose(out, orc.pearson(c1, c1), rtol=1e-5, atol=1e-6)
+
+
 def test_stripe_height():
     assert multi.stripe_height(1000, 1000, 4, 1 << 40) == 1000                  # fits: one stripe
     h = multi.stripe_height(200_000, 200_000, 4, 250 << 30)
@@ -351,3 +403,25 @@ def test_seekr_devices_set_after_the_first_use_is_named_as_the_cause():
     got = _ipc_child("late")
     assert got["at_cdll"] is None and got["at_load_recorded"] is None and got["names_several"] is True
     assert "SEEKR_DEVICES was first seen after" in got["late_note"] and "HSA_ENABLE_IPC_MODE_LEGACY" in got["late_note"]
+
+
+def test_a_failed_pearson_to_file_leaves_no_file_of_zeros_and_keeps_the_old_one(tmp_path, monkeypatch):
+    """np.save(outfile, dist) only touches the file once dist exists (pearson.py:41-43).  The stripe writer lays the file
+    out first — under a temporary name: a job that fails leaves the previous file as it was and nothing else behind; a job
+    that succeeds renames."""
+    out = str(tmp_path / "r.npy")
+    np.save(out, np.arange(6.0))
+    c1 = np.ones((5, 8), np.float32)
+    monkeypatch.setattr(multi._lib, "default_context", lambda: None)
+
+    def boom(st, spec):
+        assert os.path.exists(spec.sink.path) and spec.sink.path != out  # the stripes' file exists, under another name
+        raise MemoryError("out of device memory")
+    monkeypatch.setattr(multi, "pearson_job", boom)
+    with pytest.raises(MemoryError):
+        multi.run_pearson(c1, None, np.float32, np.float32, True, 4, None, outfile=out)
+    assert sorted(os.listdir(str(tmp_path))) == ["r.npy"] and np.array_equal(np.load(out), np.arange(6.0))
+    monkeypatch.setattr(multi, "pearson_job", lambda st, spec: None)  # "succeeds" (writes no stripe: the laid-out zeros stay)
+    multi.run_pearson(c1, None, np.float32, np.float32, True, 4, None, outfile=str(tmp_path / "r"))  # np.save appends .npy
+    got = np.load(out)
+    assert sorted(os.listdir(str(tmp_path))) == ["r.npy"] and got.shape == (5, 5) and got.dtype == np.float32
