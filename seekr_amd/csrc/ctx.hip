@@ -30,6 +30,28 @@ extern "C" int skr_device_count(int* count) {
     return SKR_OK;
 }
 
+// "0000:c1:00.0": where the device sits on the PCIe tree — /sys/bus/pci/devices/<id>/local_cpulist names the cores of its
+// NUMA node (the host code keeps the threads that feed a GPU on them: a copy across the socket link runs at half speed)
+extern "C" int skr_device_pci_bus_id(int device, char* buf, int cap) {
+    SKR_REQUIRE(buf && cap >= 16, "buffer of at least 16 bytes");
+    SKR_HIP(hipDeviceGetPCIBusId(buf, cap, device));
+    return SKR_OK;
+}
+
+// Page-lock a host range the caller owns (hipHostRegister) so that copies to / from it are plain DMA at the link's rate,
+// whatever state the runtime's own pinning cache is in; undone with skr_host_unregister before the memory is freed.
+extern "C" int skr_host_register(void* ptr, size_t bytes) {
+    SKR_REQUIRE(ptr && bytes, "empty range");
+    SKR_HIP(hipHostRegister(ptr, bytes, hipHostRegisterPortable));  // every GPU of the node copies at the pinned rate
+    return SKR_OK;
+}
+
+extern "C" int skr_host_unregister(void* ptr) {
+    SKR_REQUIRE(ptr, "NULL pointer");
+    SKR_HIP(hipHostUnregister(ptr));
+    return SKR_OK;
+}
+
 int skr_activate(const skr_ctx* ctx) {
     SKR_REQUIRE(ctx, "ctx is NULL");
     SKR_HIP(hipSetDevice(ctx->device));
@@ -87,6 +109,12 @@ extern "C" int skr_ctx_create(int device, skr_ctx** out) {
     SKR_HIP(hipMalloc((void**)&c->d_flags, 64 * sizeof(uint32_t)));
     SKR_HIP(hipHostMalloc((void**)&c->h_flags, 64 * sizeof(uint32_t), hipHostMallocDefault));
     SKR_HIP(hipMemsetAsync(c->d_flags, 0, 64 * sizeof(uint32_t), c->stream));
+    // The first host <-> device copies of the ctx happen HERE, on its own stream (a flag word up and down): the runtime
+    // hands out its copy engines at first use, and a process whose first copy went through the NULL stream copied at half
+    // rate on this stream ever after (pack.hip, upload_seqs: measured).
+    SKR_HIP(hipMemcpyAsync(c->d_flags + 32, c->h_flags, 4 * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    SKR_HIP(hipMemcpyAsync(c->h_flags + 32, c->d_flags + 32, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    SKR_HIP(hipStreamSynchronize(c->stream));
     *out = c;
     return SKR_OK;
 }

@@ -815,9 +815,12 @@ extern "C" int skr_chain_check(skr_chain* c, int* timed_out) {
     SKR_REQUIRE(c && timed_out, "NULL argument");
     SKR_TRY(skr_activate(c->ctx));
     uint32_t v = 0;
+    SKR_HIP(hipMemcpyAsync(&v, c->d_err, 4, hipMemcpyDeviceToHost, c->ctx->stream));  // (never the NULL stream: pack.hip, upload_seqs)
     SKR_HIP(hipStreamSynchronize(c->ctx->stream));
-    SKR_HIP(hipMemcpy(&v, c->d_err, 4, hipMemcpyDeviceToHost));
-    if (v) SKR_HIP(hipMemset(c->d_err, 0, 4));
+    if (v) {
+        SKR_HIP(hipMemsetAsync(c->d_err, 0, 4, c->ctx->stream));
+        SKR_HIP(hipStreamSynchronize(c->ctx->stream));
+    }
     *timed_out = v != 0;
     return SKR_OK;
 }

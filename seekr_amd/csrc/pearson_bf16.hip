@@ -1035,10 +1035,14 @@ extern "C" int skr_gemm_diag_read(skr_ctx* ctx, unsigned long long* out, int64_t
     SKR_REQUIRE(ctx->ws && ctx->ws_bytes >= (size_t)(8 + 8 * 65536) * 8, "no diagnostic launch has run");
     SKR_HIP(hipStreamSynchronize(ctx->stream));
     unsigned long long n = 0;
-    SKR_HIP(hipMemcpy(&n, ctx->ws, 8, hipMemcpyDeviceToHost));
+    SKR_HIP(hipMemcpyAsync(&n, ctx->ws, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SKR_HIP(hipStreamSynchronize(ctx->stream));
     *n_records = (int64_t)n;
     const int64_t take = std::min<int64_t>(std::min<int64_t>((int64_t)n, 65536), max_records);
-    if (take > 0) SKR_HIP(hipMemcpy(out, (char*)ctx->ws + 64, (size_t)take * 64, hipMemcpyDeviceToHost));
+    if (take > 0) {
+        SKR_HIP(hipMemcpyAsync(out, (char*)ctx->ws + 64, (size_t)take * 64, hipMemcpyDeviceToHost, ctx->stream));
+        SKR_HIP(hipStreamSynchronize(ctx->stream));
+    }
     return SKR_OK;
 }
 

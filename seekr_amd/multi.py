@@ -241,6 +241,14 @@ class Rank:
 
 
 def _hip_backend(group, rank):
+    # this thread feeds one GPU for the life of the process: it stays on the cores of that GPU's NUMA node (its uploads,
+    # downloads and the pages it touches first do not cross the socket link: _lib.cpus_near)
+    try:
+        near = _lib.cpus_near(group.devices[rank]) & os.sched_getaffinity(0)
+        if near:
+            os.sched_setaffinity(0, near)
+    except Exception:  # noqa: BLE001 - placement only
+        pass
     ctx = _lib.Context(group.devices[rank])
     size = group.size
     if group.transport == "rccl":
@@ -585,7 +593,7 @@ def run_counts(run, size, source, lengths, k, log2, mean, std, alphabet, two_bit
     """Cut the sequences into `size` ranges, run counts_job on every GPU thread (`run` = DeviceGroup.run), return
     (counts, mean, std, has_nan) — mean / std None where they were not computed."""
     bounds = bounds_by_bases(lengths, size)
-    out = np.empty((len(lengths), n_cols), dtype=np.float32)
+    out = _lib.host_pool.empty((len(lengths), n_cols), np.float32)
     parts = run(counts_job, CountSpec(source, bounds, k, log2, mean, std, alphabet, two_bit, out))
     return out, parts[0][0], parts[0][1], any(p[2] for p in parts)
 
@@ -766,7 +774,7 @@ def run_pearson(c1, c2, w1, w2, row_standardize, precision, devices, out=None, o
     if outfile is not None and out is None:
         sink = NpySink(outfile, out_dtype, m_rows, n_rows)
     else:
-        out = np.empty((m_rows, n_rows), dtype=out_dtype) if out is None else out
+        out = _lib.host_pool.empty((m_rows, n_rows), out_dtype) if out is None else out
         sink = HostSink(out)
     spec = PearsonSpec(c1, c2, shard_bounds(m_rows, size), shard_bounds(n_rows, size), f64, pad, precision, row_standardize,
                        sink, forced_stripe_rows(), out_dtype)
