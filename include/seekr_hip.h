@@ -75,9 +75,6 @@ typedef struct skr_mat skr_mat;   /* a row-major device matrix                  
 const char* skr_last_error(void);
 int skr_abi_version(void);
 int skr_device_count(int* count);
-/* PCI address of a device ("0000:c1:00.0", NUL-terminated; cap >= 16): with it the host finds the device's NUMA node in
- * sysfs and keeps the threads that upload to / download from the device on that node's cores.                          */
-int skr_device_pci_bus_id(int device, char* buf, int cap);
 /* Page-lock / release a host range the caller owns (hipHostRegister / hipHostUnregister): copies to and from a registered
  * range are plain DMA at the link's rate.  The package registers the result arrays it keeps between calls.               */
 int skr_host_register(void* ptr, size_t bytes);

@@ -50,7 +50,6 @@ SIGNATURES = {
     "skr_mat_upload": (_int, [_p, _p, _i64, _i64]),
     "skr_mat_download": (_int, [_p, _p, _i64, _i64]),
     "skr_mat_fill_zero": (_int, [_p]),
-    "skr_device_pci_bus_id": (_int, [_int, C.c_char_p, _int]),
     "skr_host_register": (_int, [_p, C.c_size_t]),
     "skr_host_unregister": (_int, [_p]),
     "skr_ctx_mark": (_int, [_p, C.POINTER(_i64)]),
@@ -353,82 +352,13 @@ _default_ctx = {}
 API_LOCK = threading.RLock()
 
 
-# ---- NUMA: the calling thread next to its GPU for the length of a call
-_local_cpus = {}   # device -> frozenset of CPUs of the device's NUMA node (empty: unknown / one node / switched off)
-_near_depth = threading.local()
-
-
-def cpus_near(device):
-    """The CPUs of the NUMA node GPU `device` hangs on (sysfs, via its PCI address), or an empty set: one node, no sysfs,
-    SEEKR_NUMA_BIND=0.  On the two-socket MI355X boxes a host <-> device copy whose host side lives on the other socket
-    runs at half the rate (upload 6.6 instead of 3.5 ms for 190 MB, download 19 instead of 10 ms for 550 MB, measured)."""
-    got = _local_cpus.get(device)
-    if got is not None:
-        return got
-    cpus = frozenset()
-    try:
-        if os.environ.get("SEEKR_NUMA_BIND", "1") != "0" and hasattr(os, "sched_setaffinity"):
-            buf = C.create_string_buffer(64)
-            if lib().skr_device_pci_bus_id(int(device), buf, 64) == SKR_OK:
-                with open("/sys/bus/pci/devices/{}/local_cpulist".format(buf.value.decode().lower())) as fh:
-                    text = fh.read().strip()
-                found = set()
-                for part in text.split(","):
-                    if part:
-                        lo, _, hi = part.partition("-")
-                        found.update(range(int(lo), int(hi or lo) + 1))
-                if 0 < len(found) < (os.cpu_count() or 0):  # a proper subset: there IS another node
-                    cpus = frozenset(found)
-    except Exception:  # noqa: BLE001 - placement is an optimisation, never an error
-        cpus = frozenset()
-    _local_cpus[device] = cpus
-    return cpus
-
-
-class near_gpu:
-    """`with near_gpu(device):` — the calling thread runs on the cores next to the GPU for the length of the block (pages it
-    touches first land on that node, copies do not cross the socket link) and gets its own affinity back afterwards: the
-    caller's placement is never changed for good.  Re-entrant per thread (only the outermost block acts); a no-op where the
-    node is unknown, the thread's affinity excludes it, or SEEKR_NUMA_BIND=0."""
-
-    def __init__(self, device=None):
-        self.device, self.saved = device, None
-
-    def __enter__(self):
-        depth = getattr(_near_depth, "n", 0)
-        _near_depth.n = depth + 1
-        if depth:
-            return self
-        try:
-            cpus = cpus_near(default_device() if self.device is None else self.device)
-            if cpus:
-                now = os.sched_getaffinity(0)
-                want = now & cpus
-                if want and want != now:
-                    os.sched_setaffinity(0, want)
-                    self.saved = now
-        except Exception:  # noqa: BLE001
-            self.saved = None
-        return self
-
-    def __exit__(self, *exc):
-        _near_depth.n -= 1
-        if self.saved is not None:
-            try:
-                os.sched_setaffinity(0, self.saved)
-            except Exception:  # noqa: BLE001
-                pass
-            self.saved = None
-        return False
-
-
 def api_call(fn):
-    """Decorator: run the function under API_LOCK (see above), the calling thread next to the default GPU (near_gpu)."""
+    """Decorator: run the function under API_LOCK (see above)."""
     import functools
 
     @functools.wraps(fn)
     def locked(*args, **kwargs):
-        with API_LOCK, near_gpu():
+        with API_LOCK:
             return fn(*args, **kwargs)
     return locked
 

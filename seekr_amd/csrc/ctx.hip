@@ -30,14 +30,6 @@ extern "C" int skr_device_count(int* count) {
     return SKR_OK;
 }
 
-// "0000:c1:00.0": where the device sits on the PCIe tree — /sys/bus/pci/devices/<id>/local_cpulist names the cores of its
-// NUMA node (the host code keeps the threads that feed a GPU on them: a copy across the socket link runs at half speed)
-extern "C" int skr_device_pci_bus_id(int device, char* buf, int cap) {
-    SKR_REQUIRE(buf && cap >= 16, "buffer of at least 16 bytes");
-    SKR_HIP(hipDeviceGetPCIBusId(buf, cap, device));
-    return SKR_OK;
-}
-
 // Page-lock a host range the caller owns (hipHostRegister) so that copies to / from it are plain DMA at the link's rate,
 // whatever state the runtime's own pinning cache is in; undone with skr_host_unregister before the memory is freed.
 extern "C" int skr_host_register(void* ptr, size_t bytes) {

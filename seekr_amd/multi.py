@@ -241,14 +241,6 @@ class Rank:
 
 
 def _hip_backend(group, rank):
-    # this thread feeds one GPU for the life of the process: it stays on the cores of that GPU's NUMA node (its uploads,
-    # downloads and the pages it touches first do not cross the socket link: _lib.cpus_near)
-    try:
-        near = _lib.cpus_near(group.devices[rank]) & os.sched_getaffinity(0)
-        if near:
-            os.sched_setaffinity(0, near)
-    except Exception:  # noqa: BLE001 - placement only
-        pass
     ctx = _lib.Context(group.devices[rank])
     size = group.size
     if group.transport == "rccl":
