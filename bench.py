@@ -812,7 +812,9 @@ def run_rank(args):
         "unit": "M seq-pairs/s (whole step: count + normalise + Pearson)",
         "n_gpus": size, "steps": steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        # --rows given: the transcript set is fixed whatever N (strong scaling: config 4 is `--gpus 8 --rows 200000`);
+        # default: 50 000 x sqrt(N) rows, i.e. a fixed number of ordered pairs per GPU (weak)
+        "higher_is_better": True, "scaling": "strong" if args.rows else "weak", "vs_baseline": None,
         "dtype": ("f32" if args.precision == "fp32" else
                   "f32 as 1 fp16 (hi x hi) + 1 block-scaled fp8 (both cross terms) MFMA product, f32 accumulate" if args.precision == "f16f8"
                   else "f32 as {} split-{} MFMA products, f32 accumulate".format(nprod, "fp16" if args.precision == "f16x3" else "bf16")),

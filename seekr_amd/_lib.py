@@ -486,6 +486,7 @@ class HostPool:
                 slab = self._free.pop(best)
                 self._kept -= slab.nbytes
                 self.stats["reused"] += 1
+                self.stats["kept_bytes"] = self._kept
         if slab is None:
             slab = _Slab(n)
             self.stats["fresh"] += 1

@@ -247,6 +247,44 @@ def test_eight_ranks_at_the_drivers_weak_scaling_size(layout, mock_lib):
     assert ab["bit_identical"] is True and "peer mailboxes" in ab["mailbox"]["transport"], ab
     assert not ab["mailbox"]["a_link_gave_up_waiting"] and ab["rccl"]["transport"] in ("not requested", "send/recv")
     assert len(out["per_rank"]["gemm_ms"]) == 8 and min(out["per_rank"]["gemm_ms"]) > 0
+    check_scale_line(out, 8, "weak")
+
+
+SCALE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "roofline_count", "n_ranks_seen", "per_rank", "verified", "verified_detail")
+
+
+def check_scale_line(out, n, scaling):
+    """What the driver's SCALE run (bench.py --gpus N for N in 1, 2, 4, 8) must find in the line the first time it is ever
+    run on a real node: the contract's keys, the sharding and scaling named, every rank seen by an RCCL
+    all-reduce, a verification all-reduced over the ranks, per-rank times, and the roofline object of the dominant kernel."""
+    for key in SCALE_KEYS:
+        assert key in out, key
+    assert out["n_gpus"] == n and out["n_ranks_seen"] == n and out["scaling"] == scaling and out["vs_baseline"] is None
+    assert out["higher_is_better"] is True and out["data"] == "synthetic" and out["value"] > 0 and out["ms_per_step"] > 0
+    cfg = out["config"]
+    assert cfg["sharding"] == "rows x%d" % n and "workload" in cfg and cfg["k"] == 6 and cfg["rows_total"] >= n * cfg["rows_per_gpu"] - n
+    assert out["verified"] is True and "all-reduced" in out["verified_detail"]["bar"] and out["verified_detail"]["worst_error_over_bar"] <= 1.0
+    rf = out["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert out["roofline_count"]["bound"] == "hbm" and out["roofline_count"]["unit"] == "GB/s"
+    for name in ("gemm_ms", "comm_ms"):
+        assert len(out["per_rank"][name]) == n
+    assert "cpu_baseline" not in out and "e2e" not in out  # rank 0 at N = 1 only (the contract), never at N > 1
+
+
+def test_the_strong_scaling_spelling_of_the_scale_command(mock_lib):
+    """`bench.py --gpus 8 --rows R`: a fixed transcript set cut over the ranks (config 4 is R = 200 000: README) — the line
+    says "strong" and carries the same contract.  R = 60 000 here (eight rank processes share this one GPU)."""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--rows", "60000", "--steps", "2", "--warmup", "1",
+           "--launch-timeout", "600"]
+    res = subprocess.run(cmd, env=_launcher_env(mock_lib), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-6000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert "layout_fallback" not in out, out.get("layout_fallback")
+    check_scale_line(out, 8, "strong")
+    assert out["config"]["rows_total"] == 60000 and out["config"]["rows_per_gpu"] == 7500 and out["steps"] == 2
 
 
 def test_bench_rank_gives_up_when_a_peer_never_arrives(mock_lib):
