@@ -620,7 +620,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
     // addresses are a scalar base per (mt | nt) + one per-lane 32-bit offset + an immediate.  Same values, same cells,
     // same cells: r is the same bits.  flags bits 2-3 (SEEKR_GEMM_EPILOGUE: 0 = off, 1 / 2 / 3 = the run length
     // below) select it; every other tile takes the general loop.
-    const bool lean = (flags & 12) && !accumulate && rk != 0.f && row_base + TM <= M && col_base + TN <= N && !(SYM && tm == tn) &&
+    const bool lean = (flags & 12) && (!accumulate || ((flags >> 2) & 3) == 3) && rk != 0.f && row_base + TM <= M && col_base + TN <= N && !(SYM && tm == tn) &&
                       ldc < (int64_t(1) << 26) && ((reinterpret_cast<uintptr_t>(C) | (uintptr_t)(ldc * 4)) & 15) == 0 &&
                       (!mirror || (ldct < (int64_t(1) << 26) && ((reinterpret_cast<uintptr_t>(Ct) | (uintptr_t)(ldct * 4)) & 15) == 0));
     if (DIAG && (diag[1] & 32)) {
@@ -677,15 +677,55 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
         // pass to the second (256 VGPRs + scratch instead of 215)
         float rk_m = rk;
         asm volatile("" : "+v"(rk_m));
-        auto body = [&](auto with_mirror, auto run_c) {
+        auto body = [&](auto with_mirror, auto run_c, auto acc_c) {
             constexpr int G = decltype(run_c)::value / 64;  // accumulator tiles per row run
+            // ACC: a later k chunk of a row wider than one accumulator run (k >= 7: 16 384 columns = four chunks): what the
+            // earlier chunks left in C is added before the store (256-byte runs only).  The old cells of a group are
+            // requested PF groups ahead — a wave has 12 loads of 1 KiB in flight — and, when this is the last chunk of a
+            // tile with a mirror, the finished values are brought back into the accumulator's layout (the exchanges below
+            // are their own inverses) and stored to the mirror from there.
+            constexpr bool ACC = decltype(acc_c)::value;
+            static_assert(!ACC || G == 4, "the accumulating lean epilogue exists for 256-byte runs");
+            constexpr int PF = 3;
+            auto quad_transpose4 = [&](float (&v)[4]) {  // 4 x 4 inside each quad of lanes (DPP); its own inverse
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    const float t0 = quad_perm<0xB1>(v[e]), t1 = quad_perm<0xB1>(v[e + 1]);
+                    v[e + 1] = odd ? v[e + 1] : t0;
+                    v[e] = odd ? t1 : v[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const float t0 = quad_perm<0x4E>(v[e]), t1 = quad_perm<0x4E>(v[e + 2]);
+                    v[e + 2] = upper ? v[e + 2] : t0;
+                    v[e] = upper ? t1 : v[e];
+                }
+            };
             // ---- the direct tile
             const int tile_d = G == 1 ? 0 : (G == 2 ? (rho >> 1) : (((rho & 1) << 1) | (rho >> 1)));  // which tile of its group a lane stores
             const int row_d = G == 1 ? 4 * rho + j : (G == 2 ? 4 * (rho & 1) + j : j);                 // ... and which of the first rows
             const uint32_t d_off = (uint32_t)((row_d * ldc + 16 * tile_d + 4 * g) * 4);
             const size_t d_rows = (size_t)ldc * (16 / G) * 4;  // from one store of a group to the next: 16 / G rows down
+            const uint32_t m_off1 = (uint32_t)((c * ldct + 4 * rho) * 4);  // ACC + mirror: the lane's four rows in row c of the mirror tile
+            f32x4v old_c[ACC ? PF : 1][4];
+            auto request = [&](int mt) {  // the cells of C that group mt will be added to, in the order its four stores go out
+                if constexpr (ACC) {
+                    const char* base = cw + (size_t)mt * d_step;
+#pragma unroll
+                    for (int x = 0; x < 4; x++)
+                        old_c[mt % PF][x] = *reinterpret_cast<const f32x4v*>(base + x * d_rows + (size_t)d_off);
+                }
+            };
+            if constexpr (ACC) {
+#pragma unroll
+                for (int mt = 0; mt < PF - 1; mt++) request(mt);
+            }
+            char* cwm = cw;
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
+                if constexpr (ACC) {
+                    if (mt + PF - 1 < MT) request(mt + PF - 1);
+                }
 #pragma unroll
                 for (int nb = 0; nb < NT / G; nb++) {
                     float t[G][4];
@@ -693,20 +733,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
                     for (int i = 0; i < G; i++) {
 #pragma unroll
                         for (int e = 0; e < 4; e++) t[i][e] = acc[mt][nb * G + i][e] * rk;
-#pragma unroll
-                        for (int e = 0; e < 4; e += 2) {  // 4 x 4 transpose inside the quads: lane j ends up with row 4 rho + j, four columns
-                            const float t0 = quad_perm<0xB1>(t[i][e]), t1 = quad_perm<0xB1>(t[i][e + 1]);
-                            t[i][e + 1] = odd ? t[i][e + 1] : t0;
-                            t[i][e] = odd ? t1 : t[i][e];
-                        }
-#pragma unroll
-                        for (int e = 0; e < 2; e++) {
-                            const float t0 = quad_perm<0x4E>(t[i][e]), t1 = quad_perm<0x4E>(t[i][e + 2]);
-                            t[i][e + 2] = upper ? t[i][e + 2] : t0;
-                            t[i][e] = upper ? t1 : t[i][e];
-                        }
+                        quad_transpose4(t[i]);  // lane j of a quad ends up with row 4 rho + j, four columns
                     }
-                    char* base = cw + nb * (64 * G);
+                    char* base = cwm + nb * (64 * G);
                     if constexpr (G == 1) {
                         put(t[0], base, d_off);
                     } else if constexpr (G == 2) {
@@ -722,19 +751,42 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
                             swap16(t[0][e], t[2][e]);  // t[0]: rows 0-3 of the four tiles, t[2]: rows 4-7
                             swap16(t[1][e], t[3][e]);  // t[1]: rows 8-11, t[3]: rows 12-15
                         }
+                        if constexpr (ACC) {  // stores go out in the order t[0], t[2], t[1], t[3]: so were the loads
+                            constexpr int at[4] = {0, 2, 1, 3};
+#pragma unroll
+                            for (int x = 0; x < 4; x++)
+#pragma unroll
+                                for (int e = 0; e < 4; e++) t[at[x]][e] = old_c[mt % PF][x][e] + t[at[x]][e];
+                        }
                         put(t[0], base, d_off);
                         put(t[2], base + d_rows, d_off);
                         put(t[1], base + 2 * d_rows, d_off);
                         put(t[3], base + 3 * d_rows, d_off);
+                        if constexpr (ACC && decltype(with_mirror)::value) {  // the finished values, back where the MFMA left the partial ones
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                swap16(t[1][e], t[3][e]);
+                                swap16(t[0][e], t[2][e]);
+                                swap32(t[2][e], t[3][e]);
+                                swap32(t[0][e], t[1][e]);
+                            }
+                            // ... and straight out to the mirror, 16 rows x 64 bytes per instruction (writing them back into the
+                            // accumulator registers for a pass with 256-byte runs made the allocator spill 100 registers)
+#pragma unroll
+                            for (int i = 0; i < 4; i++) {
+                                quad_transpose4(t[i]);
+                                put(t[i], tw[i] + mt * 64, m_off1);
+                            }
+                        }
                     }
                     // one group at a time: left to itself the scheduler interleaves the 32 independent groups of this 3 000-
                     // instruction block until all 256 registers are in use, and the allocator then spills accumulators
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                cw += d_step;
+                cwm += d_step;
             }
             // ---- the mirror: a lane's four rows are four consecutive cells of row (column index) of Ct
-            if constexpr (decltype(with_mirror)::value) {
+            if constexpr (decltype(with_mirror)::value && !ACC) {
                 const int row_m = G == 1 ? c : (G == 2 ? (c & 7) : (c & 3));
                 const int tile_m = G == 1 ? 0 : (G == 2 ? (c >> 3) : ((((c >> 2) & 1) << 1) | (c >> 3)));
                 const uint32_t m_off = (uint32_t)((row_m * ldct + 16 * tile_m + 4 * rho) * 4);
@@ -789,21 +841,22 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
                 }
             }
         };
-#ifndef SEEKR_LEAN_RUN
         const int run = (flags >> 2) & 3;  // 1: 64-byte runs, 2: 128, 3: 256
-        if (mirror) {
-            if (run == 3) body(std::true_type{}, std::integral_constant<int, 256>{});
-            else if (run == 2) body(std::true_type{}, std::integral_constant<int, 128>{});
-            else body(std::true_type{}, std::integral_constant<int, 64>{});
+        using std::false_type;
+        using std::integral_constant;
+        using std::true_type;
+        if (accumulate) {  // (lean only with run == 3: the condition above)
+            if (mirror) body(true_type{}, integral_constant<int, 256>{}, true_type{});
+            else body(false_type{}, integral_constant<int, 256>{}, true_type{});
+        } else if (mirror) {
+            if (run == 3) body(true_type{}, integral_constant<int, 256>{}, false_type{});
+            else if (run == 2) body(true_type{}, integral_constant<int, 128>{}, false_type{});
+            else body(true_type{}, integral_constant<int, 64>{}, false_type{});
         } else {
-            if (run == 3) body(std::false_type{}, std::integral_constant<int, 256>{});
-            else if (run == 2) body(std::false_type{}, std::integral_constant<int, 128>{});
-            else body(std::false_type{}, std::integral_constant<int, 64>{});
+            if (run == 3) body(false_type{}, integral_constant<int, 256>{}, false_type{});
+            else if (run == 2) body(false_type{}, integral_constant<int, 128>{}, false_type{});
+            else body(false_type{}, integral_constant<int, 64>{}, false_type{});
         }
-#else
-        if (mirror) body(std::true_type{}, std::integral_constant<int, SEEKR_LEAN_RUN>{});
-        else body(std::false_type{}, std::integral_constant<int, SEEKR_LEAN_RUN>{});
-#endif
     } else
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)

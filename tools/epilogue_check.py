@@ -33,7 +33,7 @@ def both(fn):
 
 n_checked = 0
 for prec in (L.PREC_F16X3, L.PREC_BF16X3, L.PREC_F16F8):
-    for rows, rows_b, cols in ((1500, 1111, 4096), (1024, 768, 4096), (700, 513, 16384), (600, 300, 1024), (2051, 2051, 256)):
+    for rows, rows_b, cols in ((1500, 1111, 4096), (1024, 768, 4096), (700, 513, 16384), (1280, 1024, 8192), (600, 300, 1024), (2051, 2051, 256)):
         if prec == L.PREC_BF16X3 and cols < 1024:
             continue
         xa = (rng.binomial(40, 0.06, size=(rows, cols)) * np.float32(0.5)).astype(np.float32)
