@@ -1226,6 +1226,19 @@ def test_four_wave_geometry_gives_the_same_bits():
     assert out.returncode == 0 and "w4 check ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+def test_lean_epilogue_gives_the_general_loops_bits():
+    """Round 6: whole off-diagonal tiles of the split contraction leave through a branch-free epilogue whose store
+    instructions cover 4 rows x 256 bytes (v_permlane32_swap / v_permlane16_swap / DPP row moves gather four accumulator
+    tiles; later k chunks add the old cells first).  Against the general loop (SEEKR_GEMM_EPILOGUE=0) and for all three
+    run lengths: the same bits in SELF, PLAIN, CROSS, row-stripe and thresholding mode, three split precisions, ragged
+    edges, targets whose rows are not 16-byte aligned (must decline), 1 / 2 / 4 k chunks (tools/epilogue_check.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "epilogue_check.py")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "epilogue check ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 @pytest.mark.parametrize("cols,shards", [(4096, [700, 0, 513, 1200]), (16384, [300, 301]), (1000, [64, 1, 0, 0, 90, 7, 300, 5]), (48, [3, 9])])
 def test_peer_mailbox_chain_links_in_one_process(cols, shards, L, ctx):
     """skr_colsum_seq_chain (the column-sum chain across GPUs through peer mailboxes) with the ranks' mailboxes connected
