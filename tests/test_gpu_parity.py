@@ -1692,3 +1692,22 @@ def test_normalisation_on_other_dtypes_is_in_place_like_the_reference(dtype):
         assert c2.counts is not held and np.array_equal(held, before + 1)  # the `+= 1` landed in the caller's array
         with np.errstate(all="ignore"):
             assert np.allclose(c2.counts, np.log2(before + 1), rtol=2e-3 if dtype == "float16" else 1e-12, equal_nan=True)
+
+
+@pytest.mark.parametrize("total", [4096, 2 << 20])
+def test_any_alphabet_counter_with_trailing_empty_sequences_on_an_allocation_boundary(total, L, ctx):
+    """the any-alphabet counter's unconditional prefetch of the next sequence's first bytes read bases[total] —
+    one past the buffer — for trailing EMPTY sequences (off == total); with `total` a multiple of the allocation granule
+    that is a fault.  The address is clamped now (and the buffer has slack): counts of such a set, bit for bit, including
+    the reference's rows for the empty sequences (all zero: len < k - 1)."""
+    rng = np.random.default_rng(total)
+    lens = [total // 4, total // 4, total // 2 - 37, 37, 0, 0, 0]
+    assert sum(lens) == total
+    seqs = ["".join(rng.choice(list("ACGTN"), size=n, p=[.24, .24, .24, .24, .04])) for n in lens]
+    for dtype, want in ((np.uint32, orc.count_kmers_u32(seqs, 3, "ACGTN")), (np.float32, orc.raw_counts(seqs, 3, "ACGTN"))):
+        got = L.count_generic(ctx, seqs, "ACGTN", 3, dtype).to_numpy()
+        assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert not got[-3:].any()
+    resident = L.AsciiSeqs(ctx, "".join(seqs).encode(), np.cumsum([0] + lens))  # the resident form: exactly `total` bytes
+    got = L.count_generic_dev(ctx, resident, "ACGTN", 3, np.uint32).to_numpy()
+    assert np.array_equal(got, orc.count_kmers_u32(seqs, 3, "ACGTN"))
