@@ -240,8 +240,8 @@ def test_pmc_traffic_refuses_a_summary_of_other_kernels(tmp_path):
     assert (got is None) != (why is None)
 
 
-def test_committed_round5_summaries_belong_to_the_library_built_from_this_tree():
-    """The round-5 PMC summaries under profiles/ carry the kernel-symbol fingerprint of the library this tree builds, so
+def test_committed_round6_summaries_belong_to_the_library_built_from_this_tree():
+    """The round-6 PMC summaries under profiles/ carry the kernel-symbol fingerprint of the library this tree builds, so
     bench.py quotes roofline.traffic from them for the default, the 200 000-row, the k = 7 and the f16f8 workloads (a
     kernel added or removed without re-collecting them would silently turn `traffic` into null in the driver's line)."""
     bench = _bench()
@@ -249,6 +249,6 @@ def test_committed_round5_summaries_belong_to_the_library_built_from_this_tree()
     for rows, length, k, prec, key in ((50000, 2000, 6, "f16x3", "split16_kernelIDF16_Li3"), (200000, 2000, 6, "f16x3", "split16_kernelIDF16_Li3"),
                                        (50000, 5000, 7, "f16x3", "split16_kernelIDF16_Li3"), (50000, 2000, 6, "f16f8", "split16_kernelIDF16_Li2")):
         got, why = bench.pmc_traffic(key, bench.workload_key(rows, length, k, prec, 1), lib_path)
-        assert why is None and got["bytes"] > 0 and got["source"].startswith("profiles/r5_"), (rows, k, prec, why)
+        assert why is None and got["bytes"] > 0 and got["source"].startswith("profiles/r6_"), (rows, k, prec, why)
         count, why = bench.pmc_traffic("count_rows_kernel<0", bench.workload_key(rows, length, k, prec, 1), lib_path)
         assert why is None and count["write_bytes"] > 0, (rows, k, prec, why)
