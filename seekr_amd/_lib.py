@@ -385,10 +385,15 @@ def default_context():
 # ----------------------------------------------------------------------------- result memory --
 class _Slab:
     """One block of host memory the pool owns: a uint8 array and whether its pages are registered with the HIP runtime."""
-    __slots__ = ("arr", "registered")
+    __slots__ = ("arr", "registered", "_map")
 
     def __init__(self, nbytes):
-        self.arr = np.empty(nbytes, dtype=np.uint8)  # fresh pages: the first copy into them costs what it always did
+        # an anonymous mapping of its own — whole pages that belong to this slab alone (a malloc'ed block of a few MiB may
+        # sit on the heap and share its first and last page with other objects: not something to page-lock and unlock);
+        # fresh pages: the first copy into them costs what it always did
+        import mmap
+        self._map = mmap.mmap(-1, max(int(nbytes), 1))
+        self.arr = np.frombuffer(self._map, dtype=np.uint8, count=int(nbytes))
         self.registered = False
 
     @property

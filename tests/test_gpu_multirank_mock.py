@@ -143,7 +143,7 @@ def test_bench_under_torchrun_with_two_ranks(mock_lib):
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "strong" and out["value"] > 0  # --rows fixes the set: strong (the default sizing says weak)
     assert out["config"]["rows_total"] == 6000 and out["config"]["rows_per_gpu"] == 3000
     assert "symmetric" in out["config"]["layout"] and "cpu_baseline" not in out
     # half the ordered pairs are multiplied: own triangle + half of the one cross block

@@ -16,24 +16,26 @@ ctx = L.default_context()
 rng = np.random.default_rng(6)
 
 
-ARMS = ("0", "1", "2", "3")  # the general loop; lean with 64- / 128- / 256-byte row runs
+ARMS = ("0", "1", "2", "3", "3p", "1p")  # the general loop; lean with 64- / 128- / 256-byte row runs; the same with PRESTAGE
 
 
 def both(fn):
-    """[general, lean 64, lean 128, lean 256]; asserts nothing itself."""
+    """[general, lean 64, lean 128, lean 256, lean 256 + prestage, lean 64 + prestage]; asserts nothing itself."""
     out = []
     for val in ARMS:
-        os.environ["SEEKR_GEMM_EPILOGUE"] = val
+        os.environ["SEEKR_GEMM_EPILOGUE"] = val[0]
+        os.environ["SEEKR_GEMM_PRESTAGE"] = "1" if val.endswith("p") else "0"
         ctx.reload_knobs()
         out.append(fn())
     os.environ.pop("SEEKR_GEMM_EPILOGUE")
+    os.environ.pop("SEEKR_GEMM_PRESTAGE")
     ctx.reload_knobs()
     return out
 
 
 n_checked = 0
 for prec in (L.PREC_F16X3, L.PREC_BF16X3, L.PREC_F16F8):
-    for rows, rows_b, cols in ((1500, 1111, 4096), (1024, 768, 4096), (700, 513, 16384), (1280, 1024, 8192), (600, 300, 1024), (2051, 2051, 256)):
+    for rows, rows_b, cols in ((1500, 1111, 4096), (1024, 768, 4096), (700, 513, 16384), (1280, 1024, 8192), (600, 300, 1024), (2051, 2051, 256), (6200, 5000, 64), (9000, 4100, 96)):
         if prec == L.PREC_BF16X3 and cols < 1024:
             continue
         xa = (rng.binomial(40, 0.06, size=(rows, cols)) * np.float32(0.5)).astype(np.float32)
