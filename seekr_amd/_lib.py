@@ -404,7 +404,7 @@ class _Slab:
         """Page-lock the (by now touched) pages: 5-7 ms for 576 MB, once; every later copy into them is plain DMA at the link's
         rate — without it the rate depends on the state of the runtime's own pinning cache (10 or 19 ms for the same 549 MB
         download, measured in one process).  Quietly skipped where it cannot be done (no GPU, locked-memory limit)."""
-        if not self.registered and not _shutdown:
+        if not self.registered and not _shutdown and os.environ.get("SEEKR_RESULT_POOL_REGISTER", "1") != "0":
             try:
                 self.registered = lib().skr_host_register(self.arr.ctypes.data_as(_p), self.arr.nbytes) == SKR_OK
             except Exception:  # noqa: BLE001

@@ -66,7 +66,6 @@ extern "C" int skr_ctx_reload_knobs(skr_ctx* c) {
     kn.gemm_subtile = env_int("SEEKR_GEMM_SUBTILE", 4);
     kn.gemm_wave_tile = env_int("SEEKR_GEMM_WAVE_TILE", 0);
     kn.gemm_epilogue = std::max(0, std::min(3, env_int("SEEKR_GEMM_EPILOGUE", 3)));
-    kn.gemm_prestage = env_int("SEEKR_GEMM_PRESTAGE", 0);
     kn.count_percu = std::max(0, env_int("SEEKR_COUNT_PERCU", 0));
     kn.count_persist = env_int("SEEKR_COUNT_PERSIST", 0);
     kn.count_legacy = env_int("SEEKR_COUNT_LEGACY", 0) != 0;

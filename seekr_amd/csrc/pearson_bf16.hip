@@ -178,17 +178,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
 
     const int home = PERSIST ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7) : 0;  // HW_REG_XCC_ID[3:0]
     int helping = 0;  // queues tried so far: home, home+1, ...
-    // PRESTAGE (round 6, flags bit 4, persistent f16x3 / bf16x3 launches): a tile handed over by the previous tile's lean
-    // epilogue — already popped, its k tiles 0 and 1 already staged BEFORE that epilogue's stores and multiplied while they
-    // drained (see there).  carry_tm < 0: nothing carried, the slot is popped here as always.
-    int64_t carry_tm = -1, carry_tn = -1;
-    bool queues_empty = false;
-    f32x4v acc[MT][NT];
   for (;;) {
     int64_t bid = blockIdx.x;
-    const bool carried = carry_tm >= 0;
-    if (queues_empty) return;
-    if (PERSIST && !carried) {
+    if (PERSIST) {
         if (tid == 0) {
             int64_t got = -1;
             while (helping < 8) {
@@ -208,11 +200,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
         if (bid < 0) return;
     }
     int64_t tm, tn;
-    if (carried) {
-        tm = carry_tm;
-        tn = carry_tn;
-        carry_tm = -1;
-    } else if (!tile_of_block(bid, super_n, tiles_m, tiles_n, &tm, &tn, flags >> 8) || (SYM && tn < tm)) {  // outside, or the mirror writes it
+    if (!tile_of_block(bid, super_n, tiles_m, tiles_n, &tm, &tn, flags >> 8) || (SYM && tn < tm)) {  // outside, or the mirror writes it
         if (PERSIST) continue;
         return;
     }
@@ -241,19 +229,17 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
         a_voff[p] = (uint32_t)(ra * pitch * 2 + chunk * 16);
         b_voff[p] = (uint32_t)(rb * pitch * 2 + chunk * 16);
     }
-    auto stage_at = [&](int buf, int64_t tile, const char* at, const char* bt, const uint32_t (&av)[PP], const uint32_t (&bv)[PP],
-                        bool half = false) {  // half: diagnostic only (a timing experiment, below)
+    auto stage = [&](int buf, int64_t tile, bool half = false) {  // half: diagnostic only (a timing experiment, below)
         char* abase = smem + buf * kStageBytes;
         char* bbase = abase + TM * kRowBytes;
         const uint32_t toff = (uint32_t)tile * kRowBytes;  // folded into the 32-bit lane offset: saddr + voffset form
 #pragma unroll
         for (int p = 0; p < PP; p++) {
             if (DIAG && half && p >= PP / 2) break;
-            lds_dma16(at + (av[p] + toff), abase + (wave * PP + p) * 1024);
-            lds_dma16(bt + (bv[p] + toff), bbase + (wave * PP + p) * 1024);
+            lds_dma16(a_tile + (a_voff[p] + toff), abase + (wave * PP + p) * 1024);
+            lds_dma16(b_tile + (b_voff[p] + toff), bbase + (wave * PP + p) * 1024);
         }
     };
-    auto stage = [&](int buf, int64_t tile, bool half = false) { stage_at(buf, tile, a_tile, b_tile, a_voff, b_voff, half); };
 
     const int q = lane >> 4;  // k quarter: this lane's fragment is k = 8q .. 8q+7 of the 32-k tile
     int a_off[MT], a_swz[MT], b_off[NT], b_swz[NT];
@@ -270,15 +256,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
         b_swz[t] = (rb >> 1) & 7;
     }
 
-    // (declared outside the persistent loop's body in effect: a carried tile arrives with k tiles 0 and 1 in its accumulators)
-    if (!carried) {
+    f32x4v acc[MT][NT];
 #pragma unroll
-        for (int i = 0; i < MT; i++)
+    for (int i = 0; i < MT; i++)
 #pragma unroll
-            for (int j = 0; j < NT; j++)
+        for (int j = 0; j < NT; j++)
 #pragma unroll
-                for (int e = 0; e < 4; e++) acc[i][j][e] = 0.f;
-    }
+            for (int e = 0; e < 4; e++) acc[i][j][e] = 0.f;
 
     // Two LDS stages: tile t+1 streams in by LDS-DMA while tile t is consumed; one barrier per k
     // tile.  The loop runs at the clock the chip grants an MFMA-dense body (1.9-1.95 GHz effective,
@@ -287,65 +271,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
     // phase (no MFMA ever waits on a fresh LDS read) ran in the same 25.1 vs 25.2 ms, so the
     // simple form stays.
     int cur = 0;
-    const int64_t t_begin = carried ? 2 : 0;  // a carried tile: both stages were consumed under the previous epilogue's drain, k tile 2 is on its way into stage 0
-    if (!carried) {
-        stage(0, 0);
-        if (WAVES == 4 && kt > 1) stage(1, 1);  // the 4-wave loop keeps two stages in flight (below)
-        __syncthreads();
-    }
+    stage(0, 0);
+    if (WAVES == 4 && kt > 1) stage(1, 1);  // the 4-wave loop keeps two stages in flight (below)
+    __syncthreads();
     if (DIAG) st[2] = __builtin_amdgcn_s_memtime();
     const bool no_dma = DIAG && (diag[1] & 1);  // diagnostic only: k loop without its staging traffic (results meaningless)
     const bool same_tile = DIAG && (diag[1] & 2);  // diagnostic only: every stage re-loads k tile 0 (served by the nearest cache)
     const bool two_units = DIAG && (diag[1] & 8);  // diagnostic only: TIMING CEILING of a two-product-unit split (results meaningless)
-    // one k tile out of LDS stage `buf` into the accumulators: the body of the 8-wave loop below, for the two k tiles the lean
-    // epilogue multiplies for the NEXT tile while its own stores drain (PRESTAGE)
-    auto consume_stage = [&](int buf) {
-        if constexpr (WAVES == 8 && NPROD == 3) {
-            // (the fragment addresses are derived again, from a lane id the compiler cannot tie to the loop's: shared with the k
-            // loop they would be 24 registers alive THROUGH the epilogue, which has none to spare — 600 bytes of scratch)
-            int lane_c = lane;
-            asm volatile("" : "+v"(lane_c));
-            const int q = lane_c >> 4;
-            int a_off[MT], a_swz[MT], b_off[NT], b_swz[NT];
-#pragma unroll
-            for (int t = 0; t < MT; t++) {
-                const int ra = wm * 128 + t * 16 + (lane_c & 15);
-                a_off[t] = ra * kRowBytes;
-                a_swz[t] = (ra >> 1) & 7;
-            }
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                const int rb = wn * WTN + t * 16 + (lane_c & 15);
-                b_off[t] = TM * kRowBytes + rb * kRowBytes;
-                b_swz[t] = (rb >> 1) & 7;
-            }
-            const char* base = smem + buf * kStageBytes;
-            vec8<T> ahi[MT], alo[MT], bhi[NT], blo[NT];
-#pragma unroll
-            for (int i = 0; i < NT; i++) {
-                bhi[i] = *reinterpret_cast<const vec8<T>*>(base + b_off[i] + ((q ^ b_swz[i]) << 4));
-                blo[i] = *reinterpret_cast<const vec8<T>*>(base + b_off[i] + (((4 + q) ^ b_swz[i]) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < MT; i++) {
-                ahi[i] = *reinterpret_cast<const vec8<T>*>(base + a_off[i] + ((q ^ a_swz[i]) << 4));
-                alo[i] = *reinterpret_cast<const vec8<T>*>(base + a_off[i] + (((4 + q) ^ a_swz[i]) << 4));
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                for (int nt = 0; nt < NT; nt++) {
-                    if (SWAPPED) {
-                        acc[mt][nt] = mfma16x16(ahi[mt], blo[nt], acc[mt][nt]);
-                        acc[mt][nt] = mfma16x16(alo[mt], bhi[nt], acc[mt][nt]);
-                    } else {
-                        acc[mt][nt] = mfma16x16(alo[mt], bhi[nt], acc[mt][nt]);
-                        acc[mt][nt] = mfma16x16(ahi[mt], blo[nt], acc[mt][nt]);
-                    }
-                    acc[mt][nt] = mfma16x16(ahi[mt], bhi[nt], acc[mt][nt]);
-                }
-        }
-    };
     if (DIAG && WAVES == 8 && two_units) {
         // VERDICT r3 #5, measured before anything is built around it: the two cross products (lo x hi, hi x lo: two
         // 16-bit MFMAs per k tile and accumulator tile) replaced by ONE v_mfma_i32_16x16x64_i8 — the cycles of one 16-bit
@@ -445,7 +377,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
             }
         }
     } else if constexpr (WAVES == 8) {
-        for (int64_t t = t_begin; t < kt; t++) {
+        for (int64_t t = 0; t < kt; t++) {
             if (t + 1 < kt && !no_dma) stage(cur ^ 1, same_tile ? 0 : t + 1);
             const char* base = smem + cur * kStageBytes;
             vec8<T> ahi[MT], alo[MT], bhi[NT], blo[NT];
@@ -909,64 +841,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
                 }
             }
         };
-        // ---- PRESTAGE: the next tile's first two k tiles go into the (now idle) LDS stages BEFORE this tile's stores are issued.
-        // vmcnt is in order on gfx950: a load issued after the stores cannot be waited for without waiting for them, a load
-        // issued before them can (s_waitcnt vmcnt(<stores issued since>)).  So the slot is popped here instead of at the top
-        // of the loop (same cost, moved), its two stages requested, the stores issued, and the two k tiles multiplied while
-        // the stores drain; k tile 2 is requested behind the stores and waited for with everything else by the ordinary
-        // barrier at the end.  The tile is then CARRIED into the next turn of the loop, which starts at k tile 2.
-        bool hand_over = false;
-        int64_t ntm = 0, ntn = 0;
-        const char *na_tile = nullptr, *nb_tile = nullptr;
-        uint32_t na_voff[PP], nb_voff[PP];
-        if constexpr (PERSIST && WAVES == 8 && NPROD == 3 && !DIAG && MODE != EDGES) {
-            if ((flags & 16) && !accumulate && kt >= 2) {
-                for (;;) {  // the next slot that holds a tile (a self-comparison skips those below the diagonal)
-                    if (tid == 0) {
-                        int64_t got = -1;
-                        while (helping < 8) {
-                            const int qq = (home + helping) & 7;
-                            const uint32_t i = atomicAdd(&queues[qq], 1u);
-                            if ((int64_t)i < slots_per_queue) {
-                                got = ((int64_t)i << 3) | qq;
-                                break;
-                            }
-                            helping++;
-                        }
-                        s_bid = got;
-                    }
-                    __syncthreads();
-                    const int64_t nbid = s_bid;
-                    __syncthreads();
-                    if (nbid < 0) {
-                        queues_empty = true;  // nothing left anywhere: this epilogue is the workgroup's last
-                        break;
-                    }
-                    if (tile_of_block(nbid, super_n, tiles_m, tiles_n, &ntm, &ntn, flags >> 8) && !(SYM && ntn < ntm)) {
-                        hand_over = true;
-                        break;
-                    }
-                }
-                if (hand_over) {
-                    const int64_t nrow = ntm * TM, ncol = ntn * TN;
-                    na_tile = reinterpret_cast<const char*>(A + (size_t)nrow * pitch);
-                    nb_tile = reinterpret_cast<const char*>(B + (size_t)ncol * pitch);
-#pragma unroll
-                    for (int p = 0; p < PP; p++) {
-                        const int row = (wave * PP + p) * 8 + (lane_e >> 3);
-                        const int chunk = (lane_e & 7) ^ ((row >> 1) & 7);
-                        const int64_t ra = std::min<int64_t>(row, M - 1 - nrow);
-                        const int64_t rb = std::min<int64_t>(row, N - 1 - ncol);
-                        na_voff[p] = (uint32_t)(ra * pitch * 2 + chunk * 16);
-                        nb_voff[p] = (uint32_t)(rb * pitch * 2 + chunk * 16);
-                    }
-                    stage_at(0, 0, na_tile, nb_tile, na_voff, nb_voff);
-                    stage_at(1, 1, na_tile, nb_tile, na_voff, nb_voff);
-                    __builtin_amdgcn_sched_barrier(0);
-                    asm volatile("" ::: "memory");  // the 16 requests stand in front of every store below
-                }
-            }
-        }
         const int run = (flags >> 2) & 3;  // 1: 64-byte runs, 2: 128, 3: 256
         using std::false_type;
         using std::integral_constant;
@@ -982,29 +856,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void pearson_gemm_split16_ke
             if (run == 3) body(false_type{}, integral_constant<int, 256>{}, false_type{});
             else if (run == 2) body(false_type{}, integral_constant<int, 128>{}, false_type{});
             else body(false_type{}, integral_constant<int, 64>{}, false_type{});
-        }
-        if constexpr (PERSIST && WAVES == 8 && NPROD == 3 && !DIAG && MODE != EDGES) {
-            if (hand_over) {
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < MT; i++)
-#pragma unroll
-                    for (int jj = 0; jj < NT; jj++)
-#pragma unroll
-                        for (int e = 0; e < 4; e++) acc[i][jj][e] = 0.f;
-                // my 16 stage requests have landed: at most the stores issued since (32 direct, 32 more with a mirror) may
-                // still be out (the counter's field ends at 63: one store more is waited for than necessary).  Then
-                // everybody's: a bare s_barrier — __syncthreads() would fence, i.e. wait for vmcnt(0), the stores
-                if (mirror) asm volatile("s_waitcnt vmcnt(63)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(32)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                consume_stage(0);
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // nobody reads stage 0 any more
-                if (kt > 2) stage_at(0, 2, na_tile, nb_tile, na_voff, nb_voff);  // behind the stores: waited for by the barrier below
-                consume_stage(1);
-                __syncthreads();
-                carry_tm = ntm;
-                carry_tn = ntn;
-            }
         }
     } else
 #pragma unroll
@@ -1132,13 +983,13 @@ int launch_chunk(skr_ctx* ctx, const T* Ac, const T* Bc, const SplitOut& o, int6
         const int reserve = ctx->knobs.gemm_reserve_cus >= 0 ? ctx->knobs.gemm_reserve_cus : (ctx->nranks > 1 ? 8 : 0);
         const unsigned grid = (unsigned)std::max(8, ctx->num_cu - reserve);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), 2 * kStageBytes, ctx->stream, Ac, Bc, o.C, o.Ct, M, N, ktc, o.ldc, o.ldct, K,
-                           tiles_m, tiles_n, super_n, queues, slots / 8, kt_pitch, accumulate | ((ctx->knobs.gemm_epilogue & 3) << 2) | (ctx->knobs.gemm_prestage ? 16 : 0) | (ctx->knobs.gemm_subtile << 8), diag, es);
+                           tiles_m, tiles_n, super_n, queues, slots / 8, kt_pitch, accumulate | ((ctx->knobs.gemm_epilogue & 3) << 2) | (ctx->knobs.gemm_subtile << 8), diag, es);
     } else {
         auto kern = pearson_gemm_split16_kernel<T, NPROD, MODE, false>;
         SKR_TRY(skr_kernel_lds(ctx, reinterpret_cast<const void*>(kern), 2 * kStageBytes));
         hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(512), 2 * kStageBytes, ctx->stream, Ac, Bc, o.C, o.Ct, M, N, ktc, o.ldc,
                            o.ldct, K, tiles_m, tiles_n, super_n, (uint32_t*)nullptr, (int64_t)0, kt_pitch,
-                           accumulate | ((ctx->knobs.gemm_epilogue & 3) << 2) | (ctx->knobs.gemm_prestage ? 16 : 0) | (ctx->knobs.gemm_subtile << 8), (unsigned long long*)nullptr, es);
+                           accumulate | ((ctx->knobs.gemm_epilogue & 3) << 2) | (ctx->knobs.gemm_subtile << 8), (unsigned long long*)nullptr, es);
     }
     SKR_HIP(hipGetLastError());
     return SKR_OK;

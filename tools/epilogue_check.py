@@ -16,19 +16,17 @@ ctx = L.default_context()
 rng = np.random.default_rng(6)
 
 
-ARMS = ("0", "1", "2", "3", "3p", "1p")  # the general loop; lean with 64- / 128- / 256-byte row runs; the same with PRESTAGE
+ARMS = ("0", "1", "2", "3")  # the general loop; lean with 64- / 128- / 256-byte row runs
 
 
 def both(fn):
-    """[general, lean 64, lean 128, lean 256, lean 256 + prestage, lean 64 + prestage]; asserts nothing itself."""
+    """[general, lean 64, lean 128, lean 256]; asserts nothing itself."""
     out = []
     for val in ARMS:
-        os.environ["SEEKR_GEMM_EPILOGUE"] = val[0]
-        os.environ["SEEKR_GEMM_PRESTAGE"] = "1" if val.endswith("p") else "0"
+        os.environ["SEEKR_GEMM_EPILOGUE"] = val
         ctx.reload_knobs()
         out.append(fn())
     os.environ.pop("SEEKR_GEMM_EPILOGUE")
-    os.environ.pop("SEEKR_GEMM_PRESTAGE")
     ctx.reload_knobs()
     return out
 
