@@ -162,6 +162,11 @@ def main():
     c = BasicCounter(path("g10.fa"), k=2, silent=True)
     c.get_counts()
     save("g10_mixed_normalised", c.counts), save("g10_mixed_mean", c.mean)
+    # ... and through the command (console_scripts.py:564-572): raw counts of the same file to .npy and to the labelled csv
+    cli(cs.console_kmer_counts, path("g10.fa"), "-o", path("cli_g10_raw.npy"), "-k", 2, "-b", "-rl", "-uc", "-us", "-l", "Log2.none")
+    with open(path("g10.fa"), "wb") as fh:
+        fh.write(bytes.fromhex([c for c in g10 if c["name"] == "non_ascii_only_in_headers"][0]["hex"]))
+    cli(cs.console_kmer_counts, path("g10.fa"), "-o", path("cli_g10_labelled.csv"), "-k", 2)
     os.remove(path("g10.fa"))
     out["stdout"] = np.array(log.getvalue())
     np.savez(path("results.npz"), **out)

@@ -102,6 +102,15 @@ def test_g10_files_that_are_not_ascii(baseline, golden_dir):
         assert str(a["g10_seqs_" + case["name"]]).split("\n") == case["seqs"], case["name"]
         n_counts += 1
     assert n_counts >= 13
+    # the same through seekr_kmer_counts: the .npy holds the reference's raw bits of the mixed file, the labelled csv its
+    # headers (decoded text, as the reference's DataFrame index would hold them) in the first column
+    mixed = [c for c in g["cases"] if c["name"] == "mixed_records"][0]
+    raw = np.load(os.path.join(baseline, "cli_g10_raw.npy"))
+    assert raw.dtype == np.float32 and np.array_equal(raw.view(np.uint32), np.array(mixed["raw_k2_bits"], dtype=np.uint32))
+    named = [c for c in g["cases"] if c["name"] == "non_ascii_only_in_headers"][0]
+    with open(os.path.join(baseline, "cli_g10_labelled.csv"), encoding="utf-8") as fh:
+        rows = fh.read().splitlines()
+    assert [r.split(",")[0] for r in rows[1:]] == named["headers"] and any(ord(ch) > 127 for ch in "".join(named["headers"]))
 
 
 @pytest.mark.parametrize("stripe", [300, 1])
