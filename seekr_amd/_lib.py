@@ -708,7 +708,7 @@ class FastaFile:
         check(lib().skr_fasta_headers(self._h, None, 0, C.byref(need)))
         buf = C.create_string_buffer(max(need.value, 1))
         check(lib().skr_fasta_headers(self._h, buf, need.value, None))
-        text = buf.value.decode("utf-8", "replace")
+        text = buf.raw[:max(need.value - 1, 0)].decode("utf-8", "replace")  # (.raw: a header may hold a NUL byte)
         return text.split("\n") if text else []
 
     def pack(self, ctx, first=0, count=None, alphabet="AGTC"):
@@ -815,7 +815,7 @@ class PackedSeqs:
         check(lib().skr_seqs_headers(self._h, None, 0, C.byref(need)))
         buf = C.create_string_buffer(max(need.value, 1))
         check(lib().skr_seqs_headers(self._h, buf, need.value, None))
-        text = buf.value.decode("utf-8", "replace")
+        text = buf.raw[:max(need.value - 1, 0)].decode("utf-8", "replace")  # (.raw: a header may hold a NUL byte)
         return text.split("\n") if text else []
 
     def free(self):

@@ -518,3 +518,17 @@ def test_the_parity_rule_judges_cells_as_documented():
     assert parity_rule.judge(truth, fake_ref, truth, ok, x, x)["failures"] == []   # ... a float64-exact device passes
     v = parity_rule.judge(truth + 1.5 * parity_rule.bar_of(truth), fake_ref, truth, ok, x, x)
     assert v["failures"] and all("not within the bar of float64" in f[2] for f in v["failures"])
+
+
+def test_native_parser_keeps_a_nul_byte_inside_a_header(tmp_path):
+    """Found by tools/fuzz_reader_vs_reference.py (round 6): headers travel as one '\\n'-joined buffer, and ctypes' `.value`
+    cut it at the first NUL byte — every header behind it was lost.  str.strip() does not remove NUL, so the reference
+    keeps it (fasta_reader.py:45,59)."""
+    from seekr_amd import _lib
+    from seekr_amd.fasta_reader import Reader
+    path = str(tmp_path / "nul.fa")
+    with open(path, "wb") as fh:
+        fh.write(b">a\x00b c\nACGT\n>second\nAC\x00GT\n>third\nTTTT\n")
+    fa = _lib.FastaFile(path)
+    assert fa.headers() == Reader(path).get_headers() == orc.read_fasta(path)[0] == [">a\x00b c", ">second", ">third"]
+    assert list(fa.lengths()) == [len(s) for s in Reader(path).get_seqs()] == [4, 5, 4]
