@@ -257,6 +257,10 @@ enum {
 /* what = 0: np.mean(x, axis=0) (:168), 1: np.std(x, axis=0) (:174).  out: [cols] float16 for a float16 matrix, float64
  * for every other type (numpy's result types).                                                                       */
 int skr_host_colstat(skr_ctx* ctx, const void* x, int64_t rows, int64_t cols, int np_type, int what, void* out);
+/* The same for a COLUMN-MAJOR matrix (cell (i, j) at j * rows + i: a Fortran-ordered array such as `DataFrame.values`, or a
+ * single column): there numpy reduces column by column in the PAIRWISE order of its float loops — for 50 000 rows up to
+ * 1e-5 relative away from the row-after-row order in float32.  SKR_NP_F32 / SKR_NP_F64; out: [cols] of the same type.   */
+int skr_host_colstat_colmajor(skr_ctx* ctx, const void* x, int64_t rows, int64_t cols, int np_type, int what, void* out);
 /* In place on x.  op 0: x -= vec[col] (:169), op 1: x /= vec[col] (:175) — float matrices; vec is float64 (vec_is_f64) or
  * float32 [cols], the type numpy's promotion evaluates the operation in (a float64 matrix: always float64; a float16
  * matrix: float32 for float16 / float32 / 8- and 16-bit integer vectors, float64 otherwise), the result rounded once to

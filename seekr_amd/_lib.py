@@ -144,6 +144,7 @@ SIGNATURES = {
     "skr_comm_wait": (_int, [_p, _i64]),
     "skr_comm_allreduce_f64": (_int, [_p, C.POINTER(C.c_double), _int, _int]),
     "skr_host_colstat": (_int, [_p, _p, _i64, _i64, _int, _int, _p]),
+    "skr_host_colstat_colmajor": (_int, [_p, _p, _i64, _i64, _int, _int, _p]),
     "skr_host_apply": (_int, [_p, _p, _i64, _i64, _int, _int, _p, _int, _p, _int, C.POINTER(_int)]),
 }
 # libseekr_hip_diag.so only (tools/gemm_diag.py sets LIB_PATH to it before the first call)
@@ -902,6 +903,23 @@ def host_colstat(ctx, x, what):
     out = np.empty(x.shape[1], dtype=np.float16 if x.dtype == np.float16 else np.float64)
     check(lib().skr_host_colstat(ctx._h, x.ctypes.data_as(_p), x.shape[0], x.shape[1], NP_CODES[x.dtype],
                                  {"mean": 0, "std": 1}[what], out.ctypes.data_as(_p)))
+    return out
+
+
+def column_major_like(a):
+    """Does numpy reduce `a` along axis 0 COLUMN BY COLUMN (pairwise order) rather than row after row?  When axis 0 is the
+    faster axis (Fortran order, or a strided view of one) or there is a single column; np.mean / np.std(axis=0) then add each
+    column in the pairwise order of numpy's float loops."""
+    return a.ndim == 2 and a.shape[0] >= 2 and (a.shape[1] == 1 or abs(a.strides[0]) < abs(a.strides[1]))
+
+
+def host_colstat_colmajor(ctx, x, what):
+    """np.mean / np.std along axis 0 of a float32 / float64 host matrix that numpy reduces column by column
+    (column_major_like): the pairwise order, on the device; returns a vector of x's dtype."""
+    xf = np.asfortranarray(x)
+    out = np.empty(xf.shape[1], dtype=xf.dtype)
+    check(lib().skr_host_colstat_colmajor(ctx._h, xf.ctypes.data_as(_p), xf.shape[0], xf.shape[1], NP_CODES[xf.dtype],
+                                          {"mean": 0, "std": 1}[what], out.ctypes.data_as(_p)))
     return out
 
 

@@ -201,6 +201,69 @@ __global__ __launch_bounds__(256) void elementwise_any_kernel(void* __restrict__
     if (__any(any_nan) && (threadIdx.x & 63) == 0) atomicOr(&flags[1], 1u);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same statistics when numpy reduces COLUMN BY COLUMN: a column-major (Fortran-ordered) matrix — what
+// `DataFrame.values` of a CSV hands out — or a single column.  There axis 0 is the fast axis, the reduction becomes the
+// inner loop, and numpy's float loops add a column in their PAIRWISE order (umath loops: fewer than 8 values one after the
+// other from 0; up to 128 in eight strided accumulators folded ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus leftovers; longer
+// runs split at n/2 rounded down to a multiple of 8) — the order operand.hip reproduces for the ROWS of pearson.py:35-38.
+// For 50 000 rows the two orders differ by up to 1e-5 relative in float32: not a rounding detail.  x is column-major here
+// (cell (i, j) at j * rows + i); float32 and float64 only (no cast, so numpy makes one call per column: no buffer chunks).
+// F maps a cell to the value that is summed (the cell itself; or its squared deviation from the column's mean).
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, typename F>
+__device__ T np_pairwise(const T* a, int64_t n, F f) {
+    if (n < 8) {
+        T res = (T)0;
+        for (int64_t i = 0; i < n; i++) res = res + f(a[i]);
+        return res;
+    }
+    if (n <= 128) {
+        T r[8];
+        for (int j = 0; j < 8; j++) r[j] = f(a[j]);
+        int64_t i = 8;
+        for (; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] = r[j] + f(a[i + j]);
+        T res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res = res + f(a[i]);
+        return res;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    const T left = np_pairwise<T, F>(a, n2, f);
+    return left + np_pairwise<T, F>(a + n2, n - n2, f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void colstat_pairwise_kernel(const T* __restrict__ x, int64_t rows, int64_t cols, int what,
+                                                             T* __restrict__ out) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    const T* col = x + c * rows;
+    // (the quotient by N: numpy divides the float32 sum by an intp scalar in float64 and stores float32 — one rounding of the
+    // exact quotient either way, 53 >= 2 * 24 + 2)
+    // numpy's reduction hands its inner loop the column in pieces of the iterator's buffer size (np.getbufsize(): 8 192
+    // elements) also when nothing is cast: res = ((0 + pairwise(piece 0)) + pairwise(piece 1)) + ... — observed: at 50 000
+    // float32 rows the one-piece sum is a different number
+    constexpr int64_t kNpBuf = 8192;
+    auto chunked = [&](auto f) {
+        T res = (T)0;
+        for (int64_t i0 = 0; i0 < rows; i0 += kNpBuf) res = res + np_pairwise<T>(col + i0, rows - i0 < kNpBuf ? rows - i0 : kNpBuf, f);
+        return res;
+    };
+    const T m = (T)((double)chunked([](T v) { return v; }) / (double)rows);
+    if (what == 0) {
+        out[c] = m;
+        return;
+    }
+    const T s = chunked([m](T v) {
+        const T d = v - m;
+        return d * d;
+    });
+    const T var = (T)((double)s / (double)rows);
+    out[c] = (T)sqrt((double)var);
+}
+
 struct DevBuf {  // a device allocation freed on every way out
     void* p = nullptr;
     ~DevBuf() {
@@ -242,6 +305,33 @@ extern "C" int skr_host_colstat(skr_ctx* ctx, const void* x, int64_t rows, int64
     }
     SKR_HIP(hipGetLastError());
     SKR_HIP(hipMemcpyAsync(out, dout.p, (size_t)cols * out_elem, hipMemcpyDeviceToHost, ctx->stream));
+    SKR_HIP(hipStreamSynchronize(ctx->stream));
+    return SKR_OK;
+}
+
+extern "C" int skr_host_colstat_colmajor(skr_ctx* ctx, const void* x, int64_t rows, int64_t cols, int np_type, int what, void* out) {
+    SKR_TRY(check_any(ctx, x, rows, cols, np_type));
+    SKR_REQUIRE(out || cols == 0, "out is NULL");
+    SKR_REQUIRE(what == 0 || what == 1, "what must be 0 (mean) or 1 (std)");
+    SKR_REQUIRE(np_type == NP_F32 || np_type == NP_F64, "column-major statistics exist for float32 and float64");
+    if (cols == 0) return SKR_OK;
+    SKR_TRY(skr_activate(ctx));
+    const size_t elem = np_type == NP_F32 ? 4 : 8;
+    const size_t bytes = (size_t)rows * (size_t)cols * elem;
+    DevBuf dx, dout;
+    SKR_TRY(dx.alloc(bytes));
+    SKR_TRY(dout.alloc((size_t)cols * elem));
+    if (bytes) SKR_HIP(hipMemcpyAsync(dx.p, x, bytes, hipMemcpyHostToDevice, ctx->stream));
+    {
+        SkrProfScope prof(ctx, "colstat_pairwise");
+        const dim3 grid((unsigned)((cols + 63) / 64));
+        if (np_type == NP_F32)
+            hipLaunchKernelGGL(colstat_pairwise_kernel<float>, grid, dim3(64), 0, ctx->stream, (const float*)dx.p, rows, cols, what, (float*)dout.p);
+        else
+            hipLaunchKernelGGL(colstat_pairwise_kernel<double>, grid, dim3(64), 0, ctx->stream, (const double*)dx.p, rows, cols, what, (double*)dout.p);
+    }
+    SKR_HIP(hipGetLastError());
+    SKR_HIP(hipMemcpyAsync(out, dout.p, (size_t)cols * elem, hipMemcpyDeviceToHost, ctx->stream));
     SKR_HIP(hipStreamSynchronize(ctx->stream));
     return SKR_OK;
 }

@@ -33,7 +33,10 @@ NAN_WARNING = (
 def _as_device_vector(ctx, vec, n_cols):
     """User mean/std vector -> 1 x K device vector; float32 stays float32, everything else is
     evaluated in float64 and rounded once, like numpy's in-place `counts -= vec`."""
-    arr = np.asarray(vec)
+    if isinstance(vec, (bool, int, float)):
+        arr = np.asarray(vec, dtype=np.float32)  # a Python scalar is weak (NEP 50): it takes the matrix's type BEFORE the operation
+    else:
+        arr = np.asarray(vec)
     if arr.dtype == np.float32 or arr.dtype == np.float16:
         arr = arr.astype(np.float32, copy=False)
     else:
@@ -255,8 +258,11 @@ class BasicCounter:
     def _in_place_any(self, counts, attr, what, ufunc, op):
         ctx = self._ctx()
         work = np.ascontiguousarray(counts)
-        if getattr(self, attr) is True:
-            setattr(self, attr, _lib.host_colstat(ctx, work, what))  # (:168,174: the attribute is replaced first)
+        if getattr(self, attr) is True:  # (:168,174: the attribute is replaced first)
+            if counts.dtype == np.float64 and _lib.column_major_like(counts):
+                setattr(self, attr, _lib.host_colstat_colmajor(ctx, counts, what))  # numpy adds such columns pairwise
+            else:
+                setattr(self, attr, _lib.host_colstat(ctx, work, what))
         operand = getattr(self, attr)
         self._replay(ufunc, counts, operand)
         vec = self._vector_for(counts, operand)
@@ -265,8 +271,11 @@ class BasicCounter:
         return has_nan
 
     def _store(self, dev):
-        if isinstance(self.counts, np.ndarray) and self.counts.flags.c_contiguous and self.counts.flags.writeable:
-            dev.to_numpy(out=self.counts)  # in place, like `self.counts -= ...`
+        if isinstance(self.counts, np.ndarray) and self.counts.flags.writeable:  # in place, like `self.counts -= ...`
+            if self.counts.flags.c_contiguous:
+                dev.to_numpy(out=self.counts)
+            else:
+                self.counts[...] = dev.to_numpy()  # a strided view of the caller's: its cells, not its gaps
         else:
             self.counts = dev.to_numpy()
 
@@ -278,6 +287,9 @@ class BasicCounter:
             self._in_place_any(other, "mean", "mean", np.subtract, "sub")
             return
         ctx = self._ctx()
+        if self.mean is True and _lib.column_major_like(np.asarray(self.counts)):
+            # a column-major float32 matrix (or a single column): numpy reduces it column by column, pairwise (_lib.column_major_like)
+            self.mean = _lib.host_colstat_colmajor(ctx, np.asarray(self.counts), "mean")
         dev = self._device_counts()
         if self.mean is True:
             acc = ctx.zeros(1, dev.cols)
@@ -299,6 +311,8 @@ class BasicCounter:
                 print(NAN_WARNING)
             return
         ctx = self._ctx()
+        if self.std is True and _lib.column_major_like(np.asarray(self.counts)):
+            self.std = _lib.host_colstat_colmajor(ctx, np.asarray(self.counts), "std")
         dev = self._device_counts()
         if self.std is True:
             mprime = ctx.zeros(1, dev.cols)
@@ -330,6 +344,15 @@ class BasicCounter:
             return
         ctx = self._ctx()
         dev = self._device_counts()
+        if isinstance(self.counts, np.ndarray) and self.counts.flags.writeable:
+            # the reference's `self.counts += 1` happens IN the caller's array before np.log2 binds a new one (:191-192): x + 1
+            # on the device as x - (-1) — the same float32 rounding — and back into that array (a view keeps its gaps)
+            plus = ctx.empty(dev.rows, dev.cols)
+            _lib.apply(ctx, dev, y=plus, center=ctx.from_numpy(np.full((1, dev.cols), -1.0, np.float32)))
+            if self.counts.flags.c_contiguous:
+                plus.to_numpy(out=self.counts)
+            else:
+                self.counts[...] = plus.to_numpy()
         _lib.apply(ctx, dev, pre=True)
         self.counts = dev.to_numpy()
 

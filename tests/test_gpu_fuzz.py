@@ -29,6 +29,48 @@ def test_fuzz_consumers(seed):
     assert fuzz(seed, budget_s=6.0, max_cases=1500) >= 100
 
 
+@pytest.mark.parametrize("seed", [41, 42])
+def test_fuzz_normalisation_methods_on_any_dtype_and_layout(seed):
+    """center / standardize / log2_norm on hand-assigned matrices of twelve dtypes, C-like / strided / column-major layouts and
+    eight kinds of user vector against the three numpy statements of kmer_counts.py:165-192 on the same input
+    (tests/fuzz_any_dtype.py): bytes of the result and of the replaced mean / std, in-place writes into the caller's memory
+    (gaps untouched), dtypes, the warning, numpy's exceptions with their text."""
+    from fuzz_any_dtype import fuzz
+    assert fuzz(seed, budget_s=10.0, max_cases=8000) >= 500
+
+
+@pytest.mark.parametrize("dtype,rows", [("float32", 50_000), ("float64", 30_011), ("float32", 1)])
+def test_column_major_matrices_get_numpys_pairwise_column_sums(dtype, rows):
+    """`DataFrame.values` of a CSV is column-major: numpy then reduces np.mean / np.std(axis=0) column by column in the
+    pairwise order of its float loops — 1e-5 relative away from the row-after-row order at 50 000 float32 rows, the size
+    at which the reference's C-ordered matrix needed the row order reproduced (G5).  skr_host_colstat_colmajor: mean, std and
+    the centred / scaled matrix bit for bit with numpy, also for the single-column case (reduced pairwise in any order)."""
+    import numpy as np
+    from seekr_amd.kmer_counts import BasicCounter
+    rng = np.random.default_rng(rows)
+    cols = 24 if rows > 1 else 1
+    n = rows if rows > 1 else 5000
+    base = np.asfortranarray((rng.poisson(0.5, size=(n, cols)) * (1000.0 / 1995.0)).astype(dtype))
+    assert base.flags.f_contiguous
+    mine, ref = base.copy(order="F"), base.copy(order="F")
+    c = BasicCounter(k=1, silent=True)
+    c.counts = mine
+    c.center()
+    m = np.mean(ref, axis=0)
+    ref -= m
+    assert c.mean.dtype == m.dtype and c.mean.tobytes() == m.tobytes() and c.counts is mine and np.array_equal(mine, ref)
+    c.standardize()
+    with np.errstate(all="ignore"):
+        s = np.std(ref, axis=0)
+        ref /= s
+    assert c.std.tobytes() == s.tobytes() and np.array_equal(mine, ref, equal_nan=True)
+    if rows > 1 and dtype == "float32":  # the row-after-row order would NOT have been the same bits here
+        seq = np.zeros(cols, np.float32)
+        for row in base:
+            seq = seq + row
+        assert not np.array_equal(seq / np.float32(n), m)
+
+
 def test_regression_rows_that_are_mostly_one_repeated_value(golden_dir):
     """Found by the fuzzer after 21 000 cases: with a 7-letter alphabet 90 % of the 4-mer columns are structurally
     zero, every zero column gets the same (hi, lo) pair under round-to-nearest, and the coherent hi*lo products
