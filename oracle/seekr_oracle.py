@@ -259,6 +259,65 @@ def seqsum_any(x, acc_dtype):
     return acc
 
 
+def pairwise_sum_any(a, dt):
+    """One call of numpy's float add loop over a contiguous run (numpy 2.2,
+    _core/src/umath/loops_utils.h.src: *_pairwise_sum — numpy is the
+    reference's dependency, not vendored in it): fewer than 8 values one after
+    the other from 0; up to 128 in eight strided accumulators folded
+    ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus the leftovers; longer runs split
+    at n/2 rounded down to a multiple of 8."""
+    n = len(a)
+    if n < 8:
+        res = dt(0)
+        for v in a:
+            res = dt(res + v)
+        return res
+    if n <= 128:
+        r = [dt(a[j]) for j in range(8)]
+        i = 8
+        while i < n - (n % 8):
+            for j in range(8):
+                r[j] = dt(r[j] + a[i + j])
+            i += 8
+        res = dt(dt(dt(r[0] + r[1]) + dt(r[2] + r[3])) + dt(dt(r[4] + r[5]) + dt(r[6] + r[7])))
+        while i < n:
+            res = dt(res + a[i])
+            i += 1
+        return res
+    n2 = n // 2
+    n2 -= n2 % 8
+    return dt(pairwise_sum_any(a[:n2], dt) + pairwise_sum_any(a[n2:], dt))
+
+
+NP_BUFSIZE = 8192  # np.getbufsize(): the reduction hands its inner loop at most this many elements per call
+
+
+def reduces_column_by_column(x):
+    """Does np.add.reduce(x, axis=0) make axis 0 its INNER loop?  When axis 0 is
+    the faster axis (column-major: DataFrame.values of a read CSV) or there is
+    one column; float32 / float64 only here (no cast on the way)."""
+    return (x.dtype in (np.float32, np.float64) and x.shape[0] >= 2
+            and (x.shape[1] == 1 or abs(x.strides[0]) < abs(x.strides[1])))
+
+
+def colsum_any(x, acc_dtype):
+    """np.add.reduce(x, axis=0, dtype=acc_dtype) in numpy's own order for x's
+    LAYOUT: row after row (seqsum_any) or, reduces_column_by_column, every
+    column pairwise in pieces of NP_BUFSIZE: ((0 + piece0) + piece1) + ..."""
+    if not (reduces_column_by_column(x) and x.dtype == acc_dtype):
+        return seqsum_any(x, acc_dtype)
+    dt = x.dtype.type
+    with np.errstate(all="ignore"):
+        out = np.empty(x.shape[1], dtype=x.dtype)
+        for j in range(x.shape[1]):
+            col = np.ascontiguousarray(x[:, j])
+            res = dt(0)
+            for i0 in range(0, len(col), NP_BUFSIZE):
+                res = dt(res + pairwise_sum_any(col[i0:i0 + NP_BUFSIZE], dt))
+            out[j] = res
+    return out
+
+
 def column_mean_any(x):
     """np.mean(x, axis=0) (:168): float16 sums in float32, the quotient is taken
     in float64 (float32 array / intp scalar), stored as float32 and then cast
@@ -268,20 +327,25 @@ def column_mean_any(x):
         if x.dtype == np.float16:
             s = seqsum_any(x, np.float32)
             return (s.astype(np.float64) / n).astype(np.float32).astype(np.float16)
-        return seqsum_any(x, np.float64) / n
+        if x.dtype == np.float32:  # float32 array / intp scalar: the quotient in float64, stored as float32
+            return (colsum_any(x, np.float32).astype(np.float64) / n).astype(np.float32)
+        return colsum_any(x, np.float64) / n
 
 
 def column_std_any(x):
-    """np.std(x, axis=0) (:174): float16 stays float16 at every step (each
-    quotient by N taken in float64 and rounded once to half); everything else
-    runs in float64."""
+    """np.std(x, axis=0) (:174), numpy's `_var` step by step: float16 stays
+    float16 at every step (each quotient by N taken in float64 and rounded once
+    to half), float32 stays float32, everything else runs in float64.  The
+    deviations keep x's layout ('K' order), so a column-major float matrix has
+    its squares added column by column too."""
     n = x.shape[0]
-    dt = np.float16 if x.dtype == np.float16 else np.float64
+    dt = x.dtype.type if x.dtype in (np.float16, np.float32) else np.float64
     with np.errstate(all="ignore"):
-        m = (seqsum_any(x, dt).astype(np.float64) / n).astype(dt)
-        d = (x.astype(dt) - m).astype(dt)
+        xs = x.astype(dt)
+        m = (colsum_any(xs, dt).astype(np.float64) / n).astype(dt)
+        d = (xs - m).astype(dt)
         d = (d * d).astype(dt)
-        v = (seqsum_any(d, dt).astype(np.float64) / n).astype(dt)
+        v = (colsum_any(d, dt).astype(np.float64) / n).astype(dt)
         return np.sqrt(v)
 
 

@@ -1657,7 +1657,8 @@ def test_g11_normalisation_methods_on_matrices_that_are_not_float32(golden_dir):
 def test_normalisation_on_other_dtypes_is_in_place_like_the_reference(dtype):
     """`counts -= mean` / `counts /= std` are in-place operations in the reference (kmer_counts.py:169,175): the caller's
     own array holds the result afterwards, also when it is a non-contiguous view; log2_norm adds 1 in place and binds a
-    NEW array (:191-192).  Random matrices against the oracle's restatement, bit for bit."""
+    NEW array (:191-192).  Random matrices against the oracle's restatement (which follows numpy's summation order for the
+    view's layout: oracle.colsum_any), bit for bit."""
     from seekr_amd.kmer_counts import BasicCounter
     rng = np.random.default_rng(5)
     base = (rng.poisson(1.3, size=(40, 24)) * (0.5 if dtype != "int32" else 1)).astype(dtype)
@@ -1666,7 +1667,7 @@ def test_normalisation_on_other_dtypes_is_in_place_like_the_reference(dtype):
         target = view(mine)
         c = BasicCounter(k=1, silent=True)
         c.counts = target
-        want = np.ascontiguousarray(view(base.copy()))
+        want = view(base.copy())  # the same LAYOUT: numpy adds a column-major float64 matrix column by column, pairwise
         if dtype == "int32":
             vec = np.arange(target.shape[1], dtype=np.int64)
             c.mean = vec
