@@ -50,7 +50,7 @@ SIGNATURES = {
     "skr_mat_upload": (_int, [_p, _p, _i64, _i64]),
     "skr_mat_download": (_int, [_p, _p, _i64, _i64]),
     "skr_mat_fill_zero": (_int, [_p]),
-    "skr_host_register": (_int, [_p, C.c_size_t]),
+    "skr_host_register": (_int, [_int, _p, C.c_size_t]),
     "skr_host_unregister": (_int, [_p]),
     "skr_ctx_mark": (_int, [_p, C.POINTER(_i64)]),
     "skr_ctx_mark_release": (_int, [_p, _i64]),
@@ -256,13 +256,18 @@ def device_count():
     return n.value if rc == SKR_OK else 0
 
 
+_last_device = None  # the device of the newest Context: where the result pool registers its pages (no Context, no GPU: no registering)
+
+
 class Context:
     """One GPU + one stream (skr_ctx)."""
 
     def __init__(self, device=0):
+        global _last_device
         self._h = _p()
         self.device = device
         check(lib().skr_ctx_create(int(device), C.byref(self._h)))
+        _last_device = int(device)
 
     def close(self):
         if getattr(self, "_h", None) and not _shutdown:
@@ -405,9 +410,10 @@ class _Slab:
         """Page-lock the (by now touched) pages: 5-7 ms for 576 MB, once; every later copy into them is plain DMA at the link's
         rate — without it the rate depends on the state of the runtime's own pinning cache (10 or 19 ms for the same 549 MB
         download, measured in one process).  Quietly skipped where it cannot be done (no GPU, locked-memory limit)."""
-        if not self.registered and not _shutdown and os.environ.get("SEEKR_RESULT_POOL_REGISTER", "1") != "0":
-            try:
-                self.registered = lib().skr_host_register(self.arr.ctypes.data_as(_p), self.arr.nbytes) == SKR_OK
+        if (not self.registered and not _shutdown and _last_device is not None
+                and os.environ.get("SEEKR_RESULT_POOL_REGISTER", "1") != "0"):
+            try:  # on the device of the newest Context: this may be a finaliser on a thread that has never chosen a device
+                self.registered = lib().skr_host_register(int(_last_device), self.arr.ctypes.data_as(_p), self.arr.nbytes) == SKR_OK
             except Exception:  # noqa: BLE001
                 self.registered = False
 

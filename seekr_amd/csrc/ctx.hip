@@ -32,8 +32,11 @@ extern "C" int skr_device_count(int* count) {
 
 // Page-lock a host range the caller owns (hipHostRegister) so that copies to / from it are plain DMA at the link's rate,
 // whatever state the runtime's own pinning cache is in; undone with skr_host_unregister before the memory is freed.
-extern "C" int skr_host_register(void* ptr, size_t bytes) {
+extern "C" int skr_host_register(int device, void* ptr, size_t bytes) {
     SKR_REQUIRE(ptr && bytes, "empty range");
+    // the runtime registers "on the current device" of the calling thread, and a thread that has never chosen one (a
+    // finaliser running on a collector's thread) would bring up device 0's context in every rank process of a node
+    if (device >= 0) SKR_HIP(hipSetDevice(device));
     SKR_HIP(hipHostRegister(ptr, bytes, hipHostRegisterPortable));  // every GPU of the node copies at the pinned rate
     return SKR_OK;
 }
