@@ -261,7 +261,9 @@ enum {
 int skr_host_colstat(skr_ctx* ctx, const void* x, int64_t rows, int64_t cols, int np_type, int what, void* out);
 /* The same for a COLUMN-MAJOR matrix (cell (i, j) at j * rows + i: a Fortran-ordered array such as `DataFrame.values`, or a
  * single column): there numpy reduces column by column in the PAIRWISE order of its float loops — for 50 000 rows up to
- * 1e-5 relative away from the row-after-row order in float32.  SKR_NP_F32 / SKR_NP_F64; out: [cols] of the same type.   */
+ * 1e-5 relative away from the row-after-row order in float32.  SKR_NP_F16 / SKR_NP_F32 / SKR_NP_F64 (float16: numpy's
+ * half loops, float32 accumulators within a buffer piece; integer matrices are passed as the float64 values numpy casts
+ * them to); out: [cols] of the same type.                                                                                */
 int skr_host_colstat_colmajor(skr_ctx* ctx, const void* x, int64_t rows, int64_t cols, int np_type, int what, void* out);
 /* In place on x.  op 0: x -= vec[col] (:169), op 1: x /= vec[col] (:175) — float matrices; vec is float64 (vec_is_f64) or
  * float32 [cols], the type numpy's promotion evaluates the operation in (a float64 matrix: always float64; a float16

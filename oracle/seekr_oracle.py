@@ -295,25 +295,27 @@ NP_BUFSIZE = 8192  # np.getbufsize(): the reduction hands its inner loop at most
 def reduces_column_by_column(x):
     """Does np.add.reduce(x, axis=0) make axis 0 its INNER loop?  When axis 0 is
     the faster axis (column-major: DataFrame.values of a read CSV) or there is
-    one column; float32 / float64 only here (no cast on the way)."""
-    return (x.dtype in (np.float32, np.float64) and x.shape[0] >= 2
-            and (x.shape[1] == 1 or abs(x.strides[0]) < abs(x.strides[1])))
+    one column."""
+    return x.shape[0] >= 2 and (x.shape[1] == 1 or abs(x.strides[0]) < abs(x.strides[1]))
 
 
 def colsum_any(x, acc_dtype):
     """np.add.reduce(x, axis=0, dtype=acc_dtype) in numpy's own order for x's
     LAYOUT: row after row (seqsum_any) or, reduces_column_by_column, every
-    column pairwise in pieces of NP_BUFSIZE: ((0 + piece0) + piece1) + ..."""
-    if not (reduces_column_by_column(x) and x.dtype == acc_dtype):
+    column in pieces of NP_BUFSIZE, each piece cast to the loop's type and added
+    pairwise: out = acc(out + pairwise(piece)).  The half loop (HALF_add) keeps
+    float32 accumulators inside a piece and rounds to half once per piece."""
+    if not reduces_column_by_column(x):
         return seqsum_any(x, acc_dtype)
-    dt = x.dtype.type
+    acc = np.dtype(acc_dtype).type
+    work = np.float32 if acc is np.float16 else acc
     with np.errstate(all="ignore"):
-        out = np.empty(x.shape[1], dtype=x.dtype)
+        out = np.empty(x.shape[1], dtype=acc)
         for j in range(x.shape[1]):
-            col = np.ascontiguousarray(x[:, j])
-            res = dt(0)
+            col = np.ascontiguousarray(x[:, j]).astype(work)
+            res = acc(0)
             for i0 in range(0, len(col), NP_BUFSIZE):
-                res = dt(res + pairwise_sum_any(col[i0:i0 + NP_BUFSIZE], dt))
+                res = acc(work(res) + pairwise_sum_any(col[i0:i0 + NP_BUFSIZE], work))
             out[j] = res
     return out
 
@@ -325,7 +327,7 @@ def column_mean_any(x):
     n = x.shape[0]
     with np.errstate(all="ignore"):
         if x.dtype == np.float16:
-            s = seqsum_any(x, np.float32)
+            s = colsum_any(x, np.float32)
             return (s.astype(np.float64) / n).astype(np.float32).astype(np.float16)
         if x.dtype == np.float32:  # float32 array / intp scalar: the quotient in float64, stored as float32
             return (colsum_any(x, np.float32).astype(np.float64) / n).astype(np.float32)
@@ -336,14 +338,13 @@ def column_std_any(x):
     """np.std(x, axis=0) (:174), numpy's `_var` step by step: float16 stays
     float16 at every step (each quotient by N taken in float64 and rounded once
     to half), float32 stays float32, everything else runs in float64.  The
-    deviations keep x's layout ('K' order), so a column-major float matrix has
-    its squares added column by column too."""
+    deviations keep x's layout ('K' order), so a column-major matrix has its
+    squares added column by column too."""
     n = x.shape[0]
     dt = x.dtype.type if x.dtype in (np.float16, np.float32) else np.float64
     with np.errstate(all="ignore"):
-        xs = x.astype(dt)
-        m = (colsum_any(xs, dt).astype(np.float64) / n).astype(dt)
-        d = (xs - m).astype(dt)
+        m = (colsum_any(x, dt).astype(np.float64) / n).astype(dt)
+        d = (x - m).astype(dt)
         d = (d * d).astype(dt)
         v = (colsum_any(d, dt).astype(np.float64) / n).astype(dt)
         return np.sqrt(v)

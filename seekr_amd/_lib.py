@@ -920,8 +920,12 @@ def column_major_like(a):
 
 
 def host_colstat_colmajor(ctx, x, what):
-    """np.mean / np.std along axis 0 of a float32 / float64 host matrix that numpy reduces column by column
-    (column_major_like): the pairwise order, on the device; returns a vector of x's dtype."""
+    """np.mean / np.std along axis 0 of a host matrix that numpy reduces column by column (column_major_like): the pairwise
+    order of its float loops, in pieces of the iterator's buffer, on the device.  float32 / float64 in their own arithmetic,
+    float16 in numpy's half loops (float32 accumulators within a piece), integers and bool as the float64 values numpy casts
+    them to piece by piece; returns a vector of the type np.mean / np.std give (x's own for floats, float64 otherwise)."""
+    if x.dtype.kind != "f":
+        x = x.astype(np.float64)  # exact for every integer numpy itself converts exactly; 'K' order: stays column-major
     xf = np.asfortranarray(x)
     out = np.empty(xf.shape[1], dtype=xf.dtype)
     check(lib().skr_host_colstat_colmajor(ctx._h, xf.ctypes.data_as(_p), xf.shape[0], xf.shape[1], NP_CODES[xf.dtype],

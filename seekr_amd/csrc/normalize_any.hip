@@ -211,8 +211,8 @@ __global__ __launch_bounds__(256) void elementwise_any_kernel(void* __restrict__
 // (cell (i, j) at j * rows + i); float32 and float64 only (no cast, so numpy makes one call per column: no buffer chunks).
 // F maps a cell to the value that is summed (the cell itself; or its squared deviation from the column's mean).
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, typename F>
-__device__ T np_pairwise(const T* a, int64_t n, F f) {
+template <typename T, typename A, typename F>
+__device__ T np_pairwise(const A* a, int64_t n, F f) {  // f: a cell (type A) -> the value that is summed (type T)
     if (n < 8) {
         T res = (T)0;
         for (int64_t i = 0; i < n; i++) res = res + f(a[i]);
@@ -230,8 +230,8 @@ __device__ T np_pairwise(const T* a, int64_t n, F f) {
     }
     int64_t n2 = n / 2;
     n2 -= n2 % 8;
-    const T left = np_pairwise<T, F>(a, n2, f);
-    return left + np_pairwise<T, F>(a + n2, n - n2, f);
+    const T left = np_pairwise<T, A, F>(a, n2, f);
+    return left + np_pairwise<T, A, F>(a + n2, n - n2, f);
 }
 
 template <typename T>
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64) void colstat_pairwise_kernel(const T* __restric
     constexpr int64_t kNpBuf = 8192;
     auto chunked = [&](auto f) {
         T res = (T)0;
-        for (int64_t i0 = 0; i0 < rows; i0 += kNpBuf) res = res + np_pairwise<T>(col + i0, rows - i0 < kNpBuf ? rows - i0 : kNpBuf, f);
+        for (int64_t i0 = 0; i0 < rows; i0 += kNpBuf) res = res + np_pairwise<T, T>(col + i0, rows - i0 < kNpBuf ? rows - i0 : kNpBuf, f);
         return res;
     };
     const T m = (T)((double)chunked([](T v) { return v; }) / (double)rows);
@@ -262,6 +262,36 @@ __global__ __launch_bounds__(64) void colstat_pairwise_kernel(const T* __restric
     });
     const T var = (T)((double)s / (double)rows);
     out[c] = (T)sqrt((double)var);
+}
+
+// A column-major float16 matrix.  np.mean: the column is cast to float32 in pieces of the buffer size and added pairwise in
+// float32 (umr_sum(dtype=float32)).  np.std: numpy's half loop adds a piece pairwise IN FLOAT32 accumulators
+// (HALF_pairwise_sum returns a float) and rounds to half once per piece — out = half(float(out) + piece) — every other
+// step as in colstat_any_kernel (half arrays, quotients by N in float64 rounded once to half).
+__global__ __launch_bounds__(64) void colstat_pairwise_f16_kernel(const uint16_t* __restrict__ x, int64_t rows, int64_t cols, int what,
+                                                                 uint16_t* __restrict__ out) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    const uint16_t* col = x + c * rows;
+    constexpr int64_t kNpBuf = 8192;
+    auto piece = [&](int64_t i0, auto f) { return np_pairwise<float, uint16_t>(col + i0, rows - i0 < kNpBuf ? rows - i0 : kNpBuf, f); };
+    if (what == 0) {
+        float res = 0.0f;
+        for (int64_t i0 = 0; i0 < rows; i0 += kNpBuf) res = __fadd_rn(res, piece(i0, [](uint16_t v) { return h2f(v); }));
+        out[c] = f2h((float)((double)res / (double)rows));
+        return;
+    }
+    float res = 0.0f;  // half-representable between pieces
+    for (int64_t i0 = 0; i0 < rows; i0 += kNpBuf) res = rh(__fadd_rn(res, piece(i0, [](uint16_t v) { return h2f(v); })));
+    const float m = h2f(d2h((double)res / (double)rows));
+    res = 0.0f;
+    for (int64_t i0 = 0; i0 < rows; i0 += kNpBuf)
+        res = rh(__fadd_rn(res, piece(i0, [m](uint16_t v) {
+                     const float d = rh(__fsub_rn(h2f(v), m));
+                     return rh(__fmul_rn(d, d));
+                 })));
+    const float var = h2f(d2h((double)res / (double)rows));
+    out[c] = f2h((float)sqrt((double)var));
 }
 
 struct DevBuf {  // a device allocation freed on every way out
@@ -313,10 +343,11 @@ extern "C" int skr_host_colstat_colmajor(skr_ctx* ctx, const void* x, int64_t ro
     SKR_TRY(check_any(ctx, x, rows, cols, np_type));
     SKR_REQUIRE(out || cols == 0, "out is NULL");
     SKR_REQUIRE(what == 0 || what == 1, "what must be 0 (mean) or 1 (std)");
-    SKR_REQUIRE(np_type == NP_F32 || np_type == NP_F64, "column-major statistics exist for float32 and float64");
+    SKR_REQUIRE(np_type == NP_F16 || np_type == NP_F32 || np_type == NP_F64,
+                "column-major statistics exist for float16, float32 and float64 (integers: as float64)");
     if (cols == 0) return SKR_OK;
     SKR_TRY(skr_activate(ctx));
-    const size_t elem = np_type == NP_F32 ? 4 : 8;
+    const size_t elem = (size_t)np_size(np_type);
     const size_t bytes = (size_t)rows * (size_t)cols * elem;
     DevBuf dx, dout;
     SKR_TRY(dx.alloc(bytes));
@@ -325,7 +356,9 @@ extern "C" int skr_host_colstat_colmajor(skr_ctx* ctx, const void* x, int64_t ro
     {
         SkrProfScope prof(ctx, "colstat_pairwise");
         const dim3 grid((unsigned)((cols + 63) / 64));
-        if (np_type == NP_F32)
+        if (np_type == NP_F16)
+            hipLaunchKernelGGL(colstat_pairwise_f16_kernel, grid, dim3(64), 0, ctx->stream, (const uint16_t*)dx.p, rows, cols, what, (uint16_t*)dout.p);
+        else if (np_type == NP_F32)
             hipLaunchKernelGGL(colstat_pairwise_kernel<float>, grid, dim3(64), 0, ctx->stream, (const float*)dx.p, rows, cols, what, (float*)dout.p);
         else
             hipLaunchKernelGGL(colstat_pairwise_kernel<double>, grid, dim3(64), 0, ctx->stream, (const double*)dx.p, rows, cols, what, (double*)dout.p);

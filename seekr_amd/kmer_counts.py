@@ -259,8 +259,8 @@ class BasicCounter:
         ctx = self._ctx()
         work = np.ascontiguousarray(counts)
         if getattr(self, attr) is True:  # (:168,174: the attribute is replaced first)
-            if counts.dtype == np.float64 and _lib.column_major_like(counts):
-                setattr(self, attr, _lib.host_colstat_colmajor(ctx, counts, what))  # numpy adds such columns pairwise
+            if _lib.column_major_like(counts):
+                setattr(self, attr, _lib.host_colstat_colmajor(ctx, counts, what))  # numpy adds such columns pairwise, whatever the dtype
             else:
                 setattr(self, attr, _lib.host_colstat(ctx, work, what))
         operand = getattr(self, attr)

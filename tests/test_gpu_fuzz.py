@@ -71,6 +71,40 @@ def test_column_major_matrices_get_numpys_pairwise_column_sums(dtype, rows):
         assert not np.array_equal(seq / np.float32(n), m)
 
 
+@pytest.mark.parametrize("dtype", ["float16", "int32", "uint8", "bool"])
+def test_column_major_half_and_integer_matrices_follow_numpys_pieces_too(dtype):
+    """The same layout in the other dtypes, past the 8 192-element buffer piece: float16 columns are added pairwise in float32
+    accumulators and rounded to half once per piece (numpy's HALF_add), integer and bool columns as the float64 values numpy
+    casts them to piece by piece; np.mean / np.std bit for bit, and for integers the reference's UFuncTypeError with the
+    attribute already replaced (kmer_counts.py:168-169, 174-175)."""
+    import numpy as np
+    from seekr_amd.kmer_counts import BasicCounter
+    rng = np.random.default_rng(7)
+    n, cols = 30_011, 6
+    raw = rng.poisson(0.4, size=(n, cols))
+    base = np.asfortranarray((raw * 0.5).astype(dtype) if dtype == "float16" else raw.astype(dtype))
+    mine, ref = base.copy(order="F"), base.copy(order="F")
+    c = BasicCounter(k=1, silent=True)
+    c.counts = mine
+    with np.errstate(all="ignore"):
+        m, s = np.mean(ref, axis=0), None
+        if dtype == "float16":
+            c.center()
+            ref -= m
+            assert c.mean.dtype == m.dtype and c.mean.tobytes() == m.tobytes() and mine.tobytes("A") == ref.tobytes("A")
+            c.standardize()
+            s = np.std(ref, axis=0)
+            ref /= s
+            assert c.std.tobytes() == s.tobytes() and np.array_equal(mine, ref, equal_nan=True)
+        else:
+            with pytest.raises(TypeError, match="Cannot cast ufunc"):
+                c.center()
+            assert c.mean.dtype == m.dtype and c.mean.tobytes() == m.tobytes() and np.array_equal(mine, base)
+            with pytest.raises(TypeError, match="Cannot cast ufunc"):
+                c.standardize()
+            s = np.std(ref, axis=0)
+            assert c.std.dtype == s.dtype and c.std.tobytes() == s.tobytes()
+
 def test_regression_rows_that_are_mostly_one_repeated_value(golden_dir):
     """Found by the fuzzer after 21 000 cases: with a 7-letter alphabet 90 % of the 4-mer columns are structurally
     zero, every zero column gets the same (hi, lo) pair under round-to-nearest, and the coherent hi*lo products
