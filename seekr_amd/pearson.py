@@ -13,7 +13,9 @@ float32 inputs run on the matrix cores in the arithmetic named by `SEEKR_PRECISI
 (tools/adversarial.py prints the errors of the three on worst-case inputs; bf16x3 is kept as the CONTROL arm of that
 choice — the accuracy tables of DESIGN section 2 are measured against it — not as a recommendation; bf16x4 was retired in round 5; the bf16 choices use
 the fp32 kernel below 1024 columns, f16x3 below 64).  Anything else (float64, integers, DataFrames read from
-CSV) is promoted to float64 like numpy does and runs on the f64 MFMA.
+CSV) is promoted to float64 like numpy does and runs on the f64 MFMA.  A float16 matrix — the reference would standardise
+and multiply it in half precision (1e-3 noise) — is evaluated in float64 and the result ROUNDED to the dtype the reference
+returns (float16 with float16: float16; with float32: float32): the reference's dtype, better than its bits.
 """
 import os
 
@@ -39,6 +41,13 @@ def _precision_for(dtype, row_standardize=True):
     if name in ("f16x3", "f16f8") and not row_standardize:
         name = "fp32"  # arbitrary magnitudes: outside fp16's range / inside its subnormals
     return _lib.PRECISIONS[name]
+
+
+def _result_dtype(c1, c2):
+    """What np.inner of the two row-standardised operands has in the reference: every float dtype keeps itself through
+    np.mean / np.std, integers and bool become float64."""
+    kinds = [c.dtype if c.dtype.kind == "f" else np.dtype(np.float64) for c in (c1, c2)]
+    return np.result_type(*kinds)
 
 
 def _operands(counts1, counts2):
@@ -85,6 +94,8 @@ def pearson(counts1, counts2, row_standardize=True, outfile=None):
     devices = multi.requested_devices()
     if devices or multi.forced_stripe_rows() or not _fits_one_block(_lib.default_context(), c1, c2, same, w1, w2):
         dist = _striped(c1, c2, w1, w2, same, row_standardize, devices)
+        if dist.dtype != _result_dtype(c1, c2):
+            dist = dist.astype(_result_dtype(c1, c2))
         if outfile:
             _lib.save_npy(outfile, dist)
         return dist
@@ -104,6 +115,8 @@ def pearson(counts1, counts2, row_standardize=True, outfile=None):
             d2 = ctx.from_numpy(d2.to_numpy().astype(np.float64))
         r = _lib.pearson(ctx, d1, d2, row_standardize=False, precision=_lib.PREC_F64)
     dist = r.to_numpy()
+    if dist.dtype != _result_dtype(c1, c2):  # a float16 operand (module docstring)
+        dist = dist.astype(_result_dtype(c1, c2))
     if outfile:
         _lib.save_npy(outfile, dist)
     return dist
@@ -115,4 +128,7 @@ def pearson_to_file(counts1, counts2, outfile, row_standardize=True):
     console_scripts.py:632-633): r goes from the GPU(s) to its place in the .npy file stripe by stripe and is never held in
     host memory — neither once nor, as np.save of a returned array would, twice."""
     c1, c2, w1, w2, same = _operands(counts1, counts2)
+    if _result_dtype(c1, c2).itemsize < (4 if (w1 == np.float32 and w2 == np.float32) else 8):  # a float16 operand: through the host
+        pearson(counts1, counts2, row_standardize=row_standardize, outfile=outfile)
+        return
     _striped(c1, c2, w1, w2, same, row_standardize, multi.requested_devices(), outfile_only=outfile)

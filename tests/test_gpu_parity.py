@@ -243,6 +243,27 @@ def test_g3_skewed_sets_counts_and_pearson(gold):
     assert rm.dtype == np.float64 and np.allclose(rm, g3["pearson_mixed"], rtol=RTOL, atol=ATOL_R)
 
 
+def test_pearson_returns_the_references_dtype_for_every_operand_pair(tmp_path):
+    """pearson.py:35-41 lets numpy promote: a float dtype survives np.mean / np.std, integers become float64, np.inner takes
+    the wider of the two.  The dtype of r for every pair — float16 included, where the value is the float64 result rounded to
+    the reference's dtype (the reference's own half-precision arithmetic is 1e-3 away from the truth; held to that)."""
+    from seekr_amd.pearson import pearson, pearson_to_file
+    rng = np.random.default_rng(3)
+    a, b = rng.poisson(2.0, size=(9, 64)), rng.poisson(2.0, size=(7, 64))
+    for d1, d2 in (("float16", "float16"), ("float16", "float32"), ("float32", "float16"), ("float16", "float64"), ("int32", "float32"),
+                   ("float16", "int32"), ("uint8", "uint8"), ("float32", "float32"), ("float64", "float32"), ("bool", "float16")):
+        x, y = (a > 1 if d1 == "bool" else a).astype(d1), b.astype(d2)
+        with np.errstate(all="ignore"):
+            want = orc.pearson(x, y)
+        got = pearson(x, y)
+        assert got.dtype == want.dtype and got.shape == want.shape, (d1, d2, got.dtype, want.dtype)
+        tol = 2e-2 if "float16" in (d1, d2) else 1e-5
+        assert np.allclose(got.astype(np.float64), want.astype(np.float64), rtol=tol, atol=tol), (d1, d2)
+    out = str(tmp_path / "r16.npy")
+    pearson_to_file(a.astype("float16"), b.astype("float16"), out)
+    assert np.load(out).dtype == np.float16 and np.array_equal(np.load(out), pearson(a.astype("float16"), b.astype("float16")))
+
+
 def test_g4_synthetic_2000x2kb(gold, L, ctx):
     from seekr_amd.pearson import pearson
     g4, meta = gold["g4_synth2000"], gold["meta"]
