@@ -252,3 +252,18 @@ def test_committed_round6_summaries_belong_to_the_library_built_from_this_tree()
         assert why is None and got["bytes"] > 0 and got["source"].startswith("profiles/r6_"), (rows, k, prec, why)
         count, why = bench.pmc_traffic("count_rows_kernel<0", bench.workload_key(rows, length, k, prec, 1), lib_path)
         assert why is None and count["write_bytes"] > 0, (rows, k, prec, why)
+
+
+def test_pearson_result_dtype_rule_is_numpys_promotion_of_the_reference():
+    """pearson.py:35-41: every float dtype survives np.mean / np.std, integers and bool become float64, np.inner takes the
+    wider — `seekr_amd.pearson._result_dtype` against the oracle's numpy statement, no device involved."""
+    from seekr_amd.pearson import _result_dtype
+    sys.path.insert(0, ROOT)
+    from oracle import seekr_oracle as orc
+    a = np.arange(12).reshape(3, 4) % 5
+    names = ["float16", "float32", "float64", "int8", "int32", "int64", "uint8", "uint64", "bool"]
+    for d1 in names:
+        for d2 in names:
+            x, y = a.astype(d1), a[:2].astype(d2)
+            with np.errstate(all="ignore"):
+                assert _result_dtype(x, y) == orc.pearson(x, y).dtype, (d1, d2)
