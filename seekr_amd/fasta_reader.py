@@ -39,10 +39,18 @@ class Reader:
         self.infasta, self.outfasta, self.names = infasta, outfasta, names
         self.data = None
 
-    def _load(self):
+    def _read_data(self):
+        """`data` = the file's lines, stripped (fasta_reader.py:41-45; text mode: the locale's decoding, as there)."""
         with open(self.infasta) as fh:
-            stripped = [raw.strip() for raw in fh]
-        self.data = records(stripped)
+            self.data = [raw.strip() for raw in fh]
+
+    def _upper_seq_per_line(self):
+        """`data` = one header entry, one upper-cased sequence entry, ... (fasta_reader.py:47-63)."""
+        self.data = records(self.data)
+
+    def _load(self):
+        self._read_data()
+        self._upper_seq_per_line()
         return self.data[0::2], self.data[1::2]
 
     def get_lines(self):

@@ -24,3 +24,21 @@ def my_tqdm():
         def bar(iterable=None, **_kw):
             return iterable
         return bar
+
+
+_is_kernel = _in_notebook  # the reference's name for the same question (my_tqdm.py:17-25)
+
+
+def my_trange():
+    """The range-shaped twin (my_tqdm.py:32-33): `tnrange` inside a Jupyter kernel, `trange` otherwise, plain `range`
+    when tqdm is not installed."""
+    try:
+        if _in_notebook():
+            from tqdm import tnrange as rng
+        else:
+            from tqdm import trange as rng
+        return rng
+    except ImportError:
+        def rng(*args, **_kw):
+            return range(*args)
+        return rng
