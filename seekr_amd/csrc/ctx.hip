@@ -90,6 +90,17 @@ extern "C" int skr_ctx_create(int device, skr_ctx** out) {
     if (n <= 0) return skr_set_error(SKR_ERR_HIP, "no HIP device visible");
     SKR_REQUIRE(device >= 0 && device < n, "device %d out of range (0..%d)", device, n - 1);
     SKR_HIP(hipSetDevice(device));
+    {
+        // How the host waits for the GPU (every flag read of a step is such a wait): SEEKR_HOST_WAIT=spin|yield|block asks
+        // the runtime for that policy on this device; unset = the runtime's own choice.  An A/B knob (profiles/r6_host_wait.log).
+        const char* w = getenv("SEEKR_HOST_WAIT");
+        if (w && *w) {
+            const unsigned f = !strcmp(w, "spin") ? hipDeviceScheduleSpin : !strcmp(w, "yield") ? hipDeviceScheduleYield
+                             : !strcmp(w, "block") ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto;
+            (void)hipSetDeviceFlags(f);
+            (void)hipGetLastError();
+        }
+    }
     hipDeviceProp_t prop;
     SKR_HIP(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
