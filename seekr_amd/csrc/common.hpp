@@ -21,6 +21,7 @@ struct SkrKnobs {
     int gemm_subtile = 4;        // SEEKR_GEMM_SUBTILE: order in which an XCD's CUs take the tiles of a super-tile (pearson_bf16.hip: tile_of_block)
     int gemm_epilogue = 3;       // SEEKR_GEMM_EPILOGUE: 0 = every tile through the general epilogue loop; 1 / 2 / 3 = the lean epilogue with 64- / 128- / 256-byte row runs (pearson_bf16.hip, round 6; 3 measured best)
     int gemm_wave_tile = 0;      // SEEKR_GEMM_WAVE_TILE=1: the 4-wave 128 x 128 wave-tile arm (libseekr_hip_diag.so only; tools/gemm_bench.py --diag-lib)
+    int host_wait = 0;           // SEEKR_HOST_WAIT=spin|yield|block (1|2|3): hipSetDeviceFlags when the ctx is created; 0 = the runtime's own policy
     int count_percu = 0;         // SEEKR_COUNT_PERCU: cap on resident workgroups per CU (0 = none)
     int count_persist = 0;       // SEEKR_COUNT_PERSIST=1: persistent grid at k <= 6; 2: one workgroup per sequence at k = 7 too
     bool count_legacy = false;   // SEEKR_COUNT_LEGACY=1: the round-1 counting kernel

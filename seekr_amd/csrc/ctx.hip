@@ -60,9 +60,14 @@ extern "C" int skr_ctx_reload_knobs(skr_ctx* c) {
     SKR_REQUIRE(c, "ctx is NULL");
     auto env_int = [](const char* name, int dflt) {
         const char* v = getenv(name);
-        return v && *v ? atoi(v) : dflt;
+        if (!v || !*v) return dflt;
+        if (!strcmp(v, "spin")) return 1;  // SEEKR_HOST_WAIT's words
+        if (!strcmp(v, "yield")) return 2;
+        if (!strcmp(v, "block")) return 3;
+        return atoi(v);
     };
     SkrKnobs& kn = c->knobs;
+    kn.host_wait = env_int("SEEKR_HOST_WAIT", 0);
     kn.gemm_persist = env_int("SEEKR_GEMM_PERSIST", 1) != 0;
     kn.gemm_chunk_tiles = std::max(0, env_int("SEEKR_GEMM_CHUNK_TILES", 0));
     kn.gemm_reserve_cus = env_int("SEEKR_GEMM_RESERVE_CUS", -1);
@@ -90,17 +95,6 @@ extern "C" int skr_ctx_create(int device, skr_ctx** out) {
     if (n <= 0) return skr_set_error(SKR_ERR_HIP, "no HIP device visible");
     SKR_REQUIRE(device >= 0 && device < n, "device %d out of range (0..%d)", device, n - 1);
     SKR_HIP(hipSetDevice(device));
-    {
-        // How the host waits for the GPU (every flag read of a step is such a wait): SEEKR_HOST_WAIT=spin|yield|block asks
-        // the runtime for that policy on this device; unset = the runtime's own choice.  An A/B knob (profiles/r6_host_wait.log).
-        const char* w = getenv("SEEKR_HOST_WAIT");
-        if (w && *w) {
-            const unsigned f = !strcmp(w, "spin") ? hipDeviceScheduleSpin : !strcmp(w, "yield") ? hipDeviceScheduleYield
-                             : !strcmp(w, "block") ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto;
-            (void)hipSetDeviceFlags(f);
-            (void)hipGetLastError();
-        }
-    }
     hipDeviceProp_t prop;
     SKR_HIP(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -110,6 +104,12 @@ extern "C" int skr_ctx_create(int device, skr_ctx** out) {
     c->device = device;
     c->num_cu = prop.multiProcessorCount;
     skr_ctx_reload_knobs(c);
+    if (c->knobs.host_wait >= 1 && c->knobs.host_wait <= 3) {
+        // How the host waits for the GPU (every flag read of a step is such a wait): an A/B knob, profiles/r6_host_wait.log
+        const unsigned f[4] = {hipDeviceScheduleAuto, hipDeviceScheduleSpin, hipDeviceScheduleYield, hipDeviceScheduleBlockingSync};
+        (void)hipSetDeviceFlags(f[c->knobs.host_wait]);
+        (void)hipGetLastError();
+    }
     SKR_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     SKR_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
     SKR_HIP(hipMalloc((void**)&c->d_flags, 64 * sizeof(uint32_t)));
