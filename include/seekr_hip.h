@@ -78,7 +78,7 @@ int skr_device_count(int* count);
 /* Page-lock / release a host range the caller owns (hipHostRegister / hipHostUnregister): copies to and from a registered
  * range are plain DMA at the link's rate.  The package registers the result arrays it keeps between calls.  `device`: the
  * GPU the calling thread is switched to first (the runtime registers on the thread's current device; the range is
- * portable to every GPU either way), -1 = leave the thread's device alone.                                               */
+ * portable to every GPU either way; the thread's own device is restored before returning), -1 = leave it alone.         */
 int skr_host_register(int device, void* ptr, size_t bytes);
 int skr_host_unregister(void* ptr);
 int skr_ctx_create(int device, skr_ctx** out);

@@ -36,7 +36,18 @@ extern "C" int skr_host_register(int device, void* ptr, size_t bytes) {
     SKR_REQUIRE(ptr && bytes, "empty range");
     // the runtime registers "on the current device" of the calling thread, and a thread that has never chosen one (a
     // finaliser running on a collector's thread) would bring up device 0's context in every rank process of a node
-    if (device >= 0) SKR_HIP(hipSetDevice(device));
+    // ... and the thread gets its own device back afterwards: a worker of another GPU may be the one that runs the finaliser
+    int before = -1;
+    if (device >= 0) {
+        (void)hipGetDevice(&before);
+        SKR_HIP(hipSetDevice(device));
+    }
+    struct Back {
+        int dev;
+        ~Back() {
+            if (dev >= 0) (void)hipSetDevice(dev);
+        }
+    } back{before == device ? -1 : before};
     SKR_HIP(hipHostRegister(ptr, bytes, hipHostRegisterPortable));  // every GPU of the node copies at the pinned rate
     return SKR_OK;
 }
