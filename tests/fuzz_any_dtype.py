@@ -51,6 +51,8 @@ def fuzz(seed, budget_s=30.0, max_cases=10 ** 9):
     while time.time() - t0 < budget_s and n < max_cases:
         dtype = np.dtype(DTYPES[int(rng.integers(0, len(DTYPES)))])
         rows, cols = int(rng.choice([1, 2, 3, 7, 64, 300, 1025])), int(rng.choice([1, 3, 5, 16, 33, 256, 300]))
+        if rng.integers(0, 60) == 0:  # past numpy's 8 192-element buffer piece (column-major layouts add in such pieces)
+            rows, cols = int(rng.choice([8193, 9000, 16400])), int(rng.choice([1, 2, 5]))
         raw = rng.poisson(1.1, size=(rows * 2, cols * 2))
         if rng.integers(0, 4) == 0:
             raw[:, rng.integers(0, cols * 2)] = 0
@@ -88,15 +90,9 @@ def fuzz(seed, budget_s=30.0, max_cases=10 ** 9):
         # numpy adds the ROWS one after the other when axis 1 is the faster one (any C-like layout: what get_counts() makes);
         # a column-major matrix — or a single column — it reduces column by column in its PAIRWISE order, in 8 192-element
         # pieces: both reproduced on the device for every dtype (skr_host_colstat / skr_host_colstat_colmajor), bit for bit.
-        loose = False
-        tol = 0.0
 
         def same(a, b):
-            if not loose:
-                return np.ascontiguousarray(a).tobytes() == np.ascontiguousarray(b).tobytes()
-            a64, b64 = np.asarray(a, np.float64), np.asarray(b, np.float64)
-            with np.errstate(all="ignore"):
-                return bool(((a64 == b64) | (np.isnan(a64) & np.isnan(b64)) | (np.abs(a64 - b64) <= tol * (1 + np.abs(b64)))).all())
+            return np.ascontiguousarray(a).tobytes() == np.ascontiguousarray(b).tobytes()
         assert type(got_exc) is type(want_exc) and str(got_exc) == str(want_exc), (tag, repr(got_exc), repr(want_exc))
         # the attribute the reference replaces BEFORE the in-place operation (also when that then raises)
         for attr, w in (("mean", wmean if want_exc is None else None), ("std", wstd if want_exc is None else None)):
@@ -119,8 +115,7 @@ def fuzz(seed, budget_s=30.0, max_cases=10 ** 9):
                 assert same(got, want), (tag, got.ravel()[:4], want.ravel()[:4])
             # what the operation left in the caller's own memory (the `+= 1` of log2_norm included), gaps untouched
             assert same(mine_base, ref_base), tag
-            if not loose:  # (a column whose std is 0 in one summation order and 1e-17 in the other: NaN here, inf there)
-                assert ("WARNING: You have `np.nan` values" in out.getvalue()) == (method == "standardize" and bool(np.isnan(want.astype(np.float64)).any())), tag
+            assert ("WARNING: You have `np.nan` values" in out.getvalue()) == (method == "standardize" and bool(np.isnan(want.astype(np.float64)).any())), tag
         n += 1
     return n
 
