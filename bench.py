@@ -794,6 +794,17 @@ def run_rank(args):
                         "delivers (multiplied_*), and the split path issues {} 16-bit MFMA products per multiplication "
                         "(mfma_executed_* = what the matrix cores really run, against the same dense peak)".format(
                             exec_pairs, delivered_pairs, nprod)}
+    # Which roof bounds this kernel at this width: at k <= 4 the float32 r it writes (4 B per pair) takes longer at 8 TB/s
+    # than 2*4^k flop per pair take on the matrix cores — the contraction is then an HBM-bound kernel and is priced as one
+    alg_bytes = 2.0 * n_loc * n_cols * 4 + 4.0 * n_loc * n_total
+    alg_flop = 2.0 * n_cols * delivered_pairs
+    if alg_bytes / (PEAK["hbm_gbs"] * 1e9) > alg_flop / (peak_tf * 1e12) and gemm_ms_step > 0:
+        gbs = alg_bytes / (gemm_ms_step * 1e-3) / 1e9
+        roofline.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK["hbm_gbs"], "unit": "GB/s",
+                         "frac": round(gbs / PEAK["hbm_gbs"], 4),
+                         "mfma_view": {"achieved_tflops": round(achieved_tf, 2), "peak_tflops": peak_tf, "frac": round(achieved_tf / peak_tf, 4)},
+                         "bound_note": "output bound at this width: {:.2f} ms of r and operands at 8 TB/s against {:.2f} ms of "
+                                       "matrix work at the dense peak".format(alg_bytes / (PEAK["hbm_gbs"] * 1e9) * 1e3, alg_flop / (peak_tf * 1e12) * 1e3)})
     # counting kernel: HBM bound, 0.25 B/base packed in (1 B/base ASCII for the any-alphabet kernel: SURVEY 8d) + 4 A^k B per
     # sequence out
     count_avg_ms = count["ms_total"] / max(count["launches"], 1)

@@ -44,3 +44,16 @@ def test_bench_line_carries_the_measurement_contract():
     arm = d["f16f8_arm"]
     assert arm["operand_kind"] == 3 and arm["verified"] is True and arm["worst_error_over_bar"] <= 1.0 and arm["value"] > 0
     assert "never part of `value`" in arm["note"] and d["config"]["precision"] == "f16x3"
+
+
+def test_bench_line_prices_an_output_bound_contraction_against_hbm():
+    """At k = 4 (256 columns) writing r (4 B per pair) takes longer at 8 TB/s than 512 flop per pair take at the dense
+    matrix-core peak: `roofline.bound` says "hbm", achieved / peak are GB/s, the matrix-core view is kept next to it."""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--k", "4", "--rows", "6000", "--length", "600", "--steps", "2",
+                          "--warmup", "1", "--no-cpu-baseline", "--no-target-200k", "--no-f16f8-arm"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["mfma_view"]["peak_tflops"] == 2500.0 and 0 < rf["mfma_view"]["frac"] < rf["frac"] and d["verified"] is True

@@ -7,6 +7,7 @@ python bench.py --rows 200000 --steps 3 --warmup 1 > gpurun_out/r6/bench_200k_ro
 python bench.py --precision f16f8 --steps 20 --warmup 5 > gpurun_out/r6/bench_f16f8.json 2>/dev/null
 python bench.py --alphabet ACGTN --steps 3 --warmup 1 > gpurun_out/r6/bench_acgtn_k6.json 2>/dev/null
 python bench.py -k 8 --rows 20000 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/r6/bench_k8_20k.json 2>/dev/null
+for k in 3 4 5; do python bench.py --k $k --steps 20 --warmup 5 --no-target-200k --no-f16f8-arm > gpurun_out/r6/bench_k$k.json 2>/dev/null; done  # k = 3, 4: output bound, priced against HBM
 python - <<'PY'
 import json
 for f in ("bench_default","bench_k7_5kb","bench_200k_rows_1gpu","bench_f16f8","bench_acgtn_k6","bench_k8_20k"):
