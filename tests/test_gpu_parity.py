@@ -1674,6 +1674,15 @@ def test_g11_normalisation_methods_on_matrices_that_are_not_float32(golden_dir):
     assert g11_cases.check_all(golden_dir, g11_cases.run_counter(BasicCounter)) == 9 * 2 * 16
 
 
+def test_g12_column_major_matrices_through_the_device(golden_dir):
+    """Golden set G12 through seekr_amd.BasicCounter: column-major, strided column-major and single-column matrices of
+    float32 / float64 / float16 / int32 / uint8 — mean, std, the centred-then-standardised matrix, dtypes, in-place-ness and
+    numpy's exception, byte for byte what the reference left (skr_host_colstat_colmajor + the tuned float32 path)."""
+    import g12_cases
+    from seekr_amd.kmer_counts import BasicCounter
+    assert g12_cases.check_all(golden_dir, BasicCounter) == 5 * 2 * 3
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float16", "int32"])
 def test_normalisation_on_other_dtypes_is_in_place_like_the_reference(dtype):
     """`counts -= mean` / `counts /= std` are in-place operations in the reference (kmer_counts.py:169,175): the caller's

@@ -406,6 +406,15 @@ def test_g11_normalisation_methods_on_matrices_that_are_not_float32(golden_dir):
     assert g11_cases.check_all(golden_dir, g11_cases.run_oracle(orc)) == 9 * 2 * 16
 
 
+def test_g12_column_major_matrices_as_the_reference_leaves_them(golden_dir):
+    """kmer_counts.py:165-175 on column-major / strided column-major / single-column matrices of five dtypes (300 x 7 and
+    9 001 x 3: past numpy's 8 192-element buffer piece): the oracle's restatement of numpy's column-by-column pairwise order
+    leaves the reference's bytes for mean, std and the centred-then-standardised matrix, its dtypes, and numpy's exception
+    (with the attribute already replaced) for integer matrices."""
+    import g12_cases
+    assert g12_cases.check_all(golden_dir, g12_cases.oracle_counter(orc)) == 5 * 2 * 3
+
+
 def test_oracle_column_statistics_follow_numpys_order_for_every_layout():
     """np.mean / np.std(axis=0) of kmer_counts.py:168,174 depend on the matrix's LAYOUT: row after row for C order, every
     column pairwise in 8 192-element pieces for column-major matrices and single columns (float16: float32 accumulators
