@@ -7,7 +7,7 @@ the native parser's headers and lengths are the reference's, or it raises the re
 
     PYTHONDONTWRITEBYTECODE=1 python tools/fuzz_reader_vs_reference.py SEED N_FILES
 
-Round 6: 18 000 files over three seeds, no divergence — after it found that a header holding a NUL byte came back
+Round 6: 26 000 files over four seeds, no divergence — after it found that a header holding a NUL byte came back
 truncated through ctypes' `.value` (fixed: `.raw`)."""
 import os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
