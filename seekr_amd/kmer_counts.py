@@ -30,7 +30,33 @@ NAN_WARNING = (
 )
 
 
-def _as_device_vector(ctx, vec, n_cols):
+def _shape_text(shape):
+    return "(" + ",".join(str(d) for d in shape) + ("," if len(shape) == 1 else "") + ")"
+
+
+def _column_vector(arr, n_rows, n_cols):
+    """The user's mean / std as the K values `counts -= vec` subtracts from every row (kmer_counts.py:169,175), by numpy's
+    broadcasting rules: a scalar, (K,), (1,), (1, K) ... all spread over the rows; what numpy refuses is refused in numpy's
+    words (the shapes of the in-place operation: (N,K) vec (N,K)).  An operand that varies along the ROWS — (N, 1), (N, K):
+    legal numpy, no use of the reference's — is not supported on the device."""
+    if n_rows is None:
+        return np.ascontiguousarray(np.broadcast_to(arr, (n_cols,)))
+    shape = (int(n_rows), int(n_cols))
+    try:
+        together = np.broadcast_shapes(shape, arr.shape)
+    except ValueError:
+        raise ValueError("operands could not be broadcast together with shapes {} {} {} ".format(
+            _shape_text(shape), _shape_text(arr.shape), _shape_text(shape))) from None
+    if together != shape:
+        raise ValueError("non-broadcastable output operand with shape {} doesn't match the broadcast shape {}".format(
+            _shape_text(shape), _shape_text(together)))
+    if arr.ndim >= 2 and arr.shape[-2] != 1:
+        raise NotImplementedError("a mean / std operand of shape {} varies along the rows; the device path takes one value "
+                                  "per column (a vector of length {})".format(_shape_text(arr.shape), n_cols))
+    return np.ascontiguousarray(np.broadcast_to(arr, (1, shape[1]))[0])
+
+
+def _as_device_vector(ctx, vec, n_cols, n_rows=None):
     """User mean/std vector -> 1 x K device vector; float32 stays float32, everything else is
     evaluated in float64 and rounded once, like numpy's in-place `counts -= vec`."""
     if isinstance(vec, (bool, int, float)):
@@ -41,8 +67,7 @@ def _as_device_vector(ctx, vec, n_cols):
         arr = arr.astype(np.float32, copy=False)
     else:
         arr = arr.astype(np.float64)
-    arr = np.ascontiguousarray(np.broadcast_to(arr, (n_cols,)))
-    return ctx.from_numpy(arr)
+    return ctx.from_numpy(_column_vector(arr, n_rows, n_cols))
 
 
 class BasicCounter:
@@ -229,7 +254,15 @@ class BasicCounter:
         raises — UFuncTypeError for float statistics into an integer matrix (`counts -= mean`, kmer_counts.py:169,175),
         ValueError for a vector of the wrong length — is raised here as numpy words it."""
         probe = counts[:0]
-        ufunc(probe, operand, out=probe)
+        try:
+            ufunc(probe, operand, out=probe)
+        except ValueError as e:  # broadcasting: numpy names the shapes — of the real matrix, not of the probe
+            zero, real = _shape_text(probe.shape), _shape_text(counts.shape)
+            text = str(e).replace(zero, real)
+            if text.startswith("non-broadcastable output operand"):  # ... and the broadcast shape it did not fit
+                together = np.broadcast_shapes(counts.shape, np.shape(operand))
+                text = "non-broadcastable output operand with shape {} doesn't match the broadcast shape {}".format(real, _shape_text(together))
+            raise ValueError(text) from None
 
     @staticmethod
     def _vector_for(counts, operand):
@@ -241,10 +274,11 @@ class BasicCounter:
             vec = np.asarray(operand, dtype=counts.dtype)
         else:
             vec = np.asarray(operand)
+        column = _column_vector(vec, counts.shape[0], cols)  # (K,), (1, K), a scalar ...: one value per column
         if counts.dtype.kind != "f":
-            return np.ascontiguousarray(np.broadcast_to(vec, (cols,))).astype(np.int64)  # legal integer case only (see _replay)
+            return column.astype(np.int64)  # legal integer case only (see _replay)
         wide = counts.dtype == np.float64 or np.result_type(counts.dtype, vec.dtype).itemsize > 4
-        return np.ascontiguousarray(np.broadcast_to(vec, (cols,))).astype(np.float64 if wide else np.float32)
+        return column.astype(np.float64 if wide else np.float32)
 
     def _finish_host(self, counts, work):
         """`work` (C-contiguous, holding the result) back where the reference's in-place operation leaves it."""
@@ -298,7 +332,7 @@ class BasicCounter:
             self.mean = acc.vector()
             mean_dev = acc
         else:
-            mean_dev = _as_device_vector(ctx, self.mean, dev.cols)
+            mean_dev = _as_device_vector(ctx, self.mean, dev.cols, dev.rows)
         _lib.apply(ctx, dev, center=mean_dev)
         self._store(dev)
 
@@ -324,7 +358,7 @@ class BasicCounter:
             self.std = var.vector()
             std_dev = var
         else:
-            std_dev = _as_device_vector(ctx, self.std, dev.cols)
+            std_dev = _as_device_vector(ctx, self.std, dev.cols, dev.rows)
         _, has_nan = _lib.apply(ctx, dev, scale=std_dev, want_nan=True)
         self._store(dev)
         if has_nan:
@@ -396,12 +430,12 @@ class BasicCounter:
         if self.mean is True:
             mean_mode = 1
         elif self.mean is not False:
-            mean_mode, mean_vec = 2, _as_device_vector(ctx, self.mean, dev.cols)
+            mean_mode, mean_vec = 2, _as_device_vector(ctx, self.mean, dev.cols, dev.rows)
         std_mode, std_vec = 0, None
         if self.std is True:
             std_mode = 1
         elif self.std is not False:
-            std_mode, std_vec = 2, _as_device_vector(ctx, self.std, dev.cols)
+            std_mode, std_vec = 2, _as_device_vector(ctx, self.std, dev.cols, dev.rows)
         # Log2.pre was fused into the counting flush, so the normaliser sees 'none' for it
         log2 = "Log2.post" if self.log2 == "Log2.post" else "Log2.none"
         mean_out, std_out, has_nan = _lib.normalize(ctx, dev, log2, mean_mode, mean_vec, std_mode, std_vec)

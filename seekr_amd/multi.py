@@ -458,9 +458,9 @@ class ApiHipEngine(HipEngine):
         packed.free()
         return x
 
-    def user_vector(self, vec, n_cols):
+    def user_vector(self, vec, n_cols, n_rows=None):
         from seekr_amd.kmer_counts import _as_device_vector
-        return _as_device_vector(self.ctx, vec, n_cols)
+        return _as_device_vector(self.ctx, vec, n_cols, n_rows)
 
     def vec_to_host(self, v):
         return v.vector()
@@ -569,8 +569,8 @@ def counts_job(st, spec):
     n_total = spec.bounds[-1]
     x = st.phase(lambda: eng.count(spec.source, lo, hi, spec.k, spec.log2 == "Log2.pre", spec.alphabet, spec.two_bit))
     n_cols = eng.cols(x)
-    mean = spec.mean if isinstance(spec.mean, bool) else eng.user_vector(spec.mean, n_cols)
-    std = spec.std if isinstance(spec.std, bool) else eng.user_vector(spec.std, n_cols)
+    mean = spec.mean if isinstance(spec.mean, bool) else eng.user_vector(spec.mean, n_cols, int(spec.bounds[-1]))
+    std = spec.std if isinstance(spec.std, bool) else eng.user_vector(spec.std, n_cols, int(spec.bounds[-1]))
     # Log2.pre went into the counting flush: the normaliser only has the post step left to do
     log2 = "Log2.post" if spec.log2 == "Log2.post" else "Log2.none"
     center, scale, has_nan = sharded_normalize(eng, st.comm, x, n_total, log2, mean, std)

@@ -42,7 +42,17 @@ def random_vector(rng, cols):
     if kind == 2:
         return int(rng.integers(1, 4))
     dt = ["float32", "float64", "float16", "int64", "int16", "uint8"][int(rng.integers(0, 6))]
-    return (base * (3 if "int" in dt else 1)).astype(dt) if "int" not in dt else rng.integers(1, 5, cols).astype(dt)
+    vec = (base * (3 if "int" in dt else 1)).astype(dt) if "int" not in dt else rng.integers(1, 5, cols).astype(dt)
+    shape = rng.integers(0, 12)  # numpy's broadcasting: a row vector as a matrix is fine, other shapes get numpy's sentence
+    if shape == 0:
+        return vec.reshape(1, cols)
+    if shape == 1:
+        return np.concatenate([vec, vec[:1]])      # one value too many
+    if shape == 2:
+        return vec.reshape(1, 1, cols)              # broadcasts to 3-D: does not fit the output
+    if shape == 3:
+        return vec[:1]                              # one value for every column
+    return vec
 
 
 def fuzz(seed, budget_s=30.0, max_cases=10 ** 9):

@@ -1674,6 +1674,32 @@ def test_g11_normalisation_methods_on_matrices_that_are_not_float32(golden_dir):
     assert g11_cases.check_all(golden_dir, g11_cases.run_counter(BasicCounter)) == 9 * 2 * 16
 
 
+def test_get_counts_takes_a_user_vector_by_numpys_broadcasting_rules():
+    """kmer_counts.py:169,175 inside get_counts(): a (1, K) mean / std (np.load of a row saved as a matrix) is what numpy
+    spreads over the rows — the same counts as the (K,) vector; a vector of the wrong length is refused in numpy's sentence
+    with the matrix's real shape, after counting, as in the reference."""
+    from seekr_amd.kmer_counts import BasicCounter
+    example_seqs = skewed_set(9, 6, 40, 120)
+    rng = np.random.default_rng(4)
+    mean, std = rng.uniform(1, 50, 16).astype(np.float32), rng.uniform(5, 60, 16)
+
+    def run(m, s):
+        c = BasicCounter(k=2, mean=m, std=s, silent=True, log2="Log2.none")
+        c.seqs = example_seqs
+        c.get_counts()
+        return c.counts
+    flat = run(mean, std)
+    assert np.array_equal(bits(flat), bits(orc.get_counts(example_seqs, 2, mean, std, "Log2.none")[0]))
+    assert np.array_equal(bits(run(mean.reshape(1, 16), std.reshape(1, 16))), bits(flat))
+    n = len(example_seqs)
+    with pytest.raises(ValueError) as err:
+        run(mean[:5], False)
+    assert str(err.value) == "operands could not be broadcast together with shapes (%d,16) (5,) (%d,16) " % (n, n)
+    with pytest.raises(ValueError) as err:
+        run(False, std.reshape(1, 1, 16))
+    assert str(err.value) == "non-broadcastable output operand with shape (%d,16) doesn't match the broadcast shape (1,%d,16)" % (n, n)
+
+
 def test_g12_column_major_matrices_through_the_device(golden_dir):
     """Golden set G12 through seekr_amd.BasicCounter: column-major, strided column-major and single-column matrices of
     float32 / float64 / float16 / int32 / uint8 — mean, std, the centred-then-standardised matrix, dtypes, in-place-ness and

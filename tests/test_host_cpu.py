@@ -267,3 +267,32 @@ def test_pearson_result_dtype_rule_is_numpys_promotion_of_the_reference():
             x, y = a.astype(d1), a[:2].astype(d2)
             with np.errstate(all="ignore"):
                 assert _result_dtype(x, y) == orc.pearson(x, y).dtype, (d1, d2)
+
+
+def test_user_vectors_follow_numpys_broadcasting_and_its_words():
+    """`counts -= mean` / `counts /= std` (kmer_counts.py:169,175) with a user operand: every shape numpy spreads over the rows
+    becomes the K column values; what numpy refuses is refused with numpy's own sentence (shapes of the in-place operation);
+    an operand that varies along the rows is declined explicitly.  Host logic, no device."""
+    from seekr_amd.kmer_counts import _column_vector
+    n, k = 5, 16
+    base = np.zeros((n, k), np.float32)
+    for vec in (np.float64(0.5), np.arange(k, dtype=np.float64), np.ones(1), np.ones((1, k)), np.ones((1, 1)), np.ones(5), np.ones((2, k)),
+                np.ones((1, 5)), np.ones((1, 1, k)), np.ones((n, 1)), np.ones((n, k)), np.ones((0,))):
+        vec = np.asarray(vec)
+        try:
+            want = base.copy()
+            want -= vec
+            want_exc = None
+        except ValueError as e:
+            want_exc = str(e)
+        try:
+            got = _column_vector(vec, n, k)
+            got_exc = None
+        except ValueError as e:
+            got_exc = str(e)
+        except NotImplementedError:
+            assert want_exc is None and vec.ndim == 2 and vec.shape[0] == n  # legal numpy, varies along the rows
+            continue
+        assert got_exc == want_exc, (vec.shape, got_exc, want_exc)
+        if want_exc is None:
+            assert got.shape == (k,) and np.array_equal(base - got, want)

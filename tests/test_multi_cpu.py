@@ -59,7 +59,7 @@ class ApiNumpyEngine(NumpyEngine):
         x = orc.raw_counts(seqs, k, alphabet) if len(seqs) else np.zeros((0, len(alphabet) ** k), np.float32)
         return orc.log2_plus_one(x) if log2_pre else x
 
-    def user_vector(self, vec, n_cols):
+    def user_vector(self, vec, n_cols, n_rows=None):
         return np.broadcast_to(np.asarray(vec), (n_cols,))
 
     def upload(self, rows):
