@@ -160,6 +160,16 @@ def fuzz(seed, budget_s=60.0, max_cases=10 ** 9):
                 truth = orc.pearson_f64_truth(a, b, rs)
             got = pearson(a, b, row_standardize=rs)
             assert got.dtype == want.dtype and got.shape == want.shape, ("dtype/shape", tag, got.dtype, want.dtype)
+            if n_cases % 8 == 0 and a.size <= 1 << 20:
+                # the same VALUES in another memory layout (column-major: DataFrame.values of a CSV; a strided view): the
+                # result does not depend on how the caller's matrix lies in memory (a generator of its own: gen_case's stream is frozen)
+                lay = np.random.default_rng([seed, n_cases])
+                def relaid(x):
+                    return np.asfortranarray(x) if lay.integers(0, 2) else np.repeat(x, 2, axis=1)[:, ::2]
+                a2 = relaid(a)
+                b2 = a2 if b is a else relaid(b)
+                again = pearson(a2, b2, row_standardize=rs)
+                assert again.dtype == got.dtype and again.tobytes() == got.tobytes(), ("layout of the input changed r", tag)
             with np.errstate(all="ignore"):
                 g = np.where(np.isinf(got), np.nan, got).astype(np.float64)
                 w = np.where(np.isinf(want), np.nan, want).astype(np.float64)
