@@ -85,6 +85,17 @@ void pack_range(const SeqView* seqs, int64_t first, int64_t last, const Lut& lut
     }
 }
 
+// Host-side hooks (read where a file is opened or a set is packed, never on a launch path)
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+// Threads of the reader and the packer: SEEKR_HOST_THREADS (default 16), at most the cores there are
+int host_threads() {
+    const unsigned cap = (unsigned)std::max(1, env_int("SEEKR_HOST_THREADS", 16));
+    return (int)std::max(1u, std::min(cap, std::thread::hardware_concurrency()));
+}
+
 int upload_seqs(skr_ctx* ctx, const std::vector<SeqView>& all_seqs, const Lut& lut, std::string&& headers,
                 skr_seqs** out, int64_t first = 0, int64_t count = -1) {
     // sequences [first, first + count) of `all_seqs` (count < 0: all of them)
@@ -92,7 +103,7 @@ int upload_seqs(skr_ctx* ctx, const std::vector<SeqView>& all_seqs, const Lut& l
     const int64_t n = count < 0 ? (int64_t)all_seqs.size() - first : count;
     std::vector<int64_t> word_off(n + 1, 0), mask_off(n, -1), len(n, 0);
     int64_t total = 0, max_len = 0, mask_words = 0;
-    const int nthreads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const int nthreads = host_threads();
     // pass 1: which sequences hold a non-alphabet byte (parallel), then prefix sums (serial)
     std::vector<uint8_t> dirty(n, 0);
     {
@@ -289,9 +300,8 @@ extern "C" int skr_fasta_open(const char* path, skr_fasta** out) {
     // lines at the head of a piece continue the last sequence of the piece before, and the checks that
     // need the neighbouring lines (a header that follows a header) run on the stitched list.  The
     // error reported is the one the reference's sequential loop would have reached first.
-    const int want_threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    size_t piece_min = 1u << 20;  // bytes below which another thread is not worth starting
-    if (const char* e = getenv("SEEKR_FASTA_PIECE_BYTES")) piece_min = (size_t)std::max(1, atoi(e));  // tests: force stitching
+    const int want_threads = host_threads();
+    const size_t piece_min = (size_t)std::max(1, env_int("SEEKR_FASTA_PIECE_BYTES", 1 << 20));  // bytes below which another thread is not worth starting (tests: force stitching)
     const int n_pieces = (int)std::max<size_t>(1, std::min<size_t>((size_t)want_threads, fsize / piece_min));
     std::vector<size_t> cut((size_t)n_pieces + 1, fsize);
     cut[0] = 0;
